@@ -1,0 +1,174 @@
+/* uqhip.h -- C ABI of libuqhip.so: the MI355X (gfx950) implementation of the uQ encode/decode
+ * hot path.  This is the drop-in boundary: every entry point replaces one numpy / per-base-loop
+ * site of the reference (JohnLonginotto/uq, `uq.py`), cited as `uq.py:<lines>` on each.
+ *
+ * Conventions
+ *   - Every function returns 0 on success, non-zero on failure; the message is `uq_last_error()`
+ *     (thread-local).  Nothing throws across the ABI.
+ *   - `uq_ctx` binds one HIP device and one stream.  It is NOT thread-safe: the caller serialises,
+ *     as the single-threaded reference does.  Calls enqueue on the context's stream and are
+ *     synchronous at return only where they hand a value back to the host (`h_*` out-parameters).
+ *   - `d_*` pointers are device memory (from `uq_dev_alloc`, hipMalloc, or a torch tensor's
+ *     data_ptr()); `h_*` are host.  Buffers are caller-owned.  Scratch memory is owned by the
+ *     context and grows on demand (`uq_ctx_reserve` pre-sizes it).
+ *   - Tables are row-major `uint8[rows][cols]`, as the reference's numpy arrays (uq.py:178-181).
+ *   - Row permutations and keys are `uint32` on the device (< 2^32 rows per GPU); the host mirror
+ *     widens them where numpy would give int64.
+ */
+#ifndef UQHIP_H
+#define UQHIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UQ_ABI_VERSION 1
+#define UQ_NONE UINT64_MAX
+
+typedef struct uq_ctx uq_ctx;
+
+/* ---- context, memory, errors.  Replaces cffi -> libc malloc/free (uq.py:111-126, 712-713). */
+const char* uq_last_error(void);
+int uq_abi_version(void);
+int uq_device_count(int* h_count);
+/* `stream` = an existing hipStream_t (e.g. torch's current stream) or NULL for a private one. */
+int uq_ctx_create(int device, void* stream, uq_ctx** out);
+int uq_ctx_destroy(uq_ctx* ctx);
+int uq_ctx_reserve(uq_ctx* ctx, size_t scratch_bytes);
+int uq_ctx_sync(uq_ctx* ctx);
+int uq_dev_alloc(uq_ctx* ctx, size_t bytes, void** d_out);
+int uq_dev_free(uq_ctx* ctx, void* d_ptr);
+int uq_h2d(uq_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
+int uq_d2h(uq_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
+int uq_memset(uq_ctx* ctx, void* d_dst, int value, size_t bytes);
+/* Device-side timing on the context's stream (hipEvents), for bench.py's roofline leg. */
+int uq_timer_start(uq_ctx* ctx);
+int uq_timer_stop(uq_ctx* ctx, float* h_ms);
+
+/* ---- record index.  Replaces `wc -l` (uq.py:85) and the `next(f)` line iteration (uq.py:132-137).
+ * uq_count_lines: number of '\n' in d_buf[0, nbytes).
+ * uq_index_lines: d_line_start[k] = offset of the first byte of line k, k in [0, nlines];
+ *                 d_line_start[nlines] = offset one past the last '\n'.  nlines from uq_count_lines. */
+int uq_count_lines(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint64_t* h_nlines);
+int uq_index_lines(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint64_t nlines, uint64_t* d_line_start);
+
+/* ---- a1: pass-1 statistics.  Replaces uq.py:366-375, 382, 388, 415-425.
+ * counts[base * 256 + qual] over every (base, quality) pair of reads [0, nreads); DNA length range;
+ * the first record (if any) whose third line does not start with '+' or whose SEQ/QUAL lengths
+ * differ.  The struct lives in device memory; the caller zero-initialises it with uq_stats_init
+ * (so that several calls / shards accumulate) and copies it back with uq_d2h. */
+typedef struct uq_stats {
+    uint64_t counts[256 * 256];
+    uint64_t bad_plus;          /* smallest read index with a bad '+' line, or UQ_NONE   (uq.py:382) */
+    uint64_t bad_len;           /* smallest read index with len(SEQ) != len(QUAL)        (uq.py:388) */
+    uint32_t len_min, len_max;  /* uq.py:416-417 */
+    uint32_t max_record_bytes;  /* longest record (4 lines), sizing hint for the pack tiles */
+    uint32_t reserved;
+} uq_stats;
+int uq_stats_init(uq_ctx* ctx, uq_stats* d_stats);
+int uq_stats_accumulate(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start,
+                        uint64_t first_read, uint64_t nreads, uq_stats* d_stats);
+/* First occurrence of each base byte: d_first[b] = min over pairs of (read_index << 20 | position),
+ * or UQ_NONE.  Only needed to order N-trick candidates as the reference's dict does (uq.py:480). */
+int uq_first_occurrence(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start,
+                        uint64_t first_read, uint64_t nreads, uint64_t read_index_base, uint64_t* d_first /*[256], pre-set to UQ_NONE*/);
+
+/* ---- a3 / a4: the per-read packers.  Replaces `encoder_fixed` (uq.py:108-182) and
+ * `encoder_variable` (uq.py:188-254).  Row = sum_j code(read[j]) << (bits * (L-1-j)) [+ 1 << bits*L
+ * when `variable`], big-endian, right-aligned in `*_bytes_per_row` bytes, high bytes zero. */
+typedef struct uq_pack_params {
+    int16_t dna_code[256];      /* bases.index(byte), or -1 when the byte is not in `bases` (uq.py:149-152) */
+    int16_t qual_code[256];     /* qualities.index(byte), or -1 */
+    int32_t n_qual[256];        /* N_qual[byte] for bytes with dna_code == -1, else -1 (uq.py:153) */
+    int32_t bits_per_base, bits_per_quality;
+    int32_t variable;           /* 0 = encoder_fixed, 1 = encoder_variable */
+    int32_t dna_bytes_per_row, quality_bytes_per_row;
+    int32_t max_record_bytes;   /* from uq_stats (tile sizing) */
+    int32_t dna_max;            /* longest read */
+    int32_t reserved;
+} uq_pack_params;
+/* Packs reads [first_read, first_read + nreads) into d_dna / d_qual rows [0, nreads).
+ * *d_bad (device, 8 bytes, pre-set to UQ_NONE by the callee) = smallest local read index holding a
+ * symbol with no code, else UQ_NONE. */
+int uq_pack(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start, uint64_t first_read,
+            uint64_t nreads, const uq_pack_params* h_params, uint8_t* d_dna, uint8_t* d_qual, uint64_t* d_bad);
+
+/* ---- a9 / a11: the eight --pattern byte layouts.  Replaces numpy.rot90 + ascontiguousarray /
+ * asfortranarray + the payload write of numpy.save (uq.py:263-270) and, inverse, numpy.load +
+ * rot90(-k) (uq.py:943-945).  pattern_id = 2*k + (order == '.2'), k = rotations (so '0.1'=0,
+ * '0.2'=1, '1.1'=2, '1.2'=3, '2.1'=4, '2.2'=5, '3.1'=6, '3.2'=7).  d_payload is the rows*cols
+ * payload bytes in file order; the .npy header (shape, fortran_order) is host business. */
+int uq_pattern(uq_ctx* ctx, const uint8_t* d_table, uint64_t rows, uint32_t cols, int pattern_id, uint8_t* d_payload);
+int uq_unpattern(uq_ctx* ctx, const uint8_t* d_payload, uint64_t rows, uint32_t cols, int pattern_id, uint8_t* d_table);
+
+/* ---- a5: stable argsort of rows in memcmp order.  Replaces table.view('V<C>') +
+ * numpy.argsort(axis=0) (uq.py:773-775).  d_perm[j] = index of the j-th smallest row. */
+int uq_argsort_rows(uq_ctx* ctx, const uint8_t* d_table, uint64_t rows, uint32_t cols, uint32_t* d_perm);
+
+/* ---- a5 / a6 / a7 / a11: out[j] = table[index[j]].  Replaces table[sort_order] (uq.py:777),
+ * key[sort_order] (798), columns_data[idx][sort_order] (822), table[key] on decode (953, 957, 973).
+ * index_itemsize in {1,2,4,8} (keys are stored narrowed, uq.py:790). */
+int uq_gather_rows(uq_ctx* ctx, const uint8_t* d_table, uint64_t table_rows, uint32_t cols,
+                   const void* d_index, int index_itemsize, uint64_t n_out, uint8_t* d_out);
+
+/* ---- a6: unique rows + inverse.  Replaces numpy.unique(rows as void, return_inverse=True)
+ * (uq.py:784-789).  Outputs: d_perm = stable sort order of the rows (== argsort(key, stable),
+ * uq.py:796), d_key[i] = rank of row i among the distinct rows, d_sorted_key[j] = d_key[d_perm[j]]
+ * (uq.py:798), d_unique = the distinct rows in memcmp order (capacity rows*cols; pass NULL to skip),
+ * *h_nunique = their number.  Any of d_key / d_sorted_key / d_unique may be NULL. */
+int uq_unique_rows(uq_ctx* ctx, const uint8_t* d_table, uint64_t rows, uint32_t cols,
+                   uint32_t* d_perm, uint32_t* d_key, uint32_t* d_sorted_key, uint8_t* d_unique, uint64_t* h_nunique);
+
+/* ---- a6: key narrowing.  Replaces key.astype(numpy.min_scalar_type(max(key))) (uq.py:790, 832).
+ * uq_key_itemsize: 1/2/4/8 for the largest key value nunique-1.  uq_narrow: u32 -> u8/u16/u32/u64. */
+int uq_key_itemsize(uint64_t max_key);
+int uq_narrow(uq_ctx* ctx, const uint32_t* d_key, uint64_t n, int itemsize, void* d_out);
+
+/* ---- a7: QNAME column tables.  Replaces numpy.dstack(cols)[0] + structured view (uq.py:814-815,
+ * 828-829): rows of ncols fields, each widened to `common_itemsize` and stored BIG-endian so that
+ * memcmp order == field-by-field numeric order; then the row functions above apply.
+ * uq_unstack_column converts one field of such rows back to a little-endian column of out_itemsize
+ * (uq.py:846-847 `[:,idx].astype(dtype)`). */
+int uq_stack_columns(uq_ctx* ctx, const void* const* h_d_cols, const int* h_itemsize, int ncols,
+                     uint64_t n, int common_itemsize, uint8_t* d_rows);
+int uq_unstack_column(uq_ctx* ctx, const uint8_t* d_rows, uint64_t n, int ncols, int common_itemsize,
+                      int col, int out_itemsize, void* d_out);
+
+/* ---- a12: unpack.  Replaces split_bits + the per-symbol char map, N restore and sentinel strip of
+ * the decoder (uq.py:1002-1007, 1031-1054).  Outputs fixed-pitch text: d_seq / d_qualtxt are
+ * uint8[nreads][dna_max], left-aligned, d_len[r] = read length. */
+typedef struct uq_unpack_params {
+    uint8_t base_char[256];     /* bases[code] */
+    uint8_t qual_char[256];     /* qualities[code] (0 where undefined) */
+    uint8_t qual_n_base[256];   /* qual_N[code] = the base an N-trick quality code restores, else 0 (uq.py:999, 1036) */
+    int32_t bits_per_base, bits_per_quality;
+    int32_t variable;
+    int32_t dna_bytes_per_row, quality_bytes_per_row;
+    int32_t dna_max;
+} uq_unpack_params;
+int uq_unpack(uq_ctx* ctx, const uint8_t* d_dna, const uint8_t* d_qual, uint64_t nreads,
+              const uq_unpack_params* h_params, uint8_t* d_seq, uint8_t* d_qualtxt, uint32_t* d_len,
+              uint64_t* d_bad /* smallest row with no sentinel (variable) or UQ_NONE */);
+
+/* ---- synthetic FASTQ ("synth-v1"): workload generation for tests and bench.py.
+ * Byte-identical to uq_amd/synth.py.  uq_synth_size: total bytes of reads [first, first+n).
+ * uq_synth_fastq: writes them to d_out (capacity >= that size). */
+typedef struct uq_synth_spec {
+    uint64_t seed;
+    int32_t len_lo, len_hi;
+    int32_t n_rate;             /* percent of bases that are 'N' */
+    int32_t n_qual_exclusive;   /* 1: N <-> '!' exclusively; 0: N always '#', shared */
+    int32_t dup;                /* 0 none, 1 DNA, 2 QUAL, 3 both */
+    int32_t dup_templates;
+    int32_t skip_len_mod4;
+    int32_t reserved;
+} uq_synth_spec;
+int uq_synth_size(uq_ctx* ctx, const uq_synth_spec* h_spec, uint64_t first, uint64_t n, uint64_t* h_bytes);
+int uq_synth_fastq(uq_ctx* ctx, const uq_synth_spec* h_spec, uint64_t first, uint64_t n, uint8_t* d_out, uint64_t capacity);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UQHIP_H */

@@ -1,0 +1,210 @@
+"""GPU parity: record index, pass-1 statistics, packers and the synthetic generator, through the C ABI,
+against the oracle on the same seeded inputs.  Bit-exact (byte / integer work)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_c
+import uq_oracle as O
+from uq_amd import ops, synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+S = 20261003
+
+
+def _index(ctx, d_buf):
+    nlines = ops.count_lines(ctx, d_buf)
+    ls = ops.index_lines(ctx, d_buf, nlines)
+    return nlines, ls
+
+
+def _decide_from_stats(hs, notricks=False, pad=False, first_seen=None):
+    sq = O.histogram_to_static_qualities(hs.counts, first_seen)
+    return O.decide(sq, hs.len_min, hs.len_max, notricks, pad)
+
+
+def _gpu_pack(ctx, d_buf, ls, n, d, max_record_bytes):
+    p = ops.make_pack_params(d['bases'], d['qualities'], d['N_qual'], d['bits_per_base'], d['bits_per_quality'],
+                             d['variable_read_lengths'], d['dna_bytes_per_row'], d['quality_bytes_per_row'],
+                             d['dna_max'], max_record_bytes)
+    dna, qual, bad = ops.pack(ctx, d_buf, ls, 0, n, p)
+    return (ctx.to_numpy(dna).reshape(n, -1), ctx.to_numpy(qual).reshape(n, -1), ops.bad_index(bad))
+
+
+@pytest.mark.parametrize('n,length,kw', [
+    (1, 1, {}), (3, 7, {}), (1000, 100, {}), (5000, 150, {}), (777, (36, 301), dict(n_rate=1)),
+    (300, 50, dict(n_rate=3, n_qual_exclusive=False)), (513, (1, 9), {}),
+])
+def test_synth_matches_host(ctx, n, length, kw):
+    spec = synth.Spec(S + 2, length, **kw)
+    host = synth.fastq_array(spec, n, first=5)
+    dev = ops.synth_fastq(ctx, spec, 5, n)
+    assert np.array_equal(ctx.to_numpy(dev), host)
+
+
+@pytest.mark.parametrize('misalign', [0, 1, 7, 15])
+def test_index_lines(ctx, misalign):
+    spec = synth.Spec(S + 3, (36, 120), n_rate=1)
+    host = synth.fastq_array(spec, 20000)
+    t = ctx.torch
+    backing = ctx.empty(host.size + 64)
+    d_buf = backing[misalign:misalign + host.size]
+    d_buf.copy_(t.from_numpy(host))
+    nlines, ls = _index(ctx, d_buf)
+    ref = oracle_c.index_lines(host)
+    assert nlines == len(ref) - 1 == 80000
+    assert np.array_equal(ctx.to_numpy(ls, np.uint64), ref)
+
+
+def test_index_edge_cases(ctx):
+    t = ctx.torch
+    for data in [b'', b'\n', b'abc', b'abc\n', b'\n\n\n\n', b'a\nbb\nccc\ndddd', b'x' * 40000 + b'\n' + b'y' * 17]:
+        host = np.frombuffer(data, dtype=np.uint8)
+        d = ctx.empty(max(len(data), 1))[:len(data)]
+        if len(data): d.copy_(t.from_numpy(host.copy()))
+        nlines = ops.count_lines(ctx, d)
+        assert nlines == data.count(b'\n')
+        ls = ops.index_lines(ctx, d, nlines)
+        assert np.array_equal(ctx.to_numpy(ls, np.uint64), oracle_c.index_lines(host))
+
+
+@pytest.mark.parametrize('n,length,kw', [
+    (2000, 100, {}), (3000, (36, 301), dict(n_rate=1)), (500, 50, dict(n_rate=3, n_qual_exclusive=False)),
+    (1, 5, {}), (2, (1, 3), {}),
+])
+def test_stats(ctx, n, length, kw):
+    spec = synth.Spec(S + 4, length, **kw)
+    host = synth.fastq_array(spec, n)
+    d_buf = ctx.to_device(host)
+    nlines, ls = _index(ctx, d_buf)
+    st = ops.stats_new(ctx)
+    ops.stats_accumulate(ctx, st, d_buf, ls, 0, n)
+    hs = ops.stats_fetch(ctx, st)
+    ref = oracle_c.stats(host, oracle_c.index_lines(host), 0, n)
+    assert np.array_equal(hs.counts, ref['counts'])
+    assert (hs.len_min, hs.len_max, hs.max_record_bytes) == (ref['len_min'], ref['len_max'], ref['max_record_bytes'])
+    assert hs.bad_plus is None and hs.bad_len is None
+    fs = ops.first_occurrence(ctx, d_buf, ls, 0, n)
+    assert np.array_equal(fs, ref['first_seen'])
+
+
+def test_stats_unusual_bytes_and_bad_records(ctx):
+    recs = [b'@r:1:1\nACGTZ\x80\xff\n+\n!~\x01\x02\xfe\xff\x7f\n', b'@r:2:2\nAC\n-\nII\n', b'@r:3:3\nACG\n+\nII\n', b'@r:4:4\nA\n+\nI\n']
+    data = b''.join(recs)
+    host = np.frombuffer(data, dtype=np.uint8).copy()
+    d_buf = ctx.to_device(host)
+    nlines, ls = _index(ctx, d_buf)
+    st = ops.stats_new(ctx)
+    ops.stats_accumulate(ctx, st, d_buf, ls, 0, 4)
+    hs = ops.stats_fetch(ctx, st)
+    ref = oracle_c.stats(host, oracle_c.index_lines(host), 0, 4)
+    assert np.array_equal(hs.counts, ref['counts'])
+    assert hs.bad_plus == 1 and hs.bad_len == 2
+    # shards accumulate into the same struct
+    st2 = ops.stats_new(ctx)
+    ops.stats_accumulate(ctx, st2, d_buf, ls, 0, 1)
+    ops.stats_accumulate(ctx, st2, d_buf, ls, 1, 3)
+    hs2 = ops.stats_fetch(ctx, st2)
+    assert np.array_equal(hs2.counts, ref['counts']) and hs2.bad_plus == 1 and hs2.bad_len == 2
+
+
+PACK_CASES = [
+    ('fixed100', 3000, 100, {}, {}),
+    ('fixed150', 4096 + 37, 150, {}, {}),
+    ('len1', 100, 1, {}, {}),
+    ('len4_bits8', 64, 4, {}, {}),                          # b*L % 8 == 0, fixed
+    ('var_ntrick', 3000, (36, 301), dict(n_rate=1), {}),    # 2-bit DNA via the N-trick, variable, all L mod 4
+    ('var_notricks', 3000, (36, 301), dict(n_rate=1), dict(notricks=True)),   # 3-bit ACGNT
+    ('var_pad', 1000, (20, 77), dict(n_rate=2), dict(notricks=True, pad=True)),  # 4-bit / 8-bit
+    ('n_newcode', 1500, 50, dict(n_rate=3, n_qual_exclusive=False), {}),      # N_qual = 42 (skips a code), 6 bits
+    ('short_var', 2000, (1, 12), {}, {}),
+]
+
+
+@pytest.mark.parametrize('name,n,length,kw,dk', PACK_CASES, ids=[c[0] for c in PACK_CASES])
+def test_pack_matches_oracle(ctx, name, n, length, kw, dk):
+    spec = synth.Spec(S + 5, length, **kw)
+    host = synth.fastq_array(spec, n)
+    d_buf = ctx.to_device(host)
+    nlines, ls = _index(ctx, d_buf)
+    assert nlines == 4 * n
+    st = ops.stats_new(ctx)
+    ops.stats_accumulate(ctx, st, d_buf, ls, 0, n)
+    hs = ops.stats_fetch(ctx, st)
+    d = _decide_from_stats(hs, **dk)
+    dna, qual, bad = _gpu_pack(ctx, d_buf, ls, n, d, hs.max_record_bytes)
+    assert bad is None
+    hls = oracle_c.index_lines(host)
+    rd, rq, rbad = oracle_c.pack(host, hls, 0, n, d['bases'], d['qualities'], d['N_qual'], d['bits_per_base'],
+                                 d['bits_per_quality'], d['variable_read_lengths'], d['dna_bytes_per_row'],
+                                 d['quality_bytes_per_row'])
+    assert rbad is None
+    assert np.array_equal(dna, rd)
+    assert np.array_equal(qual, rq)
+    # and the faithful Python loop on a prefix (the C loop is itself checked against it on CPU)
+    m = min(n, 200)
+    lines = O.read_lines(host.tobytes())
+    pd_, pq_ = O.encoder(lines, d['bases'], d['qualities'], d['N_qual'], d['dna_bytes_per_row'],
+                         d['quality_bytes_per_row'], d['bits_per_base'], d['bits_per_quality'],
+                         d['variable_read_lengths'], count=m)
+    assert np.array_equal(dna[:m], pd_) and np.array_equal(qual[:m], pq_)
+
+
+def test_pack_q9_carry_path(ctx):
+    """3 qualities + one NEW N code -> total_quals = 4 -> 2 bits, N_qual = 4 = 2^b: the `+=` carries (Q9)."""
+    recs = []
+    rng = np.random.RandomState(7)
+    for i in range(400):
+        L = 21
+        seq = ''.join('ACGTN'[k] for k in rng.choice(5, L, p=[.23, .23, .23, .23, .08]))
+        q = ''.join('I' if c == 'N' else '#HI'[rng.randint(3)] for c in seq)
+        recs.append('@q:%d:%d\n%s\n+\n%s\n' % (i % 3, i, seq, q))
+    data = ''.join(recs).encode()
+    host = np.frombuffer(data, dtype=np.uint8).copy()
+    lines = O.read_lines(data)
+    p1 = O.pass1(lines)
+    d = O.decide(p1['static_qualities'], p1['dna_min'], p1['dna_max'])
+    assert d['N_qual'] == {'N': 4} and d['bits_per_quality'] == 2
+    rd, rq = O.encoder(lines, d['bases'], d['qualities'], d['N_qual'], d['dna_bytes_per_row'], d['quality_bytes_per_row'],
+                       d['bits_per_base'], d['bits_per_quality'], d['variable_read_lengths'])
+    d_buf = ctx.to_device(host)
+    nlines, ls = _index(ctx, d_buf)
+    dna, qual, bad = _gpu_pack(ctx, d_buf, ls, 400, d, 128)
+    assert bad is None
+    assert np.array_equal(dna, rd) and np.array_equal(qual, rq)
+
+
+def test_pack_reports_uncoded_symbol(ctx):
+    data = b'@a:1\nACGT\n+\nIIII\n@a:2\nACXT\n+\nIIII\n'
+    host = np.frombuffer(data, dtype=np.uint8).copy()
+    d_buf = ctx.to_device(host)
+    nlines, ls = _index(ctx, d_buf)
+    p = ops.make_pack_params('ACGT', 'I', {}, 2, 2, False, 1, 1, 4, 64)
+    dna, qual, bad = ops.pack(ctx, d_buf, ls, 0, 2, p)
+    assert ops.bad_index(bad) == 1
+
+
+@pytest.mark.parametrize('name', ['cfg1_10k_100bp', 'fixed_n_newcode', 'variable_ntrick', 'variable_notricks', 'fixed_pad'])
+def test_pack_matches_reference_golden(ctx, name):
+    """DNA.raw / QUAL.raw written by the reference itself (tests/golden/*.uQ) == the HIP packers' rows."""
+    meta = json.load(open(os.path.join(GOLD, name + '.json')))
+    data = open(os.path.join(GOLD, name + '.fastq'), 'rb').read()
+    cfg, members = O.read_tar(os.path.join(GOLD, name + '.uQ'))
+    host = np.frombuffer(data, dtype=np.uint8).copy()
+    d_buf = ctx.to_device(host)
+    nlines, ls = _index(ctx, d_buf)
+    n = nlines // 4
+    st = ops.stats_new(ctx)
+    ops.stats_accumulate(ctx, st, d_buf, ls, 0, n)
+    hs = ops.stats_fetch(ctx, st)
+    fs = ops.first_occurrence(ctx, d_buf, ls, 0, n)
+    d = _decide_from_stats(hs, notricks='--notricks' in meta['flags'], pad='--pad' in meta['flags'], first_seen=fs)
+    assert d['bases'] == cfg['bases'] and d['qualities'] == cfg['qualities'] and d['N_qual'] == cfg['N_qual']
+    assert d['bits_per_base'] == cfg['bits_per_base'] and d['bits_per_quality'] == cfg['bits_per_quality']
+    dna, qual, bad = _gpu_pack(ctx, d_buf, ls, n, d, hs.max_record_bytes)
+    assert bad is None
+    assert np.array_equal(dna, O.unpattern(members['DNA.raw']))
+    assert np.array_equal(qual, O.unpattern(members['QUAL.raw']))

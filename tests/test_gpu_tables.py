@@ -1,0 +1,174 @@
+"""GPU parity for the table-build and layout kernels through the C ABI: the eight --pattern layouts and
+their inverses, row argsort, gather, unique/inverse, key narrowing, QNAME column stacking, unpack.
+Oracle = numpy as the reference uses it (oracle/uq_oracle.py) + the closed forms of oracle/uq_oracle.c.
+Bit-exact."""
+import numpy as np
+import pytest
+
+import oracle_c
+import uq_oracle as O
+from uq_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(ctx, a):
+    return ctx.to_device(np.ascontiguousarray(a))
+
+
+SHAPES = [(1, 1), (1, 7), (5, 1), (4, 3), (64, 38), (1000, 38), (4097, 113), (333, 227), (3000, 25), (70000, 14), (2, 300), (17, 16), (1025, 4)]
+
+
+@pytest.mark.parametrize('shape', SHAPES, ids=lambda s: '%dx%d' % s)
+@pytest.mark.parametrize('pat', O.PATTERNS)
+def test_pattern_payload_and_inverse(ctx, shape, pat):
+    R, C = shape
+    rng = np.random.RandomState(R * 131 + C)
+    T = rng.randint(0, 256, size=(R, C)).astype(np.uint8)
+    # numpy.save writes the array in its own memory order: compare with the bytes after the header
+    npy = O.write_pattern(T, pat)
+    payload = np.frombuffer(npy, dtype=np.uint8)[-R * C:]
+    assert np.array_equal(payload, oracle_c.pattern(T, ops.PATTERN_IDS[pat]))   # closed form == numpy
+    d_T = _dev(ctx, T.ravel())
+    out = ops.pattern(ctx, d_T, R, C, pat)
+    assert np.array_equal(ctx.to_numpy(out), payload)
+    back = ops.unpattern(ctx, out, R, C, pat)
+    assert np.array_equal(ctx.to_numpy(back).reshape(R, C), T)
+
+
+def test_pattern_misaligned_buffers(ctx):
+    R, C = 777, 38
+    rng = np.random.RandomState(3)
+    T = rng.randint(0, 256, size=(R, C)).astype(np.uint8)
+    for off_in, off_out in [(1, 0), (0, 3), (5, 9), (15, 2)]:
+        back_in = ctx.empty(R * C + 32); back_out = ctx.empty(R * C + 32)
+        d_T = back_in[off_in:off_in + R * C]; d_T.copy_(ctx.torch.from_numpy(T.ravel()))
+        d_o = back_out[off_out:off_out + R * C]
+        for pat in O.PATTERNS:
+            ops.pattern(ctx, d_T, R, C, pat, out=d_o)
+            assert np.array_equal(ctx.to_numpy(d_o), oracle_c.pattern(T, ops.PATTERN_IDS[pat])), pat
+            back = ops.unpattern(ctx, d_o, R, C, pat)
+            assert np.array_equal(ctx.to_numpy(back).reshape(R, C), T), pat
+
+
+def _rows_with_dups(rng, n, C, ndistinct, prefix=0):
+    """n rows drawn from `ndistinct` distinct random rows; optional long common prefix."""
+    base = rng.randint(0, 256, size=(ndistinct, C)).astype(np.uint8)
+    if prefix:
+        base[:, :prefix] = base[0, :prefix]
+    # make some rows differ only in the LAST byte / only inside a middle chunk
+    if ndistinct > 4 and C > 9:
+        base[1] = base[0]; base[1, -1] ^= 1
+        base[2] = base[0]; base[2, 8] ^= 0x80
+    return base[rng.randint(0, ndistinct, size=n)]
+
+
+SORT_CASES = [(1, 5, 1, 0), (2, 1, 2, 0), (1000, 1, 7, 0), (5000, 8, 5000, 0), (5000, 38, 300, 0), (20000, 38, 20000, 0),
+              (9000, 113, 500, 40), (3000, 227, 50, 100), (4096, 16, 16, 8), (10000, 9, 3, 0), (70000, 14, 60000, 0)]
+
+
+@pytest.mark.parametrize('n,C,nd,prefix', SORT_CASES, ids=lambda v: str(v))
+def test_argsort_rows_stable(ctx, n, C, nd, prefix):
+    rng = np.random.RandomState(n + C)
+    T = _rows_with_dups(rng, n, C, nd, prefix)
+    perm = ops.argsort_rows(ctx, _dev(ctx, T.ravel()), n, C)
+    got = ctx.to_numpy(perm, np.uint32).astype(np.int64)
+    assert np.array_equal(got, O.argsort_rows(T))
+
+
+@pytest.mark.parametrize('n,C,nd,prefix', SORT_CASES, ids=lambda v: str(v))
+def test_unique_rows(ctx, n, C, nd, prefix):
+    rng = np.random.RandomState(n * 3 + C)
+    T = _rows_with_dups(rng, n, C, nd, prefix)
+    perm, key, skey, uniq, nu = ops.unique_rows(ctx, _dev(ctx, T.ravel()), n, C)
+    ru, rkey = O.unique_rows(T)
+    assert nu == len(ru)
+    assert np.array_equal(ctx.to_numpy(uniq).reshape(nu, C), ru)
+    k = ctx.to_numpy(key, np.uint32).astype(np.int64)
+    assert np.array_equal(k, rkey)
+    order = np.argsort(rkey, kind='stable')
+    assert np.array_equal(ctx.to_numpy(perm, np.uint32).astype(np.int64), order)
+    assert np.array_equal(ctx.to_numpy(skey, np.uint32).astype(np.int64), rkey[order])
+    # narrowing (uq.py:790)
+    isz = ops.key_itemsize(nu - 1)
+    assert isz == O.narrow_key(rkey).dtype.itemsize
+    nk = ops.narrow(ctx, key, isz)
+    assert np.array_equal(ctx.to_numpy(nk, O.narrow_key(rkey).dtype), O.narrow_key(rkey))
+
+
+@pytest.mark.parametrize('n,C', [(1, 1), (100, 38), (5000, 113), (3000, 227), (4097, 25), (10, 300), (50000, 14)])
+@pytest.mark.parametrize('isz', [1, 2, 4, 8])
+def test_gather_rows(ctx, n, C, isz):
+    rng = np.random.RandomState(n + C + isz)
+    rows = min(n, 200) if isz == 1 else n
+    T = rng.randint(0, 256, size=(rows, C)).astype(np.uint8)
+    dt = {1: np.uint8, 2: np.uint16, 4: np.uint32, 8: np.uint64}[isz]
+    idx = rng.randint(0, min(rows, np.iinfo(dt).max + 1), size=n + 13).astype(dt)
+    out = ops.gather_rows(ctx, _dev(ctx, T.ravel()), rows, C, _dev(ctx, idx))
+    assert np.array_equal(ctx.to_numpy(out).reshape(-1, C), T[idx.astype(np.int64)])
+
+
+@pytest.mark.parametrize('dt', [np.uint8, np.uint16, np.uint32, np.uint64])
+def test_gather_items(ctx, dt):
+    rng = np.random.RandomState(5)
+    src = rng.randint(0, np.iinfo(dt).max, size=7001, dtype=np.uint64).astype(dt)
+    idx = rng.randint(0, 7001, size=9000).astype(np.uint32)
+    out = ops.gather_rows(ctx, _dev(ctx, src).view(ctx.torch.uint8), 7001, src.dtype.itemsize, _dev(ctx, idx))
+    assert np.array_equal(ctx.to_numpy(out).view(dt), src[idx])
+
+
+def test_qname_column_stack_sort_unique(ctx):
+    rng = np.random.RandomState(11)
+    n = 6000
+    cols = [rng.randint(0, 4, n).astype(np.uint8), rng.randint(0, 300, n).astype(np.uint16),
+            rng.randint(0, 70000, n).astype(np.uint32), rng.randint(0, 3, n).astype(np.uint8)]
+    cols[2][::7] = cols[2][0]
+    d_cols = [_dev(ctx, c) for c in cols]
+    common = 4
+    rows = ops.stack_columns(ctx, d_cols, common)
+    stacked = np.dstack(cols)[0]
+    be = stacked.astype('>u4').view(np.uint8).reshape(n, -1)
+    assert np.array_equal(ctx.to_numpy(rows).reshape(n, -1), be)
+    # lexicographic field order == memcmp order of the big-endian rows
+    perm = ops.argsort_rows(ctx, rows, n, 4 * common)
+    ref = np.lexsort([stacked[:, c] for c in range(3, -1, -1)])
+    assert np.array_equal(ctx.to_numpy(perm, np.uint32).astype(np.int64), ref)
+    perm, key, skey, uniq, nu = ops.unique_rows(ctx, rows, n, 4 * common)
+    ru, rinv = np.unique(stacked, axis=0, return_inverse=True)
+    assert nu == len(ru) and np.array_equal(ctx.to_numpy(key, np.uint32), rinv.ravel())
+    for c in range(4):
+        col = ops.unstack_column(ctx, uniq, nu, 4, common, c, cols[c].dtype.itemsize)
+        assert np.array_equal(ctx.to_numpy(col, cols[c].dtype), ru[:, c].astype(cols[c].dtype))
+
+
+UNPACK_CASES = [('fixed', 2000, 100, {}, {}), ('var_ntrick', 3000, (36, 301), dict(n_rate=1), {}),
+                ('var_notricks', 2000, (20, 150), dict(n_rate=2), dict(notricks=True)),
+                ('var_pad', 500, (1, 40), dict(n_rate=2), dict(notricks=True, pad=True)), ('len1', 50, 1, {}, {})]
+
+
+@pytest.mark.parametrize('name,n,length,kw,dk', UNPACK_CASES, ids=[c[0] for c in UNPACK_CASES])
+def test_unpack_roundtrip(ctx, name, n, length, kw, dk):
+    from uq_amd import synth
+    spec = synth.Spec(20261010, length, **kw)
+    host = synth.fastq_array(spec, n)
+    hls = oracle_c.index_lines(host)
+    st = oracle_c.stats(host, hls, 0, n)
+    d = O.decide(O.histogram_to_static_qualities(st['counts'], st['first_seen']), st['len_min'], st['len_max'], **dk)
+    rd, rq, _ = oracle_c.pack(host, hls, 0, n, d['bases'], d['qualities'], d['N_qual'], d['bits_per_base'], d['bits_per_quality'],
+                              d['variable_read_lengths'], d['dna_bytes_per_row'], d['quality_bytes_per_row'])
+    cfg = dict(bases=d['bases'], qualities=d['qualities'], N_qual=d['N_qual'], bits_per_base=d['bits_per_base'],
+               bits_per_quality=d['bits_per_quality'], variable_read_lengths=d['variable_read_lengths'], dna_max=d['dna_max'])
+    p = ops.make_unpack_params(cfg)
+    seq, qt, ln, bad = ops.unpack(ctx, _dev(ctx, rd.ravel()), _dev(ctx, rq.ravel()), n, p)
+    assert ops.bad_index(bad) is None
+    rs, rqt, rln, rbad = oracle_c.unpack(rd, rq, cfg)
+    assert rbad is None
+    assert np.array_equal(ctx.to_numpy(ln, np.uint32), rln)
+    assert np.array_equal(ctx.to_numpy(seq).reshape(n, -1), rs)
+    assert np.array_equal(ctx.to_numpy(qt).reshape(n, -1), rqt)
+    # and the text really is the input
+    lines = host.tobytes().split(b'\n')
+    S = ctx.to_numpy(seq).reshape(n, -1); Q = ctx.to_numpy(qt).reshape(n, -1); L = ctx.to_numpy(ln, np.uint32)
+    for r in range(0, n, max(1, n // 97)):
+        assert S[r, :L[r]].tobytes() == lines[4 * r + 1]
+        assert Q[r, :L[r]].tobytes() == lines[4 * r + 3]

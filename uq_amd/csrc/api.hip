@@ -1,0 +1,132 @@
+// api.hip -- context, memory and error entry points of the C ABI (include/uqhip.h).
+// Replaces the reference's cffi -> libc malloc/free ownership (uq.py:111-126, 712-713).
+#include <stdarg.h>
+#include "common.h"
+
+static thread_local char g_err[1024] = "";
+
+void uq_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* uq_last_error(void) { return g_err; }
+extern "C" int uq_abi_version(void) { return UQ_ABI_VERSION; }
+
+extern "C" int uq_device_count(int* h_count) {
+    UQ_REQUIRE(h_count, "uq_device_count: null out pointer");
+    UQ_CHECK_HIP(hipGetDeviceCount(h_count));
+    return 0;
+}
+
+extern "C" int uq_ctx_create(int device, void* stream, uq_ctx** out) {
+    UQ_REQUIRE(out, "uq_ctx_create: null out pointer");
+    int n = 0;
+    UQ_CHECK_HIP(hipGetDeviceCount(&n));
+    UQ_REQUIRE(device >= 0 && device < n, "uq_ctx_create: device %d out of range (%d visible)", device, n);
+    UQ_CHECK_HIP(hipSetDevice(device));
+    uq_ctx* c = new uq_ctx();
+    memset(c, 0, sizeof(*c));
+    c->device = device;
+    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+    else { UQ_CHECK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    UQ_CHECK_HIP(hipEventCreate(&c->ev0));
+    UQ_CHECK_HIP(hipEventCreate(&c->ev1));
+    UQ_CHECK_HIP(hipHostMalloc((void**)&c->h_pinned, 65536, hipHostMallocDefault));
+    *out = c;
+    return 0;
+}
+
+extern "C" int uq_ctx_destroy(uq_ctx* c) {
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->scratch) (void)hipFree(c->scratch);
+    if (c->idx_partials) (void)hipFree(c->idx_partials);
+    if (c->scan_ws) (void)hipFree(c->scan_ws);
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    (void)hipEventDestroy(c->ev0);
+    (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+int uq_scratch(uq_ctx* c, size_t bytes, void** out) {
+    if (bytes > c->scratch_bytes) {
+        UQ_CHECK_HIP(hipSetDevice(c->device));
+        UQ_CHECK_HIP(hipStreamSynchronize(c->stream));
+        if (c->scratch) { UQ_CHECK_HIP(hipFree(c->scratch)); c->scratch = nullptr; c->scratch_bytes = 0; }
+        size_t want = (bytes + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);
+        UQ_CHECK_HIP(hipMalloc(&c->scratch, want));
+        c->scratch_bytes = want;
+    }
+    *out = c->scratch;
+    return 0;
+}
+
+extern "C" int uq_ctx_reserve(uq_ctx* c, size_t bytes) {
+    UQ_REQUIRE(c, "null context");
+    void* p;
+    return uq_scratch(c, bytes, &p);
+}
+
+extern "C" int uq_ctx_sync(uq_ctx* c) {
+    UQ_REQUIRE(c, "null context");
+    UQ_CHECK_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int uq_dev_alloc(uq_ctx* c, size_t bytes, void** d_out) {
+    UQ_REQUIRE(c && d_out, "uq_dev_alloc: null argument");
+    UQ_CHECK_HIP(hipSetDevice(c->device));
+    UQ_CHECK_HIP(hipMalloc(d_out, bytes ? bytes : 1));
+    return 0;
+}
+
+extern "C" int uq_dev_free(uq_ctx* c, void* p) {
+    UQ_REQUIRE(c, "null context");
+    if (!p) return 0;
+    UQ_CHECK_HIP(hipStreamSynchronize(c->stream));
+    UQ_CHECK_HIP(hipFree(p));
+    return 0;
+}
+
+extern "C" int uq_h2d(uq_ctx* c, void* d_dst, const void* h_src, size_t bytes) {
+    UQ_REQUIRE(c, "null context");
+    if (!bytes) return 0;
+    UQ_CHECK_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, c->stream));
+    UQ_CHECK_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int uq_d2h(uq_ctx* c, void* h_dst, const void* d_src, size_t bytes) {
+    UQ_REQUIRE(c, "null context");
+    if (!bytes) return 0;
+    UQ_CHECK_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    UQ_CHECK_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int uq_memset(uq_ctx* c, void* d_dst, int value, size_t bytes) {
+    UQ_REQUIRE(c, "null context");
+    if (!bytes) return 0;
+    UQ_CHECK_HIP(hipMemsetAsync(d_dst, value, bytes, c->stream));
+    return 0;
+}
+
+extern "C" int uq_timer_start(uq_ctx* c) {
+    UQ_REQUIRE(c, "null context");
+    UQ_CHECK_HIP(hipEventRecord(c->ev0, c->stream));
+    return 0;
+}
+
+extern "C" int uq_timer_stop(uq_ctx* c, float* h_ms) {
+    UQ_REQUIRE(c && h_ms, "uq_timer_stop: null argument");
+    UQ_CHECK_HIP(hipEventRecord(c->ev1, c->stream));
+    UQ_CHECK_HIP(hipEventSynchronize(c->ev1));
+    UQ_CHECK_HIP(hipEventElapsedTime(h_ms, c->ev0, c->ev1));
+    return 0;
+}

@@ -1,0 +1,130 @@
+// gather.hip -- out[j] = table[index[j]] for rows of C bytes.
+// Replaces table[sort_order] (uq.py:777), key[sort_order] (798), columns_data[idx][sort_order] (822)
+// and, on decode, table[key] (953, 957, 973).
+//
+// A workgroup produces TR consecutive OUTPUT rows (one contiguous span -> 16-byte coalesced stores).
+// Each source row is fetched by a group of lanes as the aligned dwords that cover it (rows start at
+// arbitrary byte offsets) into an LDS slot with its 0..3 byte skew noted; the emit pass reads bytes
+// back in output order.  Small items (1/2/4/8-byte keys and QNAME columns) take a direct typed path.
+// Algorithmic HBM bytes per output row: 2 * C + index itemsize.
+#include "common.h"
+#include "tile_io.h"
+
+namespace {
+constexpr int GT = TIO_THREADS;
+
+__device__ __forceinline__ uint64_t load_index(const void* idx, int itemsize, uint64_t j) {
+    switch (itemsize) {
+        case 1: return ((const uint8_t*)idx)[j];
+        case 2: return ((const uint16_t*)idx)[j];
+        case 4: return ((const uint32_t*)idx)[j];
+        default: return ((const uint64_t*)idx)[j];
+    }
+}
+
+template <typename T>
+__global__ void gather_items_kernel(const T* __restrict__ table, uint64_t table_rows, const void* __restrict__ idx, int itemsize,
+                                    uint64_t n, T* __restrict__ out) {
+    uint64_t j = (uint64_t)blockIdx.x * GT + threadIdx.x;
+    if (j >= n) return;
+    uint64_t r = load_index(idx, itemsize, j);
+    if (r >= table_rows) r = 0;
+    out[j] = table[r];
+}
+
+struct GatherGeom {
+    uint64_t table_rows, n_out;
+    uint32_t C, TR, P;       // P = LDS pitch per row in dwords
+    uint32_t G;              // lanes per row group (power of two <= 64)
+    uint32_t magicC;
+};
+
+struct GatherFn {
+    const uint8_t* lds; const uint8_t* skew; const GatherGeom& g;
+    __device__ __forceinline__ void divmod(uint32_t k, uint32_t& q, uint32_t& rem) const {
+        fast_divmod(k, g.C, g.magicC, q, rem);
+    }
+    __device__ __forceinline__ uint8_t at(uint32_t i, uint32_t c) const { return lds[i * (g.P * 4) + skew[i] + c]; }
+    __device__ __forceinline__ uint8_t byte(uint32_t k) const { uint32_t i, c; divmod(k, i, c); return at(i, c); }
+    __device__ __forceinline__ void operator()(uint32_t k0, uint32_t* w) const {
+        uint32_t i, c; divmod(k0, i, c);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                v |= (uint32_t)at(i, c) << (8 * b);
+                if (++c == g.C) { c = 0; ++i; }
+            }
+            w[d] = v;
+        }
+    }
+};
+
+__global__ __launch_bounds__(GT) void gather_rows_kernel(const uint8_t* __restrict__ table, const void* __restrict__ idx, int itemsize,
+                                                         GatherGeom g, uint8_t* __restrict__ out) {
+    extern __shared__ __align__(16) uint8_t smem[];   // [TR][P dwords] + skew[TR]
+    uint8_t* skew = smem + (size_t)g.TR * g.P * 4;
+    uint32_t* lds32 = (uint32_t*)smem;
+    const uint64_t j0 = (uint64_t)blockIdx.x * g.TR;
+    const uint32_t n = (uint32_t)((g.n_out - j0) < g.TR ? (g.n_out - j0) : g.TR);
+    const uint32_t gl = threadIdx.x & (g.G - 1);          // lane inside the row group
+    const uint32_t groups = GT / g.G;
+    for (uint32_t i = threadIdx.x / g.G; i < n; i += groups) {
+        uint64_t r = load_index(idx, itemsize, j0 + i);
+        if (r >= g.table_rows) r = 0;
+        const uint8_t* s = table + r * g.C;
+        const uint32_t sk = (uint32_t)((uintptr_t)s & 3);
+        const uint32_t* s32 = (const uint32_t*)(s - sk);
+        const uint32_t nd = (sk + g.C + 3) >> 2;
+        for (uint32_t d = gl; d < nd; d += g.G) lds32[i * g.P + d] = s32[d];
+        if (gl == 0) skew[i] = (uint8_t)sk;
+    }
+    __syncthreads();
+    GatherFn fn{smem, skew, g};
+    emit_span(out + j0 * g.C, n * g.C, fn);
+}
+}  // namespace
+
+int uq_gather_rows_internal(uq_ctx* ctx, const uint8_t* d_table, uint64_t table_rows, uint32_t cols, const void* d_index,
+                            int index_itemsize, uint64_t n_out, uint8_t* d_out) {
+    UQ_REQUIRE(ctx, "null context");
+    UQ_REQUIRE(index_itemsize == 1 || index_itemsize == 2 || index_itemsize == 4 || index_itemsize == 8,
+               "uq_gather_rows: index itemsize %d not in {1,2,4,8}", index_itemsize);
+    UQ_REQUIRE(cols >= 1, "uq_gather_rows: rows need at least one byte");
+    if (n_out == 0) return 0;
+    UQ_REQUIRE(d_table && d_index && d_out && table_rows > 0, "uq_gather_rows: null / empty table");
+    const uint32_t blocks1 = (uint32_t)((n_out + GT - 1) / GT);
+    const bool aligned = (((uintptr_t)d_table | (uintptr_t)d_out) & (cols - 1)) == 0;
+    if (aligned && cols == 1) { gather_items_kernel<uint8_t><<<blocks1, GT, 0, ctx->stream>>>((const uint8_t*)d_table, table_rows, d_index, index_itemsize, n_out, (uint8_t*)d_out); UQ_LAUNCH_CHECK(); return 0; }
+    if (aligned && cols == 2) { gather_items_kernel<uint16_t><<<blocks1, GT, 0, ctx->stream>>>((const uint16_t*)d_table, table_rows, d_index, index_itemsize, n_out, (uint16_t*)d_out); UQ_LAUNCH_CHECK(); return 0; }
+    if (aligned && cols == 4) { gather_items_kernel<uint32_t><<<blocks1, GT, 0, ctx->stream>>>((const uint32_t*)d_table, table_rows, d_index, index_itemsize, n_out, (uint32_t*)d_out); UQ_LAUNCH_CHECK(); return 0; }
+    if (aligned && cols == 8) { gather_items_kernel<uint64_t><<<blocks1, GT, 0, ctx->stream>>>((const uint64_t*)d_table, table_rows, d_index, index_itemsize, n_out, (uint64_t*)d_out); UQ_LAUNCH_CHECK(); return 0; }
+
+    GatherGeom g;
+    g.table_rows = table_rows; g.n_out = n_out; g.C = cols;
+    g.magicC = magic_u32(cols);
+    const uint32_t nd_max = (cols + 6) >> 2;
+    g.P = nd_max | 1;                         // odd pitch: consecutive rows start on different banks
+    uint32_t G = 1;
+    while (G < nd_max && G < 64) G <<= 1;
+    g.G = G;
+    UQ_REQUIRE((size_t)g.P * 4 + 1 <= 150 * 1024, "uq_gather_rows: %u-byte rows do not fit one LDS tile", cols);
+    uint32_t TR = (48 * 1024) / (g.P * 4 + 1);
+    if (TR >= 16) TR &= ~15u;
+    if (TR == 0) TR = 1;
+    if (TR > 1024) TR = 1024;
+    g.TR = TR;
+    const size_t lds = (size_t)TR * g.P * 4 + TR + 16;
+    const uint64_t tiles = (n_out + TR - 1) / TR;
+    UQ_REQUIRE(tiles <= 0x7fffffffu, "uq_gather_rows: too many tiles");
+    if (lds > 48 * 1024) UQ_CHECK_HIP(hipFuncSetAttribute((const void*)gather_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    gather_rows_kernel<<<(uint32_t)tiles, GT, lds, ctx->stream>>>(d_table, d_index, index_itemsize, g, d_out);
+    UQ_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int uq_gather_rows(uq_ctx* ctx, const uint8_t* d_table, uint64_t table_rows, uint32_t cols, const void* d_index,
+                              int index_itemsize, uint64_t n_out, uint8_t* d_out) {
+    return uq_gather_rows_internal(ctx, d_table, table_rows, cols, d_index, index_itemsize, n_out, d_out);
+}

@@ -1,0 +1,240 @@
+// pattern.hip -- the eight --pattern byte layouts and their inverses.
+// Replaces numpy.rot90 + ascontiguousarray / asfortranarray + the payload write of numpy.save
+// (uq.py:263-270) and numpy.load + rot90(-k) on decode (uq.py:943-945).
+//
+// With T[r][c] an R x C byte table, ro(r) = r or R-1-r and co(c) = c or C-1-c, the eight payloads are
+//     row-major     out[ro(r) * C + co(c)] = T[r][c]     0.1 (-,-)  1.2 (-,c)  3.2 (r,-)  2.1 (r,c)
+//     column-major  out[co(c) * R + ro(r)] = T[r][c]     0.2 (-,-)  1.1 (-,c)  3.1 (r,-)  2.2 (r,c)
+// (byte streams verified against numpy).  ro/co are involutions, so the row-major
+// kernel is its own inverse; the column-major family has a forward and an inverse kernel.
+//
+// All three kernels move a tile of TR table rows through LDS: the row-major side of a tile is one
+// contiguous span (16-byte coalesced loads/stores), the column-major side is C runs of TR bytes
+// (dword loads/stores, realigned with v_alignbyte when R is not a multiple of 4).
+// Algorithmic HBM bytes: 2 * R * C.
+#include "common.h"
+#include "tile_io.h"
+
+namespace {
+constexpr int PT_THREADS = TIO_THREADS;
+
+struct PatGeom {
+    uint64_t R;
+    uint32_t C;
+    uint32_t TR;      // rows per tile
+    uint32_t TRp;     // column pitch in LDS for the transposing kernels (multiple of 4)
+    uint32_t fr, fc;  // flip rows / flip columns
+    uint32_t magicC;  // ceil(2^32 / C)
+};
+
+__device__ __forceinline__ void divmod_c(uint32_t k, const PatGeom& g, uint32_t& q, uint32_t& rem) {
+    fast_divmod(k, g.C, g.magicC, q, rem);
+}
+
+// ---------------------------------------------------------------- row-major family (self-inverse)
+struct RowMajorFn {
+    const uint8_t* lds; uint32_t skew, n; const PatGeom& g;
+    __device__ __forceinline__ uint8_t at(uint32_t i, uint32_t c) const {
+        uint32_t row = g.fr ? n - 1 - i : i;
+        uint32_t col = g.fc ? g.C - 1 - c : c;
+        return lds[skew + row * g.C + col];
+    }
+    __device__ __forceinline__ uint8_t byte(uint32_t k) const {
+        uint32_t i, c; divmod_c(k, g, i, c);
+        return at(i, c);
+    }
+    __device__ __forceinline__ void operator()(uint32_t k0, uint32_t* w) const {
+        uint32_t i, c; divmod_c(k0, g, i, c);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                v |= (uint32_t)at(i, c) << (8 * b);
+                if (++c == g.C) { c = 0; ++i; }
+            }
+            w[d] = v;
+        }
+    }
+};
+
+__global__ __launch_bounds__(PT_THREADS) void pattern_rm_kernel(const uint8_t* __restrict__ T, PatGeom g, uint8_t* __restrict__ out) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    const uint64_t r0 = (uint64_t)blockIdx.x * g.TR;
+    const uint32_t n = (uint32_t)((g.R - r0) < g.TR ? (g.R - r0) : g.TR);
+    const uint32_t len = n * g.C;
+    const uint32_t skew = stage_span(T + r0 * g.C, len, smem);
+    __syncthreads();
+    const uint64_t ro0 = g.fr ? g.R - r0 - n : r0;
+    RowMajorFn fn{smem, skew, n, g};
+    emit_span(out + ro0 * g.C, len, fn);
+}
+
+// ---------------------------------------------------------------- column-major, forward: T -> payload
+__global__ __launch_bounds__(PT_THREADS) void pattern_cm_kernel(const uint8_t* __restrict__ T, PatGeom g, uint8_t* __restrict__ out) {
+    extern __shared__ __align__(16) uint8_t smem[];   // lds_t[c * TRp + i_out], + 16 bytes of slack
+    const uint64_t r0 = (uint64_t)blockIdx.x * g.TR;
+    const uint32_t n = (uint32_t)((g.R - r0) < g.TR ? (g.R - r0) : g.TR);
+    const uint32_t len = n * g.C;
+    // A: 16-byte chunks of the row-major span, bytes scattered to their column runs
+    {
+        const uint8_t* src = T + r0 * g.C;
+        const uint64_t a0 = (uint64_t)(uintptr_t)src & ~uint64_t(15);
+        const uint32_t skew = (uint32_t)((uint64_t)(uintptr_t)src - a0);
+        const uint32_t nvec = (skew + len + 15) >> 4;
+        const uint4* s4 = (const uint4*)(uintptr_t)a0;
+        for (uint32_t q = threadIdx.x; q < nvec; q += PT_THREADS) {
+            uint4 v = s4[q];
+            uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            int32_t k = (int32_t)(q * 16) - (int32_t)skew;
+            uint32_t rl = 0, c = 0;
+            if (k > 0) divmod_c((uint32_t)k, g, rl, c);
+#pragma unroll
+            for (int b = 0; b < 16; ++b, ++k) {
+                if (k >= 0 && (uint32_t)k < len) {
+                    uint32_t io = g.fr ? n - 1 - rl : rl;
+                    smem[c * g.TRp + io] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
+                    if (++c == g.C) { c = 0; ++rl; }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // B: each column run -> global, dword stores
+    const uint64_t ro0 = g.fr ? g.R - r0 - n : r0;
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t* lds32 = (const uint32_t*)smem;
+    for (uint32_t c = w; c < g.C; c += PT_THREADS / 64) {
+        const uint32_t cc = g.fc ? g.C - 1 - c : c;
+        uint8_t* s = out + (uint64_t)cc * g.R + ro0;
+        uint32_t head = (uint32_t)((4 - ((uintptr_t)s & 3)) & 3);
+        if (head > n) head = n;
+        const uint32_t nd = (n - head) >> 2;
+        const uint32_t tail = n - head - 4 * nd;
+        const uint8_t* col = smem + c * g.TRp;
+        if (lane < head) s[lane] = col[lane];
+        if (lane < tail) s[head + 4 * nd + lane] = col[head + 4 * nd + lane];
+        uint32_t* s32 = (uint32_t*)(s + head);
+        const uint32_t wbase = (c * g.TRp) >> 2;
+        for (uint32_t d = lane; d < nd; d += 64) {
+            uint32_t lo = lds32[wbase + d], hi = lds32[wbase + d + 1];
+            s32[d] = __builtin_amdgcn_alignbyte(hi, lo, head);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- column-major, inverse: payload -> T
+struct ColMajorInvFn {
+    const uint8_t* lds; const uint8_t* skewc; uint32_t n; const PatGeom& g;
+    __device__ __forceinline__ uint8_t at(uint32_t rl, uint32_t c) const {
+        uint32_t io = g.fr ? n - 1 - rl : rl;
+        return lds[c * g.TRp + skewc[c] + io];
+    }
+    __device__ __forceinline__ uint8_t byte(uint32_t k) const {
+        uint32_t i, c; divmod_c(k, g, i, c);
+        return at(i, c);
+    }
+    __device__ __forceinline__ void operator()(uint32_t k0, uint32_t* w) const {
+        uint32_t i, c; divmod_c(k0, g, i, c);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                v |= (uint32_t)at(i, c) << (8 * b);
+                if (++c == g.C) { c = 0; ++i; }
+            }
+            w[d] = v;
+        }
+    }
+};
+
+__global__ __launch_bounds__(PT_THREADS) void unpattern_cm_kernel(const uint8_t* __restrict__ P, PatGeom g, uint8_t* __restrict__ T) {
+    extern __shared__ __align__(16) uint8_t smem[];   // [C * TRp] runs (each with its own 0..3 byte skew) + skew table [C]
+    uint8_t* skewc = smem + (size_t)g.C * g.TRp;
+    const uint64_t r0 = (uint64_t)blockIdx.x * g.TR;
+    const uint32_t n = (uint32_t)((g.R - r0) < g.TR ? (g.R - r0) : g.TR);
+    const uint64_t ro0 = g.fr ? g.R - r0 - n : r0;
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t* lds32 = (uint32_t*)smem;
+    for (uint32_t c = w; c < g.C; c += PT_THREADS / 64) {
+        const uint32_t cc = g.fc ? g.C - 1 - c : c;
+        const uint8_t* s = P + (uint64_t)cc * g.R + ro0;
+        const uint32_t sk = (uint32_t)((uintptr_t)s & 3);
+        const uint32_t* s32 = (const uint32_t*)(s - sk);
+        const uint32_t nd = (sk + n + 3) >> 2;
+        const uint32_t wbase = (c * g.TRp) >> 2;
+        for (uint32_t d = lane; d < nd; d += 64) lds32[wbase + d] = s32[d];
+        if (lane == 0) skewc[c] = (uint8_t)sk;
+    }
+    __syncthreads();
+    ColMajorInvFn fn{smem, skewc, n, g};
+    emit_span(T + r0 * g.C, n * g.C, fn);
+}
+
+int launch(uq_ctx* ctx, const uint8_t* in, uint64_t rows, uint32_t cols, int pattern_id, uint8_t* out, bool inverse) {
+    UQ_REQUIRE(ctx, "null context");
+    UQ_REQUIRE(pattern_id >= 0 && pattern_id < 8, "pattern id %d out of range", pattern_id);
+    UQ_REQUIRE(cols >= 1, "pattern: table needs at least one column");
+    UQ_REQUIRE(rows * (uint64_t)cols == 0 || (in && out), "pattern: null buffer");
+    if (rows == 0) return 0;
+    const int k = pattern_id >> 1, f = pattern_id & 1;
+    // (k, order) -> family and flips, SURVEY.md A.4
+    bool colmajor; uint32_t fr, fc;
+    switch (k * 2 + f) {
+        case 0: colmajor = false; fr = 0; fc = 0; break;   // 0.1
+        case 1: colmajor = true;  fr = 0; fc = 0; break;   // 0.2
+        case 2: colmajor = true;  fr = 0; fc = 1; break;   // 1.1
+        case 3: colmajor = false; fr = 0; fc = 1; break;   // 1.2
+        case 4: colmajor = false; fr = 1; fc = 1; break;   // 2.1
+        case 5: colmajor = true;  fr = 1; fc = 1; break;   // 2.2
+        case 6: colmajor = true;  fr = 1; fc = 0; break;   // 3.1
+        default: colmajor = false; fr = 1; fc = 0; break;  // 3.2
+    }
+    if (!colmajor && !fr && !fc) {
+        UQ_CHECK_HIP(hipMemcpyAsync(out, in, rows * cols, hipMemcpyDeviceToDevice, ctx->stream));
+        return 0;
+    }
+    PatGeom g;
+    g.R = rows; g.C = cols; g.fr = fr; g.fc = fc;
+    g.magicC = magic_u32(cols);
+    UQ_REQUIRE(cols <= 32768, "pattern: %u columns do not fit one LDS tile", cols);
+    const uint32_t budget = 60 * 1024;
+    size_t lds;
+    if (!colmajor) {
+        uint32_t TR = budget / cols;
+        if (TR >= 16) TR &= ~15u;
+        if (TR == 0) TR = 1;
+        if (TR > 4096) TR = 4096;
+        g.TR = TR; g.TRp = 0;
+        lds = (size_t)TR * cols + 32;
+    } else {
+        uint32_t TR = budget / cols;
+        if (TR >= 64) TR &= ~63u; else if (TR >= 4) TR &= ~3u;
+        if (TR == 0) TR = 1;
+        if (TR > 2048) TR = 2048;
+        g.TR = TR;
+        g.TRp = ((TR + 3) & ~3u) + 8;           // room for the 0..3 byte skew and the hi word of alignbyte
+        if (((g.TRp >> 2) & 1) == 0) g.TRp += 4;  // odd number of dwords: consecutive columns shift banks
+        lds = (size_t)cols * g.TRp + 16 + cols + 16;
+    }
+    UQ_REQUIRE(lds <= 160 * 1024, "pattern: tile needs %zu bytes of LDS", lds);
+    const uint64_t tiles = (rows + g.TR - 1) / g.TR;
+    UQ_REQUIRE(tiles <= 0x7fffffffu, "pattern: too many tiles");
+    const void* fn = !colmajor ? (const void*)pattern_rm_kernel : (inverse ? (const void*)unpattern_cm_kernel : (const void*)pattern_cm_kernel);
+    if (lds > 48 * 1024) UQ_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (!colmajor) pattern_rm_kernel<<<(uint32_t)tiles, PT_THREADS, lds, ctx->stream>>>(in, g, out);
+    else if (!inverse) pattern_cm_kernel<<<(uint32_t)tiles, PT_THREADS, lds, ctx->stream>>>(in, g, out);
+    else unpattern_cm_kernel<<<(uint32_t)tiles, PT_THREADS, lds, ctx->stream>>>(in, g, out);
+    UQ_LAUNCH_CHECK();
+    return 0;
+}
+}  // namespace
+
+extern "C" int uq_pattern(uq_ctx* ctx, const uint8_t* d_table, uint64_t rows, uint32_t cols, int pattern_id, uint8_t* d_payload) {
+    return launch(ctx, d_table, rows, cols, pattern_id, d_payload, false);
+}
+
+extern "C" int uq_unpattern(uq_ctx* ctx, const uint8_t* d_payload, uint64_t rows, uint32_t cols, int pattern_id, uint8_t* d_table) {
+    return launch(ctx, d_payload, rows, cols, pattern_id, d_table, true);
+}

@@ -1,0 +1,12 @@
+// radix.h -- internal interface of the device LSD radix sort (radix.hip) used by sort.hip.
+#pragma once
+#include "common.h"
+
+// Stable LSD radix sort of (u64 key, u32 value) pairs on bits [begin_bit, end_bit) of the key, 8 bits
+// per pass; passes whose digit is the same for every key are skipped.  `keys`/`vals` hold the input,
+// `keys_alt`/`vals_alt` are same-sized ping-pong buffers.  On return *in_alt tells which pair of
+// buffers holds the sorted result (0 = keys/vals, 1 = keys_alt/vals_alt).
+// `ws` must provide radix_ws_bytes(n) bytes of device scratch.
+size_t radix_ws_bytes(uint64_t n);
+int radix_sort_pairs(uq_ctx* ctx, uint64_t* keys, uint32_t* vals, uint64_t* keys_alt, uint32_t* vals_alt,
+                     uint64_t n, int begin_bit, int end_bit, void* ws, int* in_alt);

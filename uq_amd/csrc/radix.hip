@@ -1,0 +1,174 @@
+// radix.hip -- stable LSD radix sort of (u64 key, u32 value) pairs, 8 bits per pass, wave64-native.
+//
+// Per pass: (1) per-tile digit histogram (LDS atomics) -> digit-major table [256][tiles];
+// (2) exclusive scan of that table (scan.hip: kernel boundaries only, no inter-workgroup hand-off);
+// (3) scatter: each wave ranks its 1024 keys 64 at a time with eight __ballot()s per key (the wave64
+// form of match-any: lanes holding the same digit find each other, popcount below the lane = stable
+// rank), the tile is regrouped by digit in LDS and written out in runs of equal digit, so consecutive
+// lanes store to consecutive addresses.
+// Passes whose digit is constant over all keys are skipped (one 8-digit census up front).
+// HBM traffic per executed pass: 8 B read (count) + 12 B read + 12 B written (scatter) per pair.
+#include "radix.h"
+
+namespace {
+constexpr int RS_THREADS = 256;
+constexpr int RS_ITEMS = 16;
+constexpr int RS_TILE = RS_THREADS * RS_ITEMS;   // 4096 pairs per workgroup
+constexpr int RS_WAVE_KEYS = 64 * RS_ITEMS;      // 1024 per wave
+
+__device__ __forceinline__ uint32_t digit_of(uint64_t k, int shift) { return (uint32_t)(k >> shift) & 255u; }
+
+// Census of all eight digit positions at once: ghist[p][d].
+__global__ __launch_bounds__(RS_THREADS) void rs_census_kernel(const uint64_t* __restrict__ keys, uint64_t n,
+                                                               uint32_t* __restrict__ ghist) {
+    __shared__ uint32_t h[8 * 256];
+    for (int i = threadIdx.x; i < 8 * 256; i += RS_THREADS) h[i] = 0;
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * RS_THREADS;
+    for (uint64_t i = (uint64_t)blockIdx.x * RS_THREADS + threadIdx.x; i < n; i += stride) {
+        uint64_t k = keys[i];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) atomicAdd(&h[p * 256 + digit_of(k, 8 * p)], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 8 * 256; i += RS_THREADS)
+        if (h[i]) atomicAdd(&ghist[i], h[i]);
+}
+
+__global__ __launch_bounds__(RS_THREADS) void rs_count_kernel(const uint64_t* __restrict__ keys, uint64_t n, int shift,
+                                                              uint32_t nb, uint32_t* __restrict__ block_hist) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * RS_TILE;
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; ++i) {
+        uint64_t idx = base + (uint64_t)i * RS_THREADS + threadIdx.x;
+        if (idx < n) atomicAdd(&h[digit_of(keys[idx], shift)], 1u);
+    }
+    __syncthreads();
+    block_hist[(uint64_t)threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
+}
+
+__global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                                uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                                uint64_t n, int shift, uint32_t nb,
+                                                                const uint32_t* __restrict__ block_off) {
+    __shared__ uint64_t s_keys[RS_TILE];
+    __shared__ uint32_t s_vals[RS_TILE];
+    __shared__ uint32_t s_cnt[4 * 256];      // per-wave digit counts, then per-wave exclusive bases
+    __shared__ uint32_t s_start[256];        // first tile-local slot of each digit
+    __shared__ uint32_t s_goff[256];         // first global slot of each digit for this tile
+    __shared__ uint32_t s_scan[RS_THREADS / 64 + 1];
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint64_t tile0 = (uint64_t)blockIdx.x * RS_TILE;
+    const uint32_t ntile = (uint32_t)((n - tile0) < RS_TILE ? (n - tile0) : RS_TILE);
+    for (int i = tid; i < 4 * 256; i += RS_THREADS) s_cnt[i] = 0;
+    s_goff[tid] = block_off[(uint64_t)tid * nb + blockIdx.x];
+    __syncthreads();
+
+    uint64_t key[RS_ITEMS];
+    uint32_t val[RS_ITEMS];
+    uint32_t rank[RS_ITEMS];
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; ++i) {
+        const uint32_t loc = w * RS_WAVE_KEYS + i * 64 + lane;
+        const bool valid = loc < ntile;
+        key[i] = valid ? keys_in[tile0 + loc] : 0;
+        val[i] = valid ? vals_in[tile0 + loc] : 0;
+        const uint32_t d = digit_of(key[i], shift);
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (d >> b) & 1;
+            const uint64_t bal = __ballot(bit);
+            peers &= bit ? bal : ~bal;
+        }
+        // lanes with `valid` false hold an arbitrary peers mask; they never touch LDS below
+        const uint32_t leader = (uint32_t)(__ffsll((unsigned long long)peers) - 1);
+        uint32_t prev = 0;
+        if (valid && lane == leader) {
+            prev = s_cnt[w * 256 + d];
+            s_cnt[w * 256 + d] = prev + (uint32_t)__popcll(peers);
+        }
+        prev = __shfl(prev, valid ? leader : lane, 64);
+        rank[i] = prev + (uint32_t)__popcll(peers & lt_mask);
+    }
+    __syncthreads();
+    // digit `tid`: exclusive bases over the four waves, tile total
+    uint32_t tot = 0;
+#pragma unroll
+    for (int ww = 0; ww < 4; ++ww) {
+        uint32_t c = s_cnt[ww * 256 + tid];
+        s_cnt[ww * 256 + tid] = tot;
+        tot += c;
+    }
+    uint32_t all;
+    uint32_t start = block_exclusive_sum<uint32_t, RS_THREADS / 64>(tot, s_scan, all);
+    s_start[tid] = start;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; ++i) {
+        const uint32_t loc = w * RS_WAVE_KEYS + i * 64 + lane;
+        if (loc < ntile) {
+            const uint32_t d = digit_of(key[i], shift);
+            const uint32_t p = s_start[d] + s_cnt[w * 256 + d] + rank[i];
+            s_keys[p] = key[i];
+            s_vals[p] = val[i];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; ++i) {
+        const uint32_t p = i * RS_THREADS + tid;
+        if (p < ntile) {
+            const uint64_t k = s_keys[p];
+            const uint32_t d = digit_of(k, shift);
+            const uint32_t g = s_goff[d] + (p - s_start[d]);
+            keys_out[g] = k;
+            vals_out[g] = s_vals[p];
+        }
+    }
+}
+}  // namespace
+
+size_t radix_ws_bytes(uint64_t n) {
+    uint64_t nb = (n + RS_TILE - 1) / RS_TILE;
+    return (size_t)(256 * nb + 64) * 4 + 8 * 256 * 4 + 256;
+}
+
+int radix_sort_pairs(uq_ctx* ctx, uint64_t* keys, uint32_t* vals, uint64_t* keys_alt, uint32_t* vals_alt,
+                     uint64_t n, int begin_bit, int end_bit, void* ws, int* in_alt) {
+    *in_alt = 0;
+    if (n <= 1 || end_bit <= begin_bit) return 0;
+    UQ_REQUIRE(n < (uint64_t(1) << 32), "radix sort: more than 2^32-1 pairs");
+    UQ_REQUIRE(begin_bit % 8 == 0 && begin_bit >= 0 && end_bit <= 64, "radix sort: bad bit range");
+    const uint32_t nb = (uint32_t)((n + RS_TILE - 1) / RS_TILE);
+    uint32_t* ghist = (uint32_t*)ws;
+    uint32_t* block_hist = ghist + 8 * 256 + 64;
+    UQ_CHECK_HIP(hipMemsetAsync(ghist, 0, 8 * 256 * 4, ctx->stream));
+    uint32_t cb = nb < 2048 ? nb : 2048;
+    rs_census_kernel<<<cb, RS_THREADS, 0, ctx->stream>>>(keys, n, ghist);
+    UQ_LAUNCH_CHECK();
+    static thread_local uint32_t h_hist[8 * 256];
+    UQ_CHECK_HIP(hipMemcpyAsync(h_hist, ghist, sizeof(h_hist), hipMemcpyDeviceToHost, ctx->stream));
+    UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    uint64_t* kin = keys; uint32_t* vin = vals; uint64_t* kout = keys_alt; uint32_t* vout = vals_alt;
+    for (int p = begin_bit / 8; p * 8 < end_bit; ++p) {
+        bool trivial = false;
+        for (int d = 0; d < 256; ++d)
+            if (h_hist[p * 256 + d] == n) { trivial = true; break; }
+        if (trivial) continue;
+        rs_count_kernel<<<nb, RS_THREADS, 0, ctx->stream>>>(kin, n, 8 * p, nb, block_hist);
+        UQ_LAUNCH_CHECK();
+        UQ_TRY(uq_scan_exclusive_u32(ctx, block_hist, block_hist, (uint64_t)256 * nb, nullptr));
+        rs_scatter_kernel<<<nb, RS_THREADS, 0, ctx->stream>>>(kin, vin, kout, vout, n, 8 * p, nb, block_hist);
+        UQ_LAUNCH_CHECK();
+        uint64_t* tk = kin; kin = kout; kout = tk;
+        uint32_t* tv = vin; vin = vout; vout = tv;
+        *in_alt ^= 1;
+    }
+    return 0;
+}

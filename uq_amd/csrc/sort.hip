@@ -1,0 +1,306 @@
+// sort.hip -- row sort and unique/inverse on the device.
+// Replaces numpy.argsort(table.view('V<C>'), axis=0) (uq.py:773-775), numpy.unique(rows,
+// return_inverse=True) (uq.py:784-789, 828-830) and numpy.argsort(key) (uq.py:796, 833).
+//
+// Keys are whole rows of C bytes (38 .. 227 B and more) compared like memcmp.  An LSD radix sort over
+// every byte would need C passes; instead the sort is MSD by 8-byte chunks with LSD radix inside:
+//   round 0   sort all rows by chunk 0 (their first 8 bytes as a big-endian u64), stable;
+//   round k   only rows that still tie with a neighbour ("active") are touched: they are compacted,
+//             sorted by chunk k, then stably regrouped by their tie-segment id, and written back into
+//             the slots their segment occupies.  Distinct rows drop out as soon as a chunk separates
+//             them, so random reads finish after round 0 and only true duplicates visit every chunk.
+// Ties are broken by input order (stable) -- the canonical order of SURVEY.md Q17.
+// The per-row "first of its group" flags that fall out of the rounds give unique / inverse for free:
+// key = inclusive scan of the flags, and the stable sort order IS argsort(key, stable) (uq.py:796).
+#include "radix.h"
+
+namespace {
+constexpr int ST = 256;
+
+__device__ __forceinline__ uint64_t load_chunk_be(const uint8_t* row, uint32_t C, uint32_t k) {
+    const uint32_t o = 8 * k;
+    uint64_t v;
+    if (o + 8 <= C) {
+        __builtin_memcpy(&v, row + o, 8);
+        return __builtin_bswap64(v);
+    }
+    v = 0;
+    for (uint32_t i = 0; i < 8; ++i) v = (v << 8) | (o + i < C ? row[o + i] : 0);
+    return v;
+}
+
+__global__ void extract_all_kernel(const uint8_t* __restrict__ table, uint64_t n, uint32_t C, uint64_t* __restrict__ keys,
+                                   uint32_t* __restrict__ vals) {
+    uint64_t i = (uint64_t)blockIdx.x * ST + threadIdx.x;
+    if (i >= n) return;
+    keys[i] = load_chunk_be(table + i * C, C, 0);
+    vals[i] = (uint32_t)i;
+}
+
+__global__ void heads_first_kernel(const uint64_t* __restrict__ keys, uint64_t n, uint8_t* __restrict__ heads) {
+    uint64_t j = (uint64_t)blockIdx.x * ST + threadIdx.x;
+    if (j >= n) return;
+    heads[j] = (j == 0 || keys[j] != keys[j - 1]) ? 1 : 0;
+}
+
+// a[j] = row j (in sorted position) belongs to a tie segment of size >= 2; h[j] = a[j] && heads[j]
+__global__ void active_flags_kernel(const uint8_t* __restrict__ heads, uint64_t n, uint32_t* __restrict__ a, uint32_t* __restrict__ h) {
+    uint64_t j = (uint64_t)blockIdx.x * ST + threadIdx.x;
+    if (j >= n) return;
+    const bool hd = heads[j] != 0;
+    const bool next_head = (j + 1 == n) || heads[j + 1] != 0;
+    const bool act = !(hd && next_head);
+    a[j] = act ? 1u : 0u;
+    h[j] = (act && hd) ? 1u : 0u;
+}
+
+// compact the active slots: pos[u] = j, aval[u] = perm[j], sid[u] = dense id of j's tie segment;
+// and pull chunk k of each active row: keys[u], vals[u] = u
+__global__ void compact_active_kernel(const uint32_t* __restrict__ a, const uint32_t* __restrict__ apos, const uint32_t* __restrict__ h,
+                                      const uint32_t* __restrict__ hpos, const uint32_t* __restrict__ perm, uint64_t n,
+                                      const uint8_t* __restrict__ table, uint32_t C, uint32_t k,
+                                      uint32_t* __restrict__ pos, uint32_t* __restrict__ aval, uint32_t* __restrict__ sid,
+                                      uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    uint64_t j = (uint64_t)blockIdx.x * ST + threadIdx.x;
+    if (j >= n || !a[j]) return;
+    const uint32_t u = apos[j];
+    const uint32_t row = perm[j];
+    pos[u] = (uint32_t)j;
+    aval[u] = row;
+    sid[u] = hpos[j] + h[j] - 1;
+    keys[u] = load_chunk_be(table + (uint64_t)row * C, C, k);
+    vals[u] = u;
+}
+
+// d[t] = chunk value differs from the previous active element (in chunk order)
+__global__ void diff_flags_kernel(const uint64_t* __restrict__ keys, uint64_t m, uint32_t* __restrict__ d) {
+    uint64_t t = (uint64_t)blockIdx.x * ST + threadIdx.x;
+    if (t >= m) return;
+    d[t] = (t == 0 || keys[t] != keys[t - 1]) ? 1u : 0u;
+}
+
+// keys2[t] = sid[V1[t]] << 32 | rank1[t]   (rank1 = exclusive scan of d + d: monotone label of the chunk value)
+__global__ void compose_kernel(const uint32_t* __restrict__ v1, const uint32_t* __restrict__ sid, const uint32_t* __restrict__ d,
+                               const uint32_t* __restrict__ dscan, uint64_t m, uint64_t* __restrict__ keys2) {
+    uint64_t t = (uint64_t)blockIdx.x * ST + threadIdx.x;
+    if (t >= m) return;
+    keys2[t] = ((uint64_t)sid[v1[t]] << 32) | (uint64_t)(dscan[t] + d[t]);
+}
+
+// write the refined order back into the slots of the active segments and refresh their head flags
+__global__ void writeback_kernel(const uint64_t* __restrict__ keys2, const uint32_t* __restrict__ v2, const uint32_t* __restrict__ pos,
+                                 const uint32_t* __restrict__ aval, uint64_t m, uint32_t* __restrict__ perm, uint8_t* __restrict__ heads) {
+    uint64_t t = (uint64_t)blockIdx.x * ST + threadIdx.x;
+    if (t >= m) return;
+    const uint32_t j = pos[t];
+    perm[j] = aval[v2[t]];
+    heads[j] = (t == 0 || keys2[t] != keys2[t - 1]) ? 1 : 0;
+}
+
+inline uint32_t blocks_for(uint64_t n) { return (uint32_t)((n + ST - 1) / ST); }
+
+int bits_for(uint64_t v) { int b = 0; while (v) { ++b; v >>= 1; } return b; }
+
+struct Core {
+    uint8_t* heads;
+    void* extra;
+};
+
+// Sorts the rows; leaves the stable order in d_perm and the group-head flags in `heads`.
+int sort_rows_core(uq_ctx* ctx, const uint8_t* table, uint64_t n, uint32_t C, uint32_t* d_perm, size_t extra_bytes, Core* out) {
+    UQ_REQUIRE(n < (uint64_t(1) << 32), "row sort: more than 2^32-1 rows per GPU");
+    ScratchPlan plan;
+    const size_t o_keysA = plan.add(n * 8), o_keysB = plan.add(n * 8);
+    const size_t o_valsA = plan.add(n * 4), o_valsB = plan.add(n * 4);
+    const size_t o_heads = plan.add(n + 16);
+    const size_t o_a = plan.add(n * 4), o_h = plan.add(n * 4);
+    const size_t o_apos = plan.add(n * 4), o_hpos = plan.add(n * 4);
+    const size_t o_pos = plan.add(n * 4), o_aval = plan.add(n * 4), o_sid = plan.add(n * 4);
+    const size_t o_tot = plan.add(64);
+    const size_t o_rws = plan.add(radix_ws_bytes(n));
+    const size_t o_extra = plan.add(extra_bytes + 256);
+    void* base;
+    UQ_TRY(uq_scratch(ctx, plan.off, &base));
+    uint8_t* b = (uint8_t*)base;
+    uint64_t* keysA = (uint64_t*)(b + o_keysA); uint64_t* keysB = (uint64_t*)(b + o_keysB);
+    uint32_t* valsA = (uint32_t*)(b + o_valsA); uint32_t* valsB = (uint32_t*)(b + o_valsB);
+    uint8_t* heads = b + o_heads;
+    uint32_t* fa = (uint32_t*)(b + o_a); uint32_t* fh = (uint32_t*)(b + o_h);
+    uint32_t* apos = (uint32_t*)(b + o_apos); uint32_t* hpos = (uint32_t*)(b + o_hpos);
+    uint32_t* pos = (uint32_t*)(b + o_pos); uint32_t* aval = (uint32_t*)(b + o_aval); uint32_t* sid = (uint32_t*)(b + o_sid);
+    uint64_t* tot = (uint64_t*)(b + o_tot);
+    void* rws = b + o_rws;
+    out->heads = heads;
+    out->extra = b + o_extra;
+    if (n == 0) return 0;
+    hipStream_t s = ctx->stream;
+
+    // ---- round 0
+    extract_all_kernel<<<blocks_for(n), ST, 0, s>>>(table, n, C, keysA, valsA);
+    UQ_LAUNCH_CHECK();
+    int alt = 0;
+    UQ_TRY(radix_sort_pairs(ctx, keysA, valsA, keysB, valsB, n, 0, 64, rws, &alt));
+    const uint64_t* K = alt ? keysB : keysA;
+    const uint32_t* V = alt ? valsB : valsA;
+    UQ_CHECK_HIP(hipMemcpyAsync(d_perm, V, n * 4, hipMemcpyDeviceToDevice, s));
+    heads_first_kernel<<<blocks_for(n), ST, 0, s>>>(K, n, heads);
+    UQ_LAUNCH_CHECK();
+
+    // ---- refinement rounds
+    const uint32_t nchunks = (C + 7) / 8;
+    for (uint32_t k = 1; k < nchunks; ++k) {
+        active_flags_kernel<<<blocks_for(n), ST, 0, s>>>(heads, n, fa, fh);
+        UQ_LAUNCH_CHECK();
+        UQ_TRY(uq_scan_exclusive_u32(ctx, fa, apos, n, tot));
+        UQ_TRY(uq_scan_exclusive_u32(ctx, fh, hpos, n, tot + 1));
+        UQ_CHECK_HIP(hipMemcpyAsync(ctx->h_pinned, tot, 16, hipMemcpyDeviceToHost, s));
+        UQ_CHECK_HIP(hipStreamSynchronize(s));
+        const uint64_t m = ctx->h_pinned[0], nseg = ctx->h_pinned[1];
+        if (m == 0) break;
+        compact_active_kernel<<<blocks_for(n), ST, 0, s>>>(fa, apos, fh, hpos, d_perm, n, table, C, k, pos, aval, sid, keysA, valsA);
+        UQ_LAUNCH_CHECK();
+        // sort #1: active rows by the value of chunk k
+        UQ_TRY(radix_sort_pairs(ctx, keysA, valsA, keysB, valsB, m, 0, 64, rws, &alt));
+        const uint64_t* K1 = alt ? keysB : keysA;
+        uint32_t* V1 = alt ? valsB : valsA;
+        uint64_t* Kfree = alt ? keysA : keysB;       // the key buffer not holding K1
+        uint32_t* Vfree = alt ? valsA : valsB;
+        diff_flags_kernel<<<blocks_for(m), ST, 0, s>>>(K1, m, fa);
+        UQ_LAUNCH_CHECK();
+        UQ_TRY(uq_scan_exclusive_u32(ctx, fa, fh, m, nullptr));
+        compose_kernel<<<blocks_for(m), ST, 0, s>>>(V1, sid, fa, fh, m, Kfree);
+        UQ_LAUNCH_CHECK();
+        // sort #2: stable regroup by tie-segment id (high word); K1's buffer is dead and serves as ping-pong
+        int alt2 = 0;
+        const int sbits = bits_for(nseg > 0 ? nseg - 1 : 0);
+        UQ_TRY(radix_sort_pairs(ctx, Kfree, V1, (uint64_t*)K1, Vfree, m, 32, 32 + (sbits ? sbits : 1), rws, &alt2));
+        const uint64_t* K2 = alt2 ? K1 : Kfree;
+        const uint32_t* V2 = alt2 ? Vfree : V1;
+        writeback_kernel<<<blocks_for(m), ST, 0, s>>>(K2, V2, pos, aval, m, d_perm, heads);
+        UQ_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+// ---- unique / inverse from the sorted order + head flags
+__global__ void heads_to_u32_kernel(const uint8_t* __restrict__ heads, uint64_t n, uint32_t* __restrict__ f) {
+    uint64_t j = (uint64_t)blockIdx.x * ST + threadIdx.x;
+    if (j < n) f[j] = heads[j];
+}
+__global__ void keys_from_groups_kernel(const uint8_t* __restrict__ heads, const uint32_t* __restrict__ gscan, const uint32_t* __restrict__ perm,
+                                        uint64_t n, uint32_t* __restrict__ key, uint32_t* __restrict__ sorted_key, uint32_t* __restrict__ uidx) {
+    uint64_t j = (uint64_t)blockIdx.x * ST + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t g = gscan[j] + heads[j] - 1;     // inclusive count of heads - 1
+    const uint32_t row = perm[j];
+    if (key) key[row] = g;
+    if (sorted_key) sorted_key[j] = g;
+    if (uidx && heads[j]) uidx[g] = row;
+}
+
+template <typename T>
+__global__ void narrow_kernel(const uint32_t* __restrict__ in, uint64_t n, T* __restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * ST + threadIdx.x;
+    if (i < n) out[i] = (T)in[i];
+}
+
+__global__ void stack_column_kernel(const uint8_t* __restrict__ col, int itemsize, uint64_t n, int ncols, int cidx, int common,
+                                    uint8_t* __restrict__ rows) {
+    uint64_t i = (uint64_t)blockIdx.x * ST + threadIdx.x;
+    if (i >= n) return;
+    uint64_t v = 0;
+    for (int b = 0; b < itemsize; ++b) v |= (uint64_t)col[i * itemsize + b] << (8 * b);   // little-endian column
+    uint8_t* dst = rows + (i * ncols + cidx) * common;
+    for (int b = 0; b < common; ++b) dst[b] = (uint8_t)(v >> (8 * (common - 1 - b)));   // big-endian field
+}
+
+__global__ void unstack_column_kernel(const uint8_t* __restrict__ rows, uint64_t n, int ncols, int common, int cidx, int out_itemsize,
+                                      uint8_t* __restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * ST + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* src = rows + (i * ncols + cidx) * common;
+    uint64_t v = 0;
+    for (int b = 0; b < common; ++b) v = (v << 8) | src[b];
+    for (int b = 0; b < out_itemsize; ++b) out[i * out_itemsize + b] = (uint8_t)(v >> (8 * b));
+}
+}  // namespace
+
+int uq_gather_rows_internal(uq_ctx* ctx, const uint8_t* d_table, uint64_t table_rows, uint32_t cols, const void* d_index,
+                            int index_itemsize, uint64_t n_out, uint8_t* d_out);
+
+extern "C" int uq_argsort_rows(uq_ctx* ctx, const uint8_t* d_table, uint64_t rows, uint32_t cols, uint32_t* d_perm) {
+    UQ_REQUIRE(ctx && (rows == 0 || (d_table && d_perm)), "uq_argsort_rows: null argument");
+    UQ_REQUIRE(cols >= 1, "uq_argsort_rows: rows need at least one byte");
+    Core c;
+    return sort_rows_core(ctx, d_table, rows, cols, d_perm, 0, &c);
+}
+
+extern "C" int uq_unique_rows(uq_ctx* ctx, const uint8_t* d_table, uint64_t rows, uint32_t cols, uint32_t* d_perm,
+                              uint32_t* d_key, uint32_t* d_sorted_key, uint8_t* d_unique, uint64_t* h_nunique) {
+    UQ_REQUIRE(ctx && h_nunique && (rows == 0 || (d_table && d_perm)), "uq_unique_rows: null argument");
+    UQ_REQUIRE(cols >= 1, "uq_unique_rows: rows need at least one byte");
+    *h_nunique = 0;
+    if (rows == 0) return 0;
+    Core c;
+    const size_t extra = rows * 4 * 3 + 1024;
+    UQ_TRY(sort_rows_core(ctx, d_table, rows, cols, d_perm, extra, &c));
+    uint32_t* f = (uint32_t*)c.extra;
+    uint32_t* gscan = f + rows;
+    uint32_t* uidx = gscan + rows;
+    uint64_t* tot = (uint64_t*)(uidx + rows);
+    tot = (uint64_t*)(((uintptr_t)tot + 7) & ~uintptr_t(7));
+    heads_to_u32_kernel<<<blocks_for(rows), ST, 0, ctx->stream>>>(c.heads, rows, f);
+    UQ_LAUNCH_CHECK();
+    UQ_TRY(uq_scan_exclusive_u32(ctx, f, gscan, rows, tot));
+    keys_from_groups_kernel<<<blocks_for(rows), ST, 0, ctx->stream>>>(c.heads, gscan, d_perm, rows, d_key, d_sorted_key, d_unique ? uidx : nullptr);
+    UQ_LAUNCH_CHECK();
+    UQ_CHECK_HIP(hipMemcpyAsync(ctx->h_pinned, tot, 8, hipMemcpyDeviceToHost, ctx->stream));
+    UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    *h_nunique = ctx->h_pinned[0];
+    if (d_unique) UQ_TRY(uq_gather_rows_internal(ctx, d_table, rows, cols, uidx, 4, *h_nunique, d_unique));
+    return 0;
+}
+
+extern "C" int uq_key_itemsize(uint64_t max_key) {
+    // numpy.min_scalar_type of a non-negative integer (uq.py:790): u1 / u2 / u4 / u8
+    if (max_key <= 0xFFull) return 1;
+    if (max_key <= 0xFFFFull) return 2;
+    if (max_key <= 0xFFFFFFFFull) return 4;
+    return 8;
+}
+
+extern "C" int uq_narrow(uq_ctx* ctx, const uint32_t* d_key, uint64_t n, int itemsize, void* d_out) {
+    UQ_REQUIRE(ctx && (n == 0 || (d_key && d_out)), "uq_narrow: null argument");
+    if (n == 0) return 0;
+    switch (itemsize) {
+        case 1: narrow_kernel<uint8_t><<<blocks_for(n), ST, 0, ctx->stream>>>(d_key, n, (uint8_t*)d_out); break;
+        case 2: narrow_kernel<uint16_t><<<blocks_for(n), ST, 0, ctx->stream>>>(d_key, n, (uint16_t*)d_out); break;
+        case 4: narrow_kernel<uint32_t><<<blocks_for(n), ST, 0, ctx->stream>>>(d_key, n, (uint32_t*)d_out); break;
+        case 8: narrow_kernel<uint64_t><<<blocks_for(n), ST, 0, ctx->stream>>>(d_key, n, (uint64_t*)d_out); break;
+        default: UQ_REQUIRE(false, "uq_narrow: itemsize %d not in {1,2,4,8}", itemsize);
+    }
+    UQ_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int uq_stack_columns(uq_ctx* ctx, const void* const* h_d_cols, const int* h_itemsize, int ncols, uint64_t n,
+                                int common_itemsize, uint8_t* d_rows) {
+    UQ_REQUIRE(ctx && h_d_cols && h_itemsize && ncols >= 1, "uq_stack_columns: bad argument");
+    UQ_REQUIRE(common_itemsize == 1 || common_itemsize == 2 || common_itemsize == 4 || common_itemsize == 8, "uq_stack_columns: bad common itemsize");
+    if (n == 0) return 0;
+    for (int c = 0; c < ncols; ++c) {
+        UQ_REQUIRE(h_itemsize[c] >= 1 && h_itemsize[c] <= common_itemsize, "uq_stack_columns: column %d wider than the common dtype", c);
+        stack_column_kernel<<<blocks_for(n), ST, 0, ctx->stream>>>((const uint8_t*)h_d_cols[c], h_itemsize[c], n, ncols, c, common_itemsize, d_rows);
+        UQ_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" int uq_unstack_column(uq_ctx* ctx, const uint8_t* d_rows, uint64_t n, int ncols, int common_itemsize, int col,
+                                 int out_itemsize, void* d_out) {
+    UQ_REQUIRE(ctx && col >= 0 && col < ncols, "uq_unstack_column: bad argument");
+    if (n == 0) return 0;
+    unstack_column_kernel<<<blocks_for(n), ST, 0, ctx->stream>>>(d_rows, n, ncols, common_itemsize, col, out_itemsize, (uint8_t*)d_out);
+    UQ_LAUNCH_CHECK();
+    return 0;
+}

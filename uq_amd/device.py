@@ -1,0 +1,78 @@
+"""Device context: one process, one MI355X, one HIP stream.
+
+PyTorch is plumbing here -- it owns device memory (caching allocator) and the stream, and
+`torch.distributed` (RCCL) carries the multi-GPU exchange.  All compute goes through the C ABI
+(`uq_amd._lib`); tensors cross it as raw device pointers.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import call, UqHipError
+
+
+class Context:
+    """Binds a `uq_ctx` to a torch device and a dedicated torch stream (made current)."""
+
+    def __init__(self, device=0):
+        import torch
+        self.torch = torch
+        _lib.load()
+        if not torch.cuda.is_available():
+            raise UqHipError('no HIP device visible: the uQ hot path runs on MI355X only (no CPU fallback)')
+        self.device = torch.device('cuda', device)
+        torch.cuda.set_device(self.device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        torch.cuda.set_stream(self.stream)
+        h = C.c_void_p()
+        call('uq_ctx_create', int(device), C.c_void_p(self.stream.cuda_stream), C.byref(h))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            call('uq_ctx_destroy', self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- memory helpers (torch tensors as typed views of HBM)
+    def empty(self, n, dtype=None):
+        t = self.torch
+        return t.empty(int(n), dtype=dtype or t.uint8, device=self.device)
+
+    def zeros(self, n, dtype=None):
+        t = self.torch
+        return t.zeros(int(n), dtype=dtype or t.uint8, device=self.device)
+
+    def to_device(self, array):
+        """numpy array (any dtype) -> device tensor of bytes-compatible dtype."""
+        t = self.torch
+        a = np.ascontiguousarray(array)
+        if a.dtype in (np.uint16, np.uint32, np.uint64):
+            signed = {2: np.int16, 4: np.int32, 8: np.int64}[a.dtype.itemsize]
+            return t.from_numpy(a.view(signed)).to(self.device)
+        return t.from_numpy(a).to(self.device)
+
+    def bytes_to_device(self, data):
+        a = np.frombuffer(data, dtype=np.uint8)
+        return self.torch.from_numpy(a.copy() if not a.flags.writeable else a).to(self.device)
+
+    def to_numpy(self, tensor, dtype=None, shape=None):
+        a = tensor.detach().cpu().numpy()
+        if dtype is not None:
+            a = a.view(dtype)
+        if shape is not None:
+            a = a.reshape(shape)
+        return a
+
+    def sync(self):
+        call('uq_ctx_sync', self.h)
+
+    @staticmethod
+    def ptr(tensor):
+        return C.c_void_p(tensor.data_ptr()) if tensor is not None else C.c_void_p(0)

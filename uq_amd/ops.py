@@ -1,0 +1,220 @@
+"""Thin typed wrappers over the C ABI: torch tensors in, torch tensors out.  One function per
+entry point of include/uqhip.h; the reference site each one replaces is cited there."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import call, Stats, PackParams, UnpackParams, SynthSpec, UQ_NONE, load
+
+PATTERN_IDS = {'0.1': 0, '0.2': 1, '1.1': 2, '1.2': 3, '2.1': 4, '2.2': 5, '3.1': 6, '3.2': 7}
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+# ------------------------------------------------------------------ record index
+def count_lines(ctx, buf):
+    n = C.c_uint64()
+    call('uq_count_lines', ctx.h, _p(buf), buf.numel(), C.byref(n))
+    return n.value
+
+
+def index_lines(ctx, buf, nlines):
+    """int64 tensor [nlines + 1] of line start offsets (bit pattern of uint64)."""
+    t = ctx.torch
+    ls = t.empty(nlines + 1, dtype=t.int64, device=ctx.device)
+    call('uq_index_lines', ctx.h, _p(buf), buf.numel(), nlines, _p(ls))
+    return ls
+
+
+# ------------------------------------------------------------------ pass-1 statistics
+class HostStats:
+    """Host copy of uq_stats: counts[256][256] + ranges + first bad records."""
+
+    def __init__(self, s):
+        self.counts = np.ctypeslib.as_array(s.counts).reshape(256, 256).copy()
+        self.bad_plus = None if s.bad_plus == UQ_NONE else int(s.bad_plus)
+        self.bad_len = None if s.bad_len == UQ_NONE else int(s.bad_len)
+        self.len_min, self.len_max = int(s.len_min), int(s.len_max)
+        self.max_record_bytes = int(s.max_record_bytes)
+
+
+def stats_new(ctx):
+    t = ctx.torch
+    d = t.empty(C.sizeof(Stats), dtype=t.uint8, device=ctx.device)
+    call('uq_stats_init', ctx.h, _p(d))
+    return d
+
+
+def stats_accumulate(ctx, d_stats, buf, line_start, first_read, nreads):
+    call('uq_stats_accumulate', ctx.h, _p(buf), _p(line_start), first_read, nreads, _p(d_stats))
+
+
+def stats_fetch(ctx, d_stats):
+    s = Stats()
+    call('uq_d2h', ctx.h, C.byref(s), _p(d_stats), C.sizeof(Stats))
+    return HostStats(s)
+
+
+def first_occurrence(ctx, buf, line_start, first_read, nreads, index_base=0):
+    t = ctx.torch
+    d = t.full((256,), -1, dtype=t.int64, device=ctx.device)
+    call('uq_first_occurrence', ctx.h, _p(buf), _p(line_start), first_read, nreads, index_base, _p(d))
+    return d.cpu().numpy().view(np.uint64)
+
+
+# ------------------------------------------------------------------ pack
+def make_pack_params(bases, qualities, N_qual, bits_per_base, bits_per_quality, variable,
+                     dna_bytes_per_row, quality_bytes_per_row, dna_max, max_record_bytes):
+    p = PackParams()
+    for i in range(256):
+        p.dna_code[i] = -1; p.qual_code[i] = -1; p.n_qual[i] = -1
+    for i, ch in enumerate(bases): p.dna_code[ord(ch)] = i
+    for i, ch in enumerate(qualities): p.qual_code[ord(ch)] = i
+    for ch, code in N_qual.items(): p.n_qual[ord(ch)] = int(code)
+    p.bits_per_base = bits_per_base; p.bits_per_quality = bits_per_quality
+    p.variable = 1 if variable else 0
+    p.dna_bytes_per_row = dna_bytes_per_row; p.quality_bytes_per_row = quality_bytes_per_row
+    p.max_record_bytes = max_record_bytes; p.dna_max = dna_max
+    return p
+
+
+def pack(ctx, buf, line_start, first_read, nreads, params, dna=None, qual=None):
+    """Returns (dna uint8[nreads * C_dna], qual uint8[nreads * C_qual], bad read index or None)."""
+    t = ctx.torch
+    if dna is None: dna = t.empty(nreads * params.dna_bytes_per_row, dtype=t.uint8, device=ctx.device)
+    if qual is None: qual = t.empty(nreads * params.quality_bytes_per_row, dtype=t.uint8, device=ctx.device)
+    bad = t.empty(1, dtype=t.int64, device=ctx.device)
+    call('uq_pack', ctx.h, _p(buf), _p(line_start), first_read, nreads, C.byref(params), _p(dna), _p(qual), _p(bad))
+    return dna, qual, bad
+
+
+def bad_index(bad_tensor):
+    v = int(bad_tensor.cpu().numpy().view(np.uint64)[0])
+    return None if v == UQ_NONE else v
+
+
+# ------------------------------------------------------------------ patterns
+def pattern(ctx, table, rows, cols, pattern_id, out=None):
+    t = ctx.torch
+    if isinstance(pattern_id, str): pattern_id = PATTERN_IDS[pattern_id]
+    if out is None: out = t.empty(rows * cols, dtype=t.uint8, device=ctx.device)
+    call('uq_pattern', ctx.h, _p(table), rows, cols, pattern_id, _p(out))
+    return out
+
+
+def unpattern(ctx, payload, rows, cols, pattern_id, out=None):
+    t = ctx.torch
+    if isinstance(pattern_id, str): pattern_id = PATTERN_IDS[pattern_id]
+    if out is None: out = t.empty(rows * cols, dtype=t.uint8, device=ctx.device)
+    call('uq_unpattern', ctx.h, _p(payload), rows, cols, pattern_id, _p(out))
+    return out
+
+
+# ------------------------------------------------------------------ sort / gather / unique
+def argsort_rows(ctx, table, rows, cols):
+    t = ctx.torch
+    perm = t.empty(rows, dtype=t.int32, device=ctx.device)
+    call('uq_argsort_rows', ctx.h, _p(table), rows, cols, _p(perm))
+    return perm
+
+
+def gather_rows(ctx, table, table_rows, cols, index, n_out=None, out=None):
+    t = ctx.torch
+    if n_out is None: n_out = index.numel()
+    if out is None: out = t.empty(n_out * cols, dtype=t.uint8, device=ctx.device)
+    call('uq_gather_rows', ctx.h, _p(table), table_rows, cols, _p(index), index.element_size(), n_out, _p(out))
+    return out
+
+
+def unique_rows(ctx, table, rows, cols, want_key=True, want_sorted_key=True, want_unique=True):
+    """Returns (perm i32[rows], key or None, sorted_key or None, unique rows or None, nunique)."""
+    t = ctx.torch
+    perm = t.empty(rows, dtype=t.int32, device=ctx.device)
+    key = t.empty(rows, dtype=t.int32, device=ctx.device) if want_key else None
+    skey = t.empty(rows, dtype=t.int32, device=ctx.device) if want_sorted_key else None
+    uniq = t.empty(rows * cols, dtype=t.uint8, device=ctx.device) if want_unique else None
+    nu = C.c_uint64()
+    call('uq_unique_rows', ctx.h, _p(table), rows, cols, _p(perm), _p(key), _p(skey), _p(uniq), C.byref(nu))
+    if uniq is not None: uniq = uniq[:nu.value * cols]
+    return perm, key, skey, uniq, nu.value
+
+
+def key_itemsize(max_key):
+    return load().uq_key_itemsize(int(max_key))
+
+
+_NARROW_DT = {1: 'uint8', 2: 'int16', 4: 'int32', 8: 'int64'}
+
+
+def narrow(ctx, key, itemsize):
+    t = ctx.torch
+    out = t.empty(key.numel(), dtype=getattr(t, _NARROW_DT[itemsize]), device=ctx.device)
+    call('uq_narrow', ctx.h, _p(key), key.numel(), itemsize, _p(out))
+    return out
+
+
+def stack_columns(ctx, cols, common_itemsize):
+    t = ctx.torch
+    n = cols[0].numel()
+    ptrs = (C.c_void_p * len(cols))(*[c.data_ptr() for c in cols])
+    sizes = (C.c_int * len(cols))(*[c.element_size() for c in cols])
+    rows = t.empty(n * len(cols) * common_itemsize, dtype=t.uint8, device=ctx.device)
+    call('uq_stack_columns', ctx.h, ptrs, sizes, len(cols), n, common_itemsize, _p(rows))
+    return rows
+
+
+def unstack_column(ctx, rows, n, ncols, common_itemsize, col, out_itemsize):
+    t = ctx.torch
+    out = t.empty(n, dtype=getattr(t, _NARROW_DT[out_itemsize]), device=ctx.device)
+    call('uq_unstack_column', ctx.h, _p(rows), n, ncols, common_itemsize, col, out_itemsize, _p(out))
+    return out
+
+
+# ------------------------------------------------------------------ unpack
+def make_unpack_params(config):
+    p = UnpackParams()
+    bases, quals = config['bases'], config['qualities']
+    for i, ch in enumerate(bases): p.base_char[i] = ord(ch)
+    for i, ch in enumerate(quals): p.qual_char[i] = ord(ch)
+    for ch, code in config['N_qual'].items():
+        if 0 <= int(code) < 256: p.qual_n_base[int(code)] = ord(ch)
+    variable = bool(config['variable_read_lengths'])
+    lv = config['dna_max'] + (1 if variable else 0)
+    p.bits_per_base = config['bits_per_base']; p.bits_per_quality = config['bits_per_quality']
+    p.variable = 1 if variable else 0
+    p.dna_bytes_per_row = -(-p.bits_per_base * lv // 8)
+    p.quality_bytes_per_row = -(-p.bits_per_quality * lv // 8)
+    p.dna_max = config['dna_max']
+    return p
+
+
+def unpack(ctx, dna, qual, nreads, params):
+    t = ctx.torch
+    seq = t.empty(nreads * params.dna_max, dtype=t.uint8, device=ctx.device)
+    qtxt = t.empty(nreads * params.dna_max, dtype=t.uint8, device=ctx.device)
+    ln = t.empty(nreads, dtype=t.int32, device=ctx.device)
+    bad = t.empty(1, dtype=t.int64, device=ctx.device)
+    call('uq_unpack', ctx.h, _p(dna), _p(qual), nreads, C.byref(params), _p(seq), _p(qtxt), _p(ln), _p(bad))
+    return seq, qtxt, ln, bad
+
+
+# ------------------------------------------------------------------ synthetic input
+def synth_spec(spec):
+    """uq_amd.synth.Spec -> C struct."""
+    s = SynthSpec()
+    s.seed = spec.seed; s.len_lo = spec.len_lo; s.len_hi = spec.len_hi; s.n_rate = spec.n_rate
+    s.n_qual_exclusive = 1 if spec.n_qual_exclusive else 0
+    s.dup = spec.dup; s.dup_templates = spec.dup_templates; s.skip_len_mod4 = 1 if spec.skip_len_mod4 else 0
+    return s
+
+
+def synth_fastq(ctx, spec, first, n):
+    t = ctx.torch
+    cs = synth_spec(spec)
+    nbytes = C.c_uint64()
+    call('uq_synth_size', ctx.h, C.byref(cs), first, n, C.byref(nbytes))
+    out = t.empty(nbytes.value, dtype=t.uint8, device=ctx.device)
+    call('uq_synth_fastq', ctx.h, C.byref(cs), first, n, _p(out), nbytes.value)
+    return out
