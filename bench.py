@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py -- uQ encode hot path on MI355X: FASTQ MB/s on BASELINE.json configs[1].
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (config.workload): 10 M x 150 bp synthetic FASTQ ("synth-v1", seed 20261005) PER GPU, resident
+in HBM before the timed region, `--sort None --raw DNA QUAL QNAME --pattern 0.1 0.1`: weak scaling,
+reads are sharded record-parallel, rank r owns reads [r*10M, (r+1)*10M).
+One step = one pass of the hot path over the shard:
+    newline census -> record index -> pass-1 statistics (256x256 histogram, lengths, checks)
+    -> [N > 1: all-reduce of the statistics over RCCL, the path's only exchange without --sort]
+    -> alphabet / N-trick / bit-width decisions on the host (uq.py:448-545)
+    -> DNA 2-bit + QUAL 6-bit pack into the raw tables (pattern 0.1 = the tables as packed).
+QNAME column parsing is the reference's host-Python passes 2+4 ("next") and is not
+part of this step.  `value` = FASTQ bytes of all ranks / time, MAX over ranks.
+Besides the contract fields the JSON line carries `roofline` (pack kernel, HIP-event timed inside the
+timed region on the launch stream) and `cpu_baseline` (the faithful per-base Python loops of the
+oracle on one host core, on a bounded sample of the same input; rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+SEED = 20261003 + 2
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def host_decide(hs, notricks=False, pad=False):
+    from uq_amd import analysis
+    return analysis.decide_from_counts(hs.counts, hs.len_min, hs.len_max, notricks=notricks, pad=pad)
+
+
+def cpu_baseline(sample_bytes, n_sample):
+    """Oracle legs on the host: the per-base Python loops the reference runs (one core), and the C port."""
+    sys.path.insert(0, os.path.join(HERE, 'oracle'))
+    sys.path.insert(0, os.path.join(HERE, 'tests'))
+    import uq_oracle as O
+    t0 = time.perf_counter()
+    lines = O.read_lines(sample_bytes)
+    # pass-1 histogram + lengths (uq.py:369-375, 415-425), the per-base dict loop
+    sq = {}
+    dmin = dmax = len(lines[1]) - 1
+    for r in range(n_sample):
+        dna = lines[4 * r + 1][:-1]; q = lines[4 * r + 3][:-1]
+        if len(dna) > dmax: dmax = len(dna)
+        if len(dna) < dmin: dmin = len(dna)
+        for b, c in zip(dna, q):
+            try: sq[b][c] += 1
+            except KeyError:
+                sq.setdefault(b, {}); sq[b][c] = sq[b].get(c, 0) + 1
+    d = O.decide(sq, dmin, dmax)
+    dna, qual = O.encoder(lines, d['bases'], d['qualities'], d['N_qual'], d['dna_bytes_per_row'], d['quality_bytes_per_row'],
+                          d['bits_per_base'], d['bits_per_quality'], d['variable_read_lengths'])
+    t_py = time.perf_counter() - t0
+    out = {'value': round(len(sample_bytes) / 1e6 / t_py, 4), 'unit': 'MB/s', 'cores': 1, 'kind': 'port',
+           'sample': 'first %d reads (%.1f MB) of the same synthetic FASTQ: line split + per-base histogram + '
+                     'per-base pack loops of oracle/uq_oracle.py (CPython, one core), %.1f s' % (n_sample, len(sample_bytes) / 1e6, t_py),
+           'reads_per_s': round(n_sample / t_py, 1), 'host_cores': os.cpu_count()}
+    try:
+        import oracle_c
+        buf = np.frombuffer(sample_bytes, dtype=np.uint8)
+        t0 = time.perf_counter()
+        ls = oracle_c.index_lines(buf)
+        st = oracle_c.stats(buf, ls, 0, n_sample)
+        cd, cq, _ = oracle_c.pack(buf, ls, 0, n_sample, d['bases'], d['qualities'], d['N_qual'], d['bits_per_base'],
+                                  d['bits_per_quality'], d['variable_read_lengths'], d['dna_bytes_per_row'], d['quality_bytes_per_row'])
+        t_c = time.perf_counter() - t0
+        out['c_port_MBps'] = round(len(sample_bytes) / 1e6 / t_c, 2)
+        out['c_port_matches_python'] = bool(np.array_equal(cd, dna) and np.array_equal(cq, qual))
+    except Exception as e:  # the C leg is optional
+        out['c_port_error'] = repr(e)
+    return out, (dna, qual)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--reads', type=int, default=10_000_000, help='reads per GPU (default: BASELINE configs[1])')
+    ap.add_argument('--length', type=int, default=150)
+    ap.add_argument('--cpu-sample', type=int, default=100_000, help='reads timed on the host for cpu_baseline (0 = skip)')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d' % (args.gpus, world, args.gpus))
+
+    import torch
+    import torch.distributed as dist
+    from uq_amd import ops, synth
+    from uq_amd.device import Context
+
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+    ctx = Context(local_rank)
+
+    n = args.reads
+    spec = synth.Spec(SEED, args.length)
+    d_buf = ops.synth_fastq(ctx, spec, rank * n, n)           # resident in HBM before timing
+    fastq_bytes = d_buf.numel()
+    ctx.sync()
+
+    pack_events = []
+    state = {}
+
+    def step(timed):
+        nlines = ops.count_lines(ctx, d_buf)
+        ls = ops.index_lines(ctx, d_buf, nlines)
+        nreads = nlines // 4
+        st = ops.stats_new(ctx)
+        ops.stats_accumulate(ctx, st, d_buf, ls, 0, nreads)
+        if world > 1:
+            from uq_amd import dist as uqdist
+            hs = uqdist.allreduce_stats(ctx, st)
+        else:
+            hs = ops.stats_fetch(ctx, st)
+        if hs.bad_plus is not None or hs.bad_len is not None:
+            raise RuntimeError('malformed FASTQ record')
+        d = host_decide(hs)
+        p = ops.make_pack_params(d['bases'], d['qualities'], d['N_qual'], d['bits_per_base'], d['bits_per_quality'],
+                                 d['variable_read_lengths'], d['dna_bytes_per_row'], d['quality_bytes_per_row'],
+                                 d['dna_max'], hs.max_record_bytes)
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        dna, qual, bad = ops.pack(ctx, d_buf, ls, 0, nreads, p)
+        e1.record()
+        if timed: pack_events.append((e0, e1))
+        state.update(dna=dna, qual=qual, bad=bad, d=d, nreads=nreads, ls=ls)
+
+    for _ in range(args.warmup):
+        step(False)
+
+    def fence():
+        if world > 1: dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=ctx.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if ops.bad_index(state['bad']) is not None:
+        raise RuntimeError('pack reported an uncoded symbol at read %d' % ops.bad_index(state['bad']))
+    d = state['d']
+    nreads = state['nreads']
+    pack_ms = float(np.mean([a.elapsed_time(b) for a, b in pack_events]))
+    algo_bytes = fastq_bytes + nreads * (d['dna_bytes_per_row'] + d['quality_bytes_per_row'])
+    achieved = algo_bytes / 1e9 / (pack_ms / 1e3)
+
+    traffic = None
+    tpath = os.path.join(HERE, 'profiles', 'pack_traffic.json')
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get('reads') == nreads and tj.get('length') == args.length:
+                traffic = tj.get('hbm_bytes_per_launch')
+        except Exception:
+            traffic = None
+
+    result = {
+        'metric': 'FASTQ encode MB/s (150bp synthetic; bit-exact tables vs reference)',
+        'value': round(world * fastq_bytes / 1e6 / (dt / args.steps), 1), 'unit': 'MB/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic',
+        'reads_per_s': round(world * nreads / (dt / args.steps), 1),
+        'config': {'workload': 'BASELINE configs[1]: %d x %dbp synth-v1 FASTQ per GPU (%.3f GB), --sort None --raw DNA QUAL QNAME '
+                               '--pattern 0.1 0.1; step = census + index + stats + decisions + 2-bit DNA / %d-bit QUAL pack'
+                               % (nreads, args.length, fastq_bytes / 1e9, d['bits_per_quality']),
+                   'reads_per_gpu': nreads, 'read_length': args.length, 'fastq_bytes_per_gpu': fastq_bytes,
+                   'sharding': 'record-parallel, %d shard(s)' % world},
+        'roofline': {'bound': 'hbm', 'kernel': 'pack_tile_kernel', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
+                     'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                     'algorithmic_bytes_per_launch': int(algo_bytes), 'avg_launch_ms': round(pack_ms, 4)},
+    }
+
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        ns = min(args.cpu_sample, nreads)
+        end = int(state['ls'][4 * ns].item())
+        sample = bytes(d_buf[:end].cpu().numpy().tobytes())
+        cb, (rd, rq) = cpu_baseline(sample, ns)
+        gd = state['dna'][:ns * d['dna_bytes_per_row']].cpu().numpy().reshape(ns, -1)
+        gq = state['qual'][:ns * d['quality_bytes_per_row']].cpu().numpy().reshape(ns, -1)
+        cb['gpu_rows_match_oracle_on_sample'] = bool(np.array_equal(gd, rd) and np.array_equal(gq, rq))
+        if not cb['gpu_rows_match_oracle_on_sample']:
+            raise RuntimeError('parity failure: GPU rows differ from the oracle on the CPU sample')
+        result['cpu_baseline'] = cb
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
