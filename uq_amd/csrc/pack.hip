@@ -5,14 +5,17 @@
 // variable-length input, a sentinel 1 << (b * L); stored big-endian and right-aligned in C bytes.
 // A base byte that is not in `bases` takes DNA code 0 and the quality code N_qual[byte] (uq.py:151-153).
 //
-// Kernel `pack_tile_kernel` (the hot one): one workgroup packs a tile of R consecutive reads.
+// Kernel `pack_tile_kernel<BD, BQ, NTRICK>` (the hot one): one workgroup packs a tile of R consecutive
+// reads; bits per symbol are template constants so every shift is an immediate.
 //   A  the tile's records are one contiguous byte span of the FASTQ stream: it is copied to LDS with
-//      fully coalesced 16-byte loads (the QNAME and '+' lines ride along; they share cache lines).
-//   B  every (read, position) becomes a code byte through LUTs held in LDS; codes are written in
-//      REVERSED order (index t = L-1-j), the sentinel is simply code 1 at t = L, zeros above.
-//   C  a thread owns 8 consecutive codes of one read (one aligned ds_read_b64): 8*b bits = exactly b
-//      whole output bytes, so no thread ever shares a byte with another -- no atomics, no ballots.
-//   D  the packed tile is a contiguous span of the output table: stored with 16-byte coalesced stores.
+//      fully coalesced 16-byte loads, all issued before the first LDS write (the QNAME and '+' lines
+//      ride along; they share cache lines with the payload).
+//   B  a thread owns 8 consecutive symbols of one read, for BOTH streams: it pulls the 8 base and 8
+//      quality characters out of LDS (two aligned ds_read_b64 each, funnel-shifted), maps them to codes
+//      through LUTs held in LDS (the N-trick needs the base to choose the quality code), and Horner-
+//      packs them with v_lshl_or: 8 symbols of b bits = exactly b whole output bytes, so no thread
+//      ever shares a byte with another -- no atomics, no ballots.  The sentinel is code 1 at index L.
+//   C  the packed tile is a contiguous span of the output table: stored with 16-byte coalesced stores.
 // Algorithmic HBM bytes per read: record bytes read + C_dna + C_qual written (+32 B of line offsets).
 //
 // Kernel `pack_carry_kernel`: the Q9 corner (an N quality code equal to 2^b, uq.py:493-494) makes
@@ -31,27 +34,35 @@ struct PackLut {
 
 struct PackGeom {
     uint32_t R;            // reads per tile
-    uint32_t Lp;           // code bytes per read in LDS (multiple of 8)
-    uint32_t bd, bq;       // bits per base / quality
     uint32_t Cd, Cq;       // bytes per row
-    uint32_t Gd, Gq;       // 8-code groups per row
+    uint32_t G;            // 8-symbol groups per row = ceil((dna_max + variable) / 8)
     uint32_t variable;
     uint32_t stage_bytes;  // size of the staging region (multiple of 16)
-    uint32_t magicG;       // ceil(2^32 / (Gd + Gq))
+    uint32_t out_bytes;    // size of the output tiles region (multiple of 16)
+    uint32_t magicG;       // for division by G
     uint32_t dna_max;      // longest read the geometry was sized for
+    uint32_t fill_d, fill_q;  // the characters with code 0 (bases[0], qualities[0]) replicated in 4 bytes
 };
 
-// LDS carve (dynamic): [stage | out_d out_q alias stage] [codes_d] [codes_q] [meta u32 x (4R+1)] [luts]
+// 8 consecutive bytes at LDS byte offset `o` (any alignment) from two aligned 8-byte reads.
+__device__ __forceinline__ uint64_t lds_load8(const uint8_t* base, int32_t o) {
+    const uint64_t* p = (const uint64_t*)(base + (o & ~7));
+    const uint64_t q0 = p[0], q1 = p[1];
+    const uint32_t sh = (uint32_t)(o & 7) * 8;
+    return sh ? (q0 >> sh) | (q1 << (64 - sh)) : q0;
+}
+
+// LDS carve (dynamic): [16 B guard][stage][out_d | out_q][meta u32 x (4R+4)][luts 3 x 512 B]
+template <int BD, int BQ, bool NTRICK>
 __global__ __launch_bounds__(PK_THREADS) void pack_tile_kernel(const uint8_t* __restrict__ buf,
                                                                const uint64_t* __restrict__ ls, uint64_t first,
                                                                uint64_t n, PackLut lut, PackGeom g,
                                                                uint8_t* __restrict__ dna, uint8_t* __restrict__ qual,
                                                                unsigned long long* __restrict__ bad) {
     extern __shared__ __align__(16) uint8_t smem[];
-    uint8_t* stage = smem;
-    uint8_t* codes_d = stage + g.stage_bytes;
-    uint8_t* codes_q = codes_d + g.R * g.Lp;
-    uint32_t* meta = (uint32_t*)(codes_q + g.R * g.Lp);
+    uint8_t* stage = smem + 16;                       // reads of up to 8 bytes below offset 0 stay in bounds
+    uint8_t* out_d = stage + g.stage_bytes;
+    uint32_t* meta = (uint32_t*)(out_d + g.out_bytes);
     int16_t* l_dna = (int16_t*)(meta + 4 * g.R + 4);
     int16_t* l_qual = l_dna + 256;
     int16_t* l_nq = l_qual + 256;
@@ -59,83 +70,104 @@ __global__ __launch_bounds__(PK_THREADS) void pack_tile_kernel(const uint8_t* __
     const uint32_t tid = threadIdx.x;
     const uint64_t r0 = (uint64_t)blockIdx.x * g.R;
     const uint32_t Rt = (uint32_t)((n - r0) < g.R ? (n - r0) : g.R);   // reads in this tile
+    uint8_t* out_q = out_d + ((Rt * g.Cd + 15) & ~15u);
 
     l_dna[tid] = lut.dna_code[tid];
     l_qual[tid] = lut.qual_code[tid];
-    l_nq[tid] = lut.n_qual[tid];
+    if (NTRICK) l_nq[tid] = lut.n_qual[tid];
 
-    // ---- A: stage the span
+    // ---- A: stage the span (loads first, LDS writes after: up to 8 x 16 B in flight per lane)
     const uint64_t* lsp = ls + 4 * (first + r0);
     const uint64_t g0 = lsp[0];
     const uint64_t g1 = lsp[4 * Rt];
     const uint64_t a0 = ((uint64_t)(uintptr_t)buf + g0) & ~uint64_t(15);   // absolute, 16-aligned
     const uint32_t skew = (uint32_t)(((uint64_t)(uintptr_t)buf + g0) - a0);
     const uint32_t nvec = (uint32_t)((g1 - g0 + skew + 15) >> 4);
-    if ((uint64_t)nvec * 16 > g.stage_bytes) {   // a record longer than the caller's max_record_bytes
+    if ((uint64_t)nvec * 16 + 16 > g.stage_bytes) {   // a record longer than the caller's max_record_bytes
         if (tid == 0) atomicMin(bad, (unsigned long long)r0);
         return;
     }
     const uint4* src = (const uint4*)(uintptr_t)a0;
     uint4* dst = (uint4*)stage;
-    for (uint32_t i = tid; i < nvec; i += PK_THREADS) dst[i] = src[i];
+    for (uint32_t base = 0; base < nvec; base += 8 * PK_THREADS) {
+        uint4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t i = base + u * PK_THREADS + tid;
+            if (i < nvec) v[u] = src[i];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t i = base + u * PK_THREADS + tid;
+            if (i < nvec) dst[i] = v[u];
+        }
+    }
     for (uint32_t i = tid; i <= 4 * Rt; i += PK_THREADS) meta[i] = (uint32_t)(lsp[i] - g0) + skew;
     __syncthreads();
 
-    // ---- B: characters -> codes (reversed), sentinel, zero padding
-    const uint32_t w = tid >> 6, lane = tid & 63;
+    // ---- B: one thread = 8 consecutive symbols of one read, both streams: characters -> codes -> bits
+    const uint32_t items = Rt * g.G;
     uint32_t badr = 0xFFFFFFFFu;
-    for (uint32_t r = w; r < Rt; r += PK_THREADS / 64) {
+    for (uint32_t idx = tid; idx < items; idx += PK_THREADS) {
+        uint32_t r, gg;
+        fast_divmod(idx, g.G, g.magicG, r, gg);
         const uint32_t so = meta[4 * r + 1];
         uint32_t L = meta[4 * r + 2] - so - 1;
         const uint32_t qo = meta[4 * r + 3];
         if (L > g.dna_max || meta[4 * r + 4] - qo - 1 != L) { badr = r; L = 0; }
-        uint8_t* cd = codes_d + r * g.Lp;
-        uint8_t* cq = codes_q + r * g.Lp;
-        for (uint32_t j = lane; j < g.Lp; j += 64) {
-            if (j < L) {
-                uint32_t cb = stage[so + j], cc = stage[qo + j];
-                int dc = l_dna[cb], qc = l_qual[cc];
-                if (dc < 0) { dc = 0; qc = l_nq[cb]; }
-                if (qc < 0) { badr = r; qc = 0; }
-                uint32_t t = L - 1 - j;
-                cd[t] = (uint8_t)dc;
-                cq[t] = (uint8_t)qc;
-            } else {
-                uint8_t v = (uint8_t)((j == L) ? g.variable : 0);
-                cd[j] = v;
-                cq[j] = v;
-            }
+        // symbols t = 8gg .. 8gg+7 (t counts from the END of the read) = characters j = L-1-t, i.e. the
+        // 8 bytes ending at position L - 8gg; byte k of the window is character j = j0 + k
+        const int32_t j0 = (int32_t)L - 8 * (int32_t)gg - 8;
+        uint64_t cb8 = lds_load8(stage, (int32_t)so + j0);
+        uint64_t cq8 = lds_load8(stage, (int32_t)qo + j0);
+        if (j0 < 0) {   // window reaches above the first base: those symbols are zero (fill with code-0 characters)
+            const uint64_t m = j0 <= -8 ? 0ull : (~0ull << (8 * (uint32_t)(-j0)));
+            cb8 = (cb8 & m) | ((((uint64_t)g.fill_d << 32) | g.fill_d) & ~m);
+            cq8 = (cq8 & m) | ((((uint64_t)g.fill_q << 32) | g.fill_q) & ~m);
         }
+        const uint32_t cbw[2] = {(uint32_t)cb8, (uint32_t)(cb8 >> 32)};
+        const uint32_t cqw[2] = {(uint32_t)cq8, (uint32_t)(cq8 >> 32)};
+        // characters 0..3 are the MORE significant half of the group
+        uint32_t ad[2] = {0, 0}, aq[2] = {0, 0};
+        int32_t orall = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t cb = (cbw[k >> 2] >> (8 * (k & 3))) & 255u;
+            const uint32_t cc = (cqw[k >> 2] >> (8 * (k & 3))) & 255u;
+            int32_t dc = l_dna[cb];
+            int32_t qc = l_qual[cc];
+            if (NTRICK) {
+                if (dc < 0) { dc = 0; qc = l_nq[cb]; }
+            }
+            orall |= dc | qc;
+            ad[k >> 2] = (ad[k >> 2] << BD) | (uint32_t)dc;
+            aq[k >> 2] = (aq[k >> 2] << BQ) | (uint32_t)qc;
+        }
+        if (orall < 0) {            // a character without a code: report, keep the row deterministic
+            badr = r;
+            ad[0] = ad[1] = aq[0] = aq[1] = 0;
+        }
+        uint64_t vd = ((uint64_t)ad[0] << (4 * BD)) | ad[1];
+        uint64_t vq = ((uint64_t)aq[0] << (4 * BQ)) | aq[1];
+        if (g.variable) {                                  // sentinel = code 1 at symbol index t = L
+            const int32_t i = (int32_t)L - 8 * (int32_t)gg;
+            if (i >= 0 && i < 8) { vd |= 1ull << (BD * i); vq |= 1ull << (BQ * i); }
+        }
+        // 8 symbols of b bits = b whole bytes; byte index bi counts from the row's LAST byte
+        uint8_t* od = out_d + r * g.Cd + (g.Cd - 1) - BD * gg;
+        uint8_t* oq = out_q + r * g.Cq + (g.Cq - 1) - BQ * gg;
+        const uint32_t nd = g.Cd - BD * gg, nq = g.Cq - BQ * gg;     // bytes left in the row from here up
+#pragma unroll
+        for (int i = 0; i < BD; ++i)
+            if ((uint32_t)i < nd) od[-i] = (uint8_t)(vd >> (8 * i));
+#pragma unroll
+        for (int i = 0; i < BQ; ++i)
+            if ((uint32_t)i < nq) oq[-i] = (uint8_t)(vq >> (8 * i));
     }
     if (badr != 0xFFFFFFFFu) atomicMin(bad, (unsigned long long)(r0 + badr));
     __syncthreads();
 
-    // ---- C: 8 codes -> b bytes.  Output tiles alias the staging region (no longer needed).
-    uint8_t* out_d = stage;
-    uint8_t* out_q = stage + ((Rt * g.Cd + 15) & ~15u);
-    const uint32_t Gt = g.Gd + g.Gq;
-    const uint32_t items = Rt * Gt;
-    for (uint32_t idx = tid; idx < items; idx += PK_THREADS) {
-        uint32_t r, gg;
-        fast_divmod(idx, Gt, g.magicG, r, gg);
-        const bool isq = gg >= g.Gd;
-        if (isq) gg -= g.Gd;
-        const uint32_t b = isq ? g.bq : g.bd, C = isq ? g.Cq : g.Cd;
-        const uint8_t* cp = (isq ? codes_q : codes_d) + r * g.Lp + 8 * gg;
-        const uint64_t c8 = *(const uint64_t*)cp;
-        uint64_t v = 0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v |= ((c8 >> (8 * i)) & 0xFFull) << (b * i);
-        uint8_t* orow = (isq ? out_q : out_d) + r * C;
-        const uint32_t i0 = b * gg;                       // byte index counted from the row's LAST byte
-        for (uint32_t i = 0; i < b; ++i) {
-            uint32_t bi = i0 + i;
-            if (bi < C) orow[C - 1 - bi] = (uint8_t)(v >> (8 * i));
-        }
-    }
-    __syncthreads();
-
-    // ---- D: coalesced stores of the two packed tiles
+    // ---- C: coalesced stores of the two packed tiles
     {
         const uint64_t nb = (uint64_t)Rt * g.Cd;
         uint8_t* gdst = dna + r0 * g.Cd;
@@ -195,6 +227,28 @@ __global__ __launch_bounds__(256) void pack_carry_kernel(const uint8_t* __restri
     while (pd >= 0) { drow[pd] = (uint8_t)td; td >>= 8; --pd; }
     while (pq >= 0) { qrow[pq] = (uint8_t)tq; tq >>= 8; --pq; }
 }
+
+typedef void (*PackKernel)(const uint8_t*, const uint64_t*, uint64_t, uint64_t, PackLut, PackGeom, uint8_t*, uint8_t*, unsigned long long*);
+
+template <int BD, int BQ>
+PackKernel pick_nt(bool ntrick) { return ntrick ? pack_tile_kernel<BD, BQ, true> : pack_tile_kernel<BD, BQ, false>; }
+
+template <int BD>
+PackKernel pick_bq(int bq, bool ntrick) {
+    switch (bq) {
+        case 1: return pick_nt<BD, 1>(ntrick); case 2: return pick_nt<BD, 2>(ntrick); case 3: return pick_nt<BD, 3>(ntrick);
+        case 4: return pick_nt<BD, 4>(ntrick); case 5: return pick_nt<BD, 5>(ntrick); case 6: return pick_nt<BD, 6>(ntrick);
+        case 7: return pick_nt<BD, 7>(ntrick); default: return pick_nt<BD, 8>(ntrick);
+    }
+}
+
+PackKernel pick_kernel(int bd, int bq, bool ntrick) {
+    switch (bd) {
+        case 1: return pick_bq<1>(bq, ntrick); case 2: return pick_bq<2>(bq, ntrick); case 3: return pick_bq<3>(bq, ntrick);
+        case 4: return pick_bq<4>(bq, ntrick); case 5: return pick_bq<5>(bq, ntrick); case 6: return pick_bq<6>(bq, ntrick);
+        case 7: return pick_bq<7>(bq, ntrick); default: return pick_bq<8>(bq, ntrick);
+    }
+}
 }  // namespace
 
 extern "C" int uq_pack(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start, uint64_t first_read,
@@ -212,14 +266,19 @@ extern "C" int uq_pack(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line
 
     PackLut lut;
     int max_d = 0, max_q = 0;
+    bool ntrick = false;
+    int fill_d = -1, fill_q = -1;
     for (int i = 0; i < 256; ++i) {
         lut.dna_code[i] = hp->dna_code[i];
         lut.qual_code[i] = hp->qual_code[i];
         lut.n_qual[i] = (int16_t)(hp->n_qual[i] > 32767 ? 32767 : hp->n_qual[i]);
         if (hp->dna_code[i] > max_d) max_d = hp->dna_code[i];
         if (hp->qual_code[i] > max_q) max_q = hp->qual_code[i];
-        if (hp->dna_code[i] < 0 && hp->n_qual[i] > max_q) max_q = hp->n_qual[i];
+        if (hp->dna_code[i] < 0 && hp->n_qual[i] >= 0) { ntrick = true; if (hp->n_qual[i] > max_q) max_q = hp->n_qual[i]; }
+        if (hp->dna_code[i] == 0 && fill_d < 0) fill_d = i;
+        if (hp->qual_code[i] == 0 && fill_q < 0) fill_q = i;
     }
+    UQ_REQUIRE(fill_d >= 0 && fill_q >= 0, "uq_pack: the alphabets need a symbol with code 0");
     UQ_REQUIRE(max_d < (1 << bd), "uq_pack: a DNA code does not fit %u bits", bd);
     const bool carry = max_q >= (1 << bq);   // Q9: N quality code == 2^b (or beyond)
 
@@ -232,36 +291,34 @@ extern "C" int uq_pack(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line
     }
 
     PackGeom g;
-    g.bd = bd; g.bq = bq; g.Cd = Cd; g.Cq = Cq; g.variable = hp->variable ? 1 : 0;
-    g.Gd = (Cd + bd - 1) / bd; g.Gq = (Cq + bq - 1) / bq;
-    g.Lp = 8 * (g.Gd > g.Gq ? g.Gd : g.Gq);
-    if (g.Lp < ((Lv + 7) & ~7u)) g.Lp = (Lv + 7) & ~7u;
+    g.Cd = Cd; g.Cq = Cq; g.variable = hp->variable ? 1 : 0;
+    g.G = (Lv + 7) / 8;
     g.dna_max = (uint32_t)hp->dna_max;
-    g.magicG = magic_u32(g.Gd + g.Gq);
+    g.magicG = magic_u32(g.G);
+    g.fill_d = 0x01010101u * (uint32_t)fill_d;
+    g.fill_q = 0x01010101u * (uint32_t)fill_q;
     const uint32_t rec = (uint32_t)hp->max_record_bytes;
     UQ_REQUIRE(rec >= 4, "uq_pack: max_record_bytes not set (take it from uq_stats)");
-    // LDS budget: aim for ~3 workgroups per CU.
-    const uint32_t budget = 48 * 1024;
-    const uint32_t fixed = 3 * 512 + 64;
-    const uint32_t per_read = rec + 2 * g.Lp + 16;
+    // LDS budget per workgroup: ~32 KB keeps four to five workgroups (16-20 waves) resident per CU.
+    const uint32_t budget = 32 * 1024;
+    const uint32_t fixed = 3 * 512 + 16 + 64 + 64;
+    const uint32_t per_read = rec + Cd + Cq + 16;
     UQ_REQUIRE(per_read + fixed + 64 <= 150 * 1024, "uq_pack: a %u-byte record does not fit one LDS tile", rec);
-    uint32_t R = (budget - fixed - 64) / per_read;
+    uint32_t R = (budget - fixed) / per_read;
     if (R >= 16) R &= ~15u;            // keeps every tile's output offset 16-byte aligned
     if (R > 256) R = 256;
     if (R == 0) R = 1;
     g.R = R;
-    uint32_t stage = R * rec + 32;
-    uint32_t outb = ((R * Cd + 15) & ~15u) + R * Cq + 16;
-    if (outb > stage) stage = outb;
-    g.stage_bytes = (stage + 15) & ~15u;
-    const size_t lds = (size_t)g.stage_bytes + 2 * (size_t)R * g.Lp + (4 * R + 4) * 4 + 3 * 512;
+    g.stage_bytes = ((R * rec + 48) + 15) & ~15u;
+    g.out_bytes = (((R * Cd + 15) & ~15u) + R * Cq + 15) & ~15u;
+    const size_t lds = 16 + (size_t)g.stage_bytes + g.out_bytes + (4 * R + 4) * 4 + 3 * 512;
     UQ_REQUIRE(lds <= 160 * 1024, "uq_pack: tile needs %zu bytes of LDS", lds);
     const uint64_t tiles = (nreads + R - 1) / R;
     UQ_REQUIRE(tiles <= 0x7fffffffu, "uq_pack: too many tiles");
-    if (lds > 48 * 1024)
-        UQ_CHECK_HIP(hipFuncSetAttribute((const void*)pack_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    pack_tile_kernel<<<(uint32_t)tiles, PK_THREADS, lds, ctx->stream>>>(d_buf, d_line_start, first_read, nreads, lut, g, d_dna,
-                                                                        d_qual, (unsigned long long*)d_bad);
+    PackKernel k = pick_kernel((int)bd, (int)bq, ntrick);
+    if (lds > 48 * 1024) UQ_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    k<<<(uint32_t)tiles, PK_THREADS, lds, ctx->stream>>>(d_buf, d_line_start, first_read, nreads, lut, g, d_dna, d_qual,
+                                                         (unsigned long long*)d_bad);
     UQ_LAUNCH_CHECK();
     return 0;
 }
