@@ -104,16 +104,6 @@ __global__ __launch_bounds__(IDX_THREADS) void scatter_newlines_kernel(const uin
     }
 }
 
-__global__ void sum_partials_kernel(const uint32_t* __restrict__ partials, uint64_t n, uint64_t* __restrict__ out) {
-    __shared__ uint64_t lds[4];
-    uint64_t s = 0;
-    for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) s += partials[i];
-    s = wave_sum(s);
-    if (lane_id() == 0) lds[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) *out = lds[0] + lds[1] + lds[2] + lds[3];
-}
-
 int run_count(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint64_t* nblocks_out) {
     const uint32_t mis = (uint32_t)((uintptr_t)d_buf & 15);
     const uint64_t nvec = (nbytes + mis + 15) / 16;
@@ -140,10 +130,11 @@ extern "C" int uq_count_lines(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes
     UQ_REQUIRE(d_buf, "uq_count_lines: null buffer");
     uint64_t nb;
     UQ_TRY(run_count(ctx, d_buf, nbytes, &nb));
+    // exclusive scan of the per-tile counts right away: its total is the census, and uq_index_lines
+    // reuses the scanned offsets for the same buffer
     void* scr;
     UQ_TRY(uq_scratch(ctx, 256, &scr));
-    sum_partials_kernel<<<1, 256, 0, ctx->stream>>>(ctx->idx_partials, nb, (uint64_t*)scr);
-    UQ_LAUNCH_CHECK();
+    UQ_TRY(uq_scan_exclusive_u32(ctx, ctx->idx_partials, ctx->idx_partials, nb, (uint64_t*)scr));
     UQ_CHECK_HIP(hipMemcpyAsync(ctx->h_pinned, scr, 8, hipMemcpyDeviceToHost, ctx->stream));
     UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     *h_nlines = ctx->h_pinned[0];
@@ -167,9 +158,9 @@ extern "C" int uq_index_lines(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes
         nb = (nvec * 16 + IDX_TILE - 1) / IDX_TILE;
     } else {
         UQ_TRY(run_count(ctx, d_buf, nbytes, &nb));
+        UQ_TRY(uq_scan_exclusive_u32(ctx, ctx->idx_partials, ctx->idx_partials, nb, nullptr));
     }
-    ctx->idx_buf = nullptr;  // the partials are consumed (scanned in place) below
-    UQ_TRY(uq_scan_exclusive_u32(ctx, ctx->idx_partials, ctx->idx_partials, nb, nullptr));
+    ctx->idx_buf = nullptr;
     scatter_newlines_kernel<<<(uint32_t)nb, IDX_THREADS, 0, ctx->stream>>>((const uint4*)(d_buf - mis), mis, nbytes, nvec,
                                                                            ctx->idx_partials, nlines, d_line_start);
     UQ_LAUNCH_CHECK();

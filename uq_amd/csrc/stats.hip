@@ -2,29 +2,26 @@
 // Replaces the per-base dict increment `static_qualities[base][qual] += 1` and the length range /
 // sanity checks of uq.py:366-375, 382, 388, 415-425.
 //
-// Each half-wave (32 lanes) owns one record at a time; a lane takes 4 consecutive (base, quality)
-// pairs per step with two unaligned dword loads, so a 150-base read is one step of 38 lanes.  Counts
-// go to a workgroup-private LDS table [32 base slots][256 qualities] of u32 (ds_add_u32); base bytes
-// outside the 31 common nucleotide letters use global atomics on the full 256 x 256 table, so any
-// byte is counted exactly.  Tables are flushed to the u64 global table once per workgroup.
-// HBM traffic: the record bytes once + 32 B of line offsets per record.
+// Workgroups are persistent (they keep a private LDS count table for the whole launch) and walk
+// over tiles of R consecutive records.  A tile is one contiguous byte span: it is copied to LDS with
+// 16-byte coalesced loads (the next tile's span bounds are requested one iteration ahead), then each
+// half-wave (32 lanes) owns one record at a time and a lane takes 4 consecutive (base, quality) pairs
+// per step (a 150-base read is one step of 38 lanes).  Counts go to the LDS table
+// [64 base bytes 64..127][64 quality bytes qbase..qbase+63] of u32 with fire-and-forget ds_add_u32
+// (slot = byte - window base: no lookup, no wait between the four adds); any pair outside the two
+// windows uses a global atomic on the full 256 x 256 table, so every byte value is counted exactly.
+// `qbase` is a speed hint the host takes from the first record.  Tables are flushed to the u64 global
+// table once per workgroup.  A tile whose span exceeds the staging buffer (very long reads) is counted
+// straight from HBM.
+// Algorithmic HBM bytes: the record bytes once + 32 B of line offsets per record.
 #include "common.h"
 
 namespace {
 constexpr int ST_THREADS = 256;
-constexpr int ST_SLOTS = 32;              // slot 31 = "other"
-constexpr uint32_t ST_OTHER = 31;
-
-struct SlotLut { uint8_t slot[256]; uint8_t byte_of[ST_SLOTS]; };
-
-SlotLut make_slot_lut() {
-    SlotLut l;
-    memset(l.slot, ST_OTHER, sizeof(l.slot));
-    memset(l.byte_of, 0, sizeof(l.byte_of));
-    const char* common = "ACGTNacgtnRYKMSWBDHVU.-*Xryksw=";  // 31 letters seen in sequence lines
-    for (int i = 0; common[i] && i < 31; ++i) { l.slot[(uint8_t)common[i]] = (uint8_t)i; l.byte_of[i] = (uint8_t)common[i]; }
-    return l;
-}
+constexpr uint32_t ST_BBASE = 64;          // base bytes with an LDS counter: [64, 128)
+constexpr uint32_t ST_NB = 64, ST_NQ = 64;
+constexpr uint32_t ST_CAP = 12 * 1024;     // staging bytes per tile
+constexpr uint32_t ST_RMAX = 64;           // records per tile, upper bound (4 * ST_RMAX + 1 <= 2 * ST_THREADS)
 
 __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p) {
     uint32_t v;
@@ -37,58 +34,157 @@ __device__ __forceinline__ uint32_t load_tail(const uint8_t* buf, uint64_t pos, 
         if (pos + i < nbytes) v |= (uint32_t)buf[pos + i] << (8 * i);
     return v;
 }
+// 4 consecutive bytes at LDS byte offset `o` (any alignment).
+__device__ __forceinline__ uint32_t lds_load4(const uint8_t* base, uint32_t o) {
+    const uint32_t* p = (const uint32_t*)(base + (o & ~3u));
+    return __builtin_amdgcn_alignbyte(p[1], p[0], o & 3u);
+}
+
+__device__ __forceinline__ void count_pair(uint32_t b, uint32_t c, uint32_t qbase, uint32_t* hist, uq_stats* st) {
+    const uint32_t sb = b - ST_BBASE, sq = c - qbase;
+    if (sb < ST_NB && sq < ST_NQ) atomicAdd(&hist[sb * ST_NQ + sq], 1u);
+    else atomicAdd((unsigned long long*)&st->counts[b * 256 + c], 1ull);
+}
+__device__ __forceinline__ void count_quad(uint32_t vb, uint32_t vq, uint32_t cnt, uint32_t qbase, uint32_t* hist, uq_stats* st) {
+    count_pair(vb & 255u, vq & 255u, qbase, hist, st);
+    if (cnt > 1) count_pair((vb >> 8) & 255u, (vq >> 8) & 255u, qbase, hist, st);
+    if (cnt > 2) count_pair((vb >> 16) & 255u, (vq >> 16) & 255u, qbase, hist, st);
+    if (cnt > 3) count_pair(vb >> 24, vq >> 24, qbase, hist, st);
+}
+
+struct Acc {
+    uint32_t lmin = 0xFFFFFFFFu, lmax = 0, rmax = 0;
+    uint64_t bad_plus = UQ_NONE, bad_len = UQ_NONE;
+    __device__ __forceinline__ void record(uint64_t gr, bool plus_ok, uint32_t L, uint32_t Lq, uint32_t rb) {
+        if (!plus_ok) bad_plus = bad_plus < gr ? bad_plus : gr;
+        if (L != Lq) bad_len = bad_len < gr ? bad_len : gr;
+        lmin = L < lmin ? L : lmin;
+        lmax = L > lmax ? L : lmax;
+        rmax = rb > rmax ? rb : rmax;
+    }
+};
 
 __global__ __launch_bounds__(ST_THREADS) void stats_kernel(const uint8_t* __restrict__ buf, uint64_t nbytes,
                                                            const uint64_t* __restrict__ ls, uint64_t first,
-                                                           uint64_t n, SlotLut lut, uq_stats* __restrict__ st) {
-    __shared__ uint32_t hist[ST_SLOTS * 256];
-    __shared__ uint8_t slot_of[256];
-    for (int i = threadIdx.x; i < ST_SLOTS * 256; i += ST_THREADS) hist[i] = 0;
-    if (threadIdx.x < 256) slot_of[threadIdx.x] = lut.slot[threadIdx.x];
+                                                           uint64_t n, uint32_t R, uint32_t qbase, uq_stats* __restrict__ st) {
+    __shared__ uint32_t hist[ST_NB * ST_NQ];
+    __shared__ __align__(16) uint8_t stage[ST_CAP + 32];
+    __shared__ uint32_t meta[4 * ST_RMAX + 4];
+    __shared__ uint32_t tile_lmax;
+    for (int i = threadIdx.x; i < (int)(ST_NB * ST_NQ); i += ST_THREADS) hist[i] = 0;
     __syncthreads();
 
-    const uint32_t lane = lane_id();
+    const uint32_t tid = threadIdx.x, lane = lane_id();
     const uint32_t hl = lane & 31;
-    const uint64_t gid = ((uint64_t)blockIdx.x * (ST_THREADS / 64) + (threadIdx.x >> 6)) * 2 + (lane >> 5);
-    const uint64_t G = (uint64_t)gridDim.x * (ST_THREADS / 64) * 2;
-    uint32_t lmin = 0xFFFFFFFFu, lmax = 0, rmax = 0;
-    uint64_t bad_plus = UQ_NONE, bad_len = UQ_NONE;
+    const uint32_t hw = (tid >> 6) * 2 + (lane >> 5);       // half-wave index inside the workgroup, 0..7
+    constexpr uint32_t NHW = 2 * (ST_THREADS / 64);
+    Acc acc;
+    const uint64_t ntiles = (n + R - 1) / R;
 
-    for (uint64_t r = gid; r < n; r += G) {
-        const uint64_t* p = ls + 4 * (first + r);
-        const uint64_t p0 = p[0], s = p[1], e1 = p[2], q = p[3], e2 = p[4];
-        const uint32_t L = (uint32_t)(e1 - s - 1), Lq = (uint32_t)(e2 - q - 1);
-        if (hl == 0) {
-            if (buf[e1] != '+') bad_plus = bad_plus < r ? bad_plus : r;
-            if (L != Lq) bad_len = bad_len < r ? bad_len : r;
-            lmin = L < lmin ? L : lmin;
-            lmax = L > lmax ? L : lmax;
-            uint32_t rb = (uint32_t)(e2 - p0);
-            rmax = rb > rmax ? rb : rmax;
+    // Software pipeline over this workgroup's tiles t, t + S, t + 2S, ... (S = gridDim.x):
+    //   span bounds are requested two tiles ahead, the tile's bytes + line offsets one tile ahead (they
+    //   stay in registers, in flight, while the current tile is counted out of LDS).
+    const uint64_t S = gridDim.x;
+    struct Bounds { uint64_t g0, g1; };
+    struct Regs { uint4 v[3]; uint64_t m0, m1; uint64_t g0; uint32_t skew, nvec, Rt; bool exists, staged; };
+    auto load_bounds = [&](uint64_t tt) {
+        Bounds b{0, 0};
+        if (tt < ntiles) {
+            const uint32_t Rn = (uint32_t)((n - tt * R) < R ? (n - tt * R) : R);
+            b.g0 = ls[4 * (first + tt * R)]; b.g1 = ls[4 * (first + tt * R) + 4 * Rn];
         }
-        const uint32_t Lc = L < Lq ? L : Lq;
-        for (uint32_t j = hl * 4; j < Lc; j += 128) {
-            uint32_t vb = load_u32_unaligned(buf + s + j);   // s + j + 3 <= e1 + 1 < nbytes always
-            uint32_t vq = (q + j + 4 <= nbytes) ? load_u32_unaligned(buf + q + j) : load_tail(buf, q + j, nbytes);
-            uint32_t cnt = Lc - j < 4 ? Lc - j : 4;
+        return b;
+    };
+    auto issue = [&](uint64_t tt, Bounds b) {
+        Regs x;
+        x.exists = tt < ntiles; x.staged = false; x.m0 = x.m1 = 0; x.g0 = b.g0; x.skew = 0; x.nvec = 0; x.Rt = 0;
+        x.v[0] = x.v[1] = x.v[2] = make_uint4(0, 0, 0, 0);
+        if (!x.exists) return x;
+        x.Rt = (uint32_t)((n - tt * R) < R ? (n - tt * R) : R);
+        const uint64_t a0 = ((uint64_t)(uintptr_t)buf + b.g0) & ~uint64_t(15);
+        x.skew = (uint32_t)(((uint64_t)(uintptr_t)buf + b.g0) - a0);
+        const uint64_t span = b.g1 - b.g0 + x.skew;
+        x.staged = span + 16 <= ST_CAP;
+        if (!x.staged) return x;
+        x.nvec = (uint32_t)((span + 15) >> 4);
+        const uint4* src = (const uint4*)(uintptr_t)a0;
 #pragma unroll
-            for (uint32_t k = 0; k < 4; ++k) {
-                if (k < cnt) {
-                    uint32_t b = (vb >> (8 * k)) & 255u, c = (vq >> (8 * k)) & 255u;
-                    uint32_t sl = slot_of[b];
-                    if (sl != ST_OTHER) atomicAdd(&hist[sl * 256 + c], 1u);
-                    else atomicAdd((unsigned long long*)&st->counts[b * 256 + c], 1ull);
+        for (int u = 0; u < 3; ++u) { const uint32_t i = u * ST_THREADS + tid; if (i < x.nvec) x.v[u] = src[i]; }
+        const uint64_t* lsp = ls + 4 * (first + tt * R);
+        if (tid <= 4 * x.Rt) x.m0 = lsp[tid];
+        if (tid + ST_THREADS <= 4 * x.Rt) x.m1 = lsp[tid + ST_THREADS];
+        return x;
+    };
+
+    uint64_t t = blockIdx.x;
+    Bounds b_next = load_bounds(t + S);
+    Regs cur = issue(t, load_bounds(t));
+    for (; t < ntiles; t += S) {
+        const uint64_t r0 = t * R;
+        const uint32_t Rt = cur.Rt;
+        const Bounds b_nn = load_bounds(t + 2 * S);
+        if (cur.staged) {
+            if (tid <= 4 * Rt) meta[tid] = (uint32_t)(cur.m0 - cur.g0) + cur.skew;
+            if (tid + ST_THREADS <= 4 * Rt) meta[tid + ST_THREADS] = (uint32_t)(cur.m1 - cur.g0) + cur.skew;
+            if (tid == 0) tile_lmax = 0;
+#pragma unroll
+            for (int u = 0; u < 3; ++u) { const uint32_t i = u * ST_THREADS + tid; if (i < cur.nvec) ((uint4*)stage)[i] = cur.v[u]; }
+        }
+        __syncthreads();
+        const bool staged = cur.staged;
+        cur = issue(t + S, b_next);          // next tile's loads fly while this one is counted
+        b_next = b_nn;
+        if (staged) {
+            // per-record checks (one lane per record) and the longest read of the tile
+            for (uint32_t r = tid; r < Rt; r += ST_THREADS) {
+                const uint32_t p0 = meta[4 * r], s = meta[4 * r + 1], e1 = meta[4 * r + 2], q = meta[4 * r + 3], e2 = meta[4 * r + 4];
+                const uint32_t L = e1 - s - 1, Lq = e2 - q - 1;
+                acc.record(r0 + r, stage[e1] == '+', L, Lq, e2 - p0);
+                atomicMax(&tile_lmax, L < Lq ? L : Lq);
+            }
+            __syncthreads();
+            // pairs: one lane per group of 8 consecutive positions of one record
+            const uint32_t G8 = (tile_lmax + 7) >> 3;
+            const float rcpG = 1.0f / (float)(G8 ? G8 : 1);
+            const uint32_t items = Rt * G8;
+            for (uint32_t idx = tid; idx < items; idx += ST_THREADS) {
+                uint32_t r = (uint32_t)((float)idx * rcpG);
+                uint32_t gg = idx - r * G8;
+                if ((int32_t)gg < 0) { --r; gg += G8; } else if (gg >= G8) { ++r; gg -= G8; }
+                const uint32_t s = meta[4 * r + 1], e1 = meta[4 * r + 2], q = meta[4 * r + 3], e2 = meta[4 * r + 4];
+                const uint32_t L = e1 - s - 1, Lq = e2 - q - 1;
+                const uint32_t Lc = L < Lq ? L : Lq;
+                const uint32_t j = 8 * gg;
+                if (j >= Lc) continue;
+                const uint32_t cnt = Lc - j;
+                count_quad(lds_load4(stage, s + j), lds_load4(stage, q + j), cnt, qbase, hist, st);
+                if (cnt > 4) count_quad(lds_load4(stage, s + j + 4), lds_load4(stage, q + j + 4), cnt - 4, qbase, hist, st);
+            }
+        } else {
+            // oversize tile: straight from HBM, one record per half-wave
+            const uint64_t* lsp = ls + 4 * (first + r0);
+            for (uint32_t r = hw; r < Rt; r += NHW) {
+                const uint64_t* p = lsp + 4 * r;
+                const uint64_t p0 = p[0], s = p[1], e1 = p[2], q = p[3], e2 = p[4];
+                const uint32_t L = (uint32_t)(e1 - s - 1), Lq = (uint32_t)(e2 - q - 1);
+                if (hl == 0) acc.record(r0 + r, buf[e1] == '+', L, Lq, (uint32_t)(e2 - p0));
+                const uint32_t Lc = L < Lq ? L : Lq;
+                for (uint32_t j = hl * 4; j < Lc; j += 128) {
+                    const uint32_t vb = load_u32_unaligned(buf + s + j);   // s + j + 3 <= e1 + 1 < nbytes always
+                    const uint32_t vq = (q + j + 4 <= nbytes) ? load_u32_unaligned(buf + q + j) : load_tail(buf, q + j, nbytes);
+                    count_quad(vb, vq, Lc - j, qbase, hist, st);
                 }
             }
         }
+        __syncthreads();
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < (ST_SLOTS - 1) * 256; i += ST_THREADS) {
-        uint32_t v = hist[i];
-        if (v) atomicAdd((unsigned long long*)&st->counts[(uint32_t)lut.byte_of[i >> 8] * 256 + (i & 255)], (unsigned long long)v);
+    for (int i = threadIdx.x; i < (int)(ST_NB * ST_NQ); i += ST_THREADS) {
+        const uint32_t v = hist[i];
+        if (v) atomicAdd((unsigned long long*)&st->counts[(ST_BBASE + i / ST_NQ) * 256 + qbase + (i % ST_NQ)], (unsigned long long)v);
     }
-    lmin = wave_min(lmin); lmax = wave_max(lmax); rmax = wave_max(rmax);
-    bad_plus = wave_min(bad_plus); bad_len = wave_min(bad_len);
+    const uint32_t lmin = wave_min(acc.lmin), lmax = wave_max(acc.lmax), rmax = wave_max(acc.rmax);
+    const uint64_t bad_plus = wave_min(acc.bad_plus), bad_len = wave_min(acc.bad_len);
     if (lane == 0) {
         if (lmin != 0xFFFFFFFFu) atomicMin(&st->len_min, lmin);
         atomicMax(&st->len_max, lmax);
@@ -143,17 +239,35 @@ extern "C" int uq_stats_accumulate(uq_ctx* ctx, const uint8_t* d_buf, const uint
                                    uint64_t first_read, uint64_t nreads, uq_stats* d_stats) {
     UQ_REQUIRE(ctx && d_buf && d_line_start && d_stats, "uq_stats_accumulate: null argument");
     if (nreads == 0) return 0;
-    // The kernel needs the end of the buffer to guard its last unaligned load: read it from the index.
+    // Two host peeks (one sync): the shard's byte range from the index (tile sizing, tail guard) and
+    // the first record's offsets (to place the quality window of the LDS table).
     uint64_t* tmp = ctx->h_pinned;
     UQ_CHECK_HIP(hipMemcpyAsync(tmp, d_line_start + 4 * (first_read + nreads), 8, hipMemcpyDeviceToHost, ctx->stream));
+    UQ_CHECK_HIP(hipMemcpyAsync(tmp + 1, d_line_start + 4 * first_read, 40, hipMemcpyDeviceToHost, ctx->stream));
     UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     const uint64_t nbytes = tmp[0];
-    static const SlotLut lut = make_slot_lut();
-    uint64_t groups = (nreads + 1) / 2;
-    uint32_t blocks = (uint32_t)((groups + 3) / 4);
-    if (blocks > UQ_NUM_CU * 4) blocks = UQ_NUM_CU * 4;
-    if (blocks == 0) blocks = 1;
-    stats_kernel<<<blocks, ST_THREADS, 0, ctx->stream>>>(d_buf, nbytes, d_line_start, first_read, nreads, lut, d_stats);
+    const uint64_t q = tmp[4], e = tmp[5];
+    uint32_t qbase = 33;
+    uint64_t len = e > q + 1 ? e - q - 1 : 0;
+    if (len > 4096) len = 4096;
+    if (len) {
+        uint8_t* qh = (uint8_t*)(tmp + 8);
+        UQ_CHECK_HIP(hipMemcpyAsync(qh, d_buf + q, len, hipMemcpyDeviceToHost, ctx->stream));
+        UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        uint32_t mn = 255;
+        for (uint64_t i = 0; i < len; ++i)
+            if (qh[i] < mn) mn = qh[i];
+        if (mn >= 64) qbase = 59;          // Phred+64 era files: window [59, 123)
+        else if (mn < 33) qbase = 0;
+    }
+    // tile = R records sized from the average record length so that a typical span fits the staging buffer
+    const uint64_t avg = (nbytes - tmp[1]) / nreads + 1;
+    uint64_t R = (ST_CAP - 64) / (avg + avg / 8 + 1);
+    if (R > ST_RMAX) R = ST_RMAX;
+    if (R < 1) R = 1;
+    const uint64_t ntiles = (nreads + R - 1) / R;
+    uint32_t blocks = (uint32_t)(ntiles < UQ_NUM_CU * 5 ? ntiles : UQ_NUM_CU * 5);
+    stats_kernel<<<blocks, ST_THREADS, 0, ctx->stream>>>(d_buf, nbytes, d_line_start, first_read, nreads, (uint32_t)R, qbase, d_stats);
     UQ_LAUNCH_CHECK();
     return 0;
 }
