@@ -52,7 +52,12 @@ __device__ __forceinline__ uint64_t lds_load8(const uint8_t* base, int32_t o) {
     return sh ? (q0 >> sh) | (q1 << (64 - sh)) : q0;
 }
 
+constexpr int PK_NV = 5;   // 16-byte loads per lane per tile: a tile spans at most PK_NV * 256 * 16 = 20 KiB
+
 // LDS carve (dynamic): [16 B guard][stage][out_d | out_q][meta u32 x (4R+4)][luts 3 x 512 B]
+// Workgroups are persistent: each walks tiles b, b + S, b + 2S, ... with a software pipeline -- the
+// next tile's bytes and line offsets are loaded into registers (in flight) while the current tile is
+// packed out of LDS; span bounds are requested two tiles ahead.
 template <int BD, int BQ, bool NTRICK>
 __global__ __launch_bounds__(PK_THREADS) void pack_tile_kernel(const uint8_t* __restrict__ buf,
                                                                const uint64_t* __restrict__ ls, uint64_t first,
@@ -68,128 +73,154 @@ __global__ __launch_bounds__(PK_THREADS) void pack_tile_kernel(const uint8_t* __
     int16_t* l_nq = l_qual + 256;
 
     const uint32_t tid = threadIdx.x;
-    const uint64_t r0 = (uint64_t)blockIdx.x * g.R;
-    const uint32_t Rt = (uint32_t)((n - r0) < g.R ? (n - r0) : g.R);   // reads in this tile
-    uint8_t* out_q = out_d + ((Rt * g.Cd + 15) & ~15u);
-
     l_dna[tid] = lut.dna_code[tid];
     l_qual[tid] = lut.qual_code[tid];
     if (NTRICK) l_nq[tid] = lut.n_qual[tid];
 
-    // ---- A: stage the span (loads first, LDS writes after: up to 8 x 16 B in flight per lane)
-    const uint64_t* lsp = ls + 4 * (first + r0);
-    const uint64_t g0 = lsp[0];
-    const uint64_t g1 = lsp[4 * Rt];
-    const uint64_t a0 = ((uint64_t)(uintptr_t)buf + g0) & ~uint64_t(15);   // absolute, 16-aligned
-    const uint32_t skew = (uint32_t)(((uint64_t)(uintptr_t)buf + g0) - a0);
-    const uint32_t nvec = (uint32_t)((g1 - g0 + skew + 15) >> 4);
-    if ((uint64_t)nvec * 16 + 16 > g.stage_bytes) {   // a record longer than the caller's max_record_bytes
-        if (tid == 0) atomicMin(bad, (unsigned long long)r0);
-        return;
-    }
-    const uint4* src = (const uint4*)(uintptr_t)a0;
-    uint4* dst = (uint4*)stage;
-    for (uint32_t base = 0; base < nvec; base += 8 * PK_THREADS) {
-        uint4 v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const uint32_t i = base + u * PK_THREADS + tid;
-            if (i < nvec) v[u] = src[i];
+    const uint64_t R = g.R;
+    const uint64_t ntiles = (n + R - 1) / R;
+    const uint64_t S = gridDim.x;
+    struct Bounds { uint64_t g0, g1; };
+    struct Regs { uint4 v[PK_NV]; uint64_t m0; uint64_t g0; uint32_t skew, nvec, Rt; bool ok; };
+    auto load_bounds = [&](uint64_t tt) {
+        Bounds b{0, 0};
+        if (tt < ntiles) {
+            const uint32_t Rn = (uint32_t)((n - tt * R) < R ? (n - tt * R) : R);
+            b.g0 = ls[4 * (first + tt * R)]; b.g1 = ls[4 * (first + tt * R) + 4 * Rn];
         }
+        return b;
+    };
+    auto issue = [&](uint64_t tt, Bounds b) {
+        Regs x;
+        x.ok = false; x.m0 = 0; x.g0 = b.g0; x.skew = 0; x.nvec = 0; x.Rt = 0;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const uint32_t i = base + u * PK_THREADS + tid;
-            if (i < nvec) dst[i] = v[u];
-        }
-    }
-    for (uint32_t i = tid; i <= 4 * Rt; i += PK_THREADS) meta[i] = (uint32_t)(lsp[i] - g0) + skew;
-    __syncthreads();
+        for (int u = 0; u < PK_NV; ++u) x.v[u] = make_uint4(0, 0, 0, 0);
+        if (tt >= ntiles) return x;
+        x.Rt = (uint32_t)((n - tt * R) < R ? (n - tt * R) : R);
+        const uint64_t a0 = ((uint64_t)(uintptr_t)buf + b.g0) & ~uint64_t(15);   // absolute, 16-aligned
+        x.skew = (uint32_t)(((uint64_t)(uintptr_t)buf + b.g0) - a0);
+        const uint64_t span = b.g1 - b.g0 + x.skew;
+        x.nvec = (uint32_t)((span + 15) >> 4);
+        x.ok = span + 32 <= g.stage_bytes && x.nvec <= (uint32_t)(PK_NV * PK_THREADS);
+        if (!x.ok) return x;                          // a record longer than the caller's max_record_bytes
+        const uint4* src = (const uint4*)(uintptr_t)a0;
+#pragma unroll
+        for (int u = 0; u < PK_NV; ++u) { const uint32_t i = u * PK_THREADS + tid; if (i < x.nvec) x.v[u] = src[i]; }
+        if (tid <= 4 * x.Rt) x.m0 = ls[4 * (first + tt * R) + tid];
+        return x;
+    };
 
-    // ---- B: one thread = 8 consecutive symbols of one read, both streams: characters -> codes -> bits
-    const uint32_t items = Rt * g.G;
+    uint64_t t = blockIdx.x;
+    Bounds b_next = load_bounds(t + S);
+    Regs cur = issue(t, load_bounds(t));
     uint32_t badr = 0xFFFFFFFFu;
-    for (uint32_t idx = tid; idx < items; idx += PK_THREADS) {
-        uint32_t r, gg;
-        fast_divmod(idx, g.G, g.magicG, r, gg);
-        const uint32_t so = meta[4 * r + 1];
-        uint32_t L = meta[4 * r + 2] - so - 1;
-        const uint32_t qo = meta[4 * r + 3];
-        if (L > g.dna_max || meta[4 * r + 4] - qo - 1 != L) { badr = r; L = 0; }
-        // symbols t = 8gg .. 8gg+7 (t counts from the END of the read) = characters j = L-1-t, i.e. the
-        // 8 bytes ending at position L - 8gg; byte k of the window is character j = j0 + k
-        const int32_t j0 = (int32_t)L - 8 * (int32_t)gg - 8;
-        uint64_t cb8 = lds_load8(stage, (int32_t)so + j0);
-        uint64_t cq8 = lds_load8(stage, (int32_t)qo + j0);
-        if (j0 < 0) {   // window reaches above the first base: those symbols are zero (fill with code-0 characters)
-            const uint64_t m = j0 <= -8 ? 0ull : (~0ull << (8 * (uint32_t)(-j0)));
-            cb8 = (cb8 & m) | ((((uint64_t)g.fill_d << 32) | g.fill_d) & ~m);
-            cq8 = (cq8 & m) | ((((uint64_t)g.fill_q << 32) | g.fill_q) & ~m);
-        }
-        const uint32_t cbw[2] = {(uint32_t)cb8, (uint32_t)(cb8 >> 32)};
-        const uint32_t cqw[2] = {(uint32_t)cq8, (uint32_t)(cq8 >> 32)};
-        // characters 0..3 are the MORE significant half of the group
-        uint32_t ad[2] = {0, 0}, aq[2] = {0, 0};
-        int32_t orall = 0;
+    uint64_t bad_tile = UQ_NONE;
+    for (; t < ntiles; t += S) {
+        const uint64_t r0 = t * R;
+        const uint32_t Rt = cur.Rt;
+        uint8_t* out_q = out_d + ((Rt * g.Cd + 15) & ~15u);
+        const Bounds b_nn = load_bounds(t + 2 * S);
+        // ---- A: registers -> LDS
+        if (cur.ok) {
+            if (tid <= 4 * Rt) meta[tid] = (uint32_t)(cur.m0 - cur.g0) + cur.skew;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint32_t cb = (cbw[k >> 2] >> (8 * (k & 3))) & 255u;
-            const uint32_t cc = (cqw[k >> 2] >> (8 * (k & 3))) & 255u;
-            int32_t dc = l_dna[cb];
-            int32_t qc = l_qual[cc];
-            if (NTRICK) {
-                if (dc < 0) { dc = 0; qc = l_nq[cb]; }
+            for (int u = 0; u < PK_NV; ++u) { const uint32_t i = u * PK_THREADS + tid; if (i < cur.nvec) ((uint4*)stage)[i] = cur.v[u]; }
+        } else if (tid == 0) {
+            bad_tile = bad_tile < r0 ? bad_tile : r0;
+        }
+        __syncthreads();
+        const bool ok = cur.ok;
+        cur = issue(t + S, b_next);
+        b_next = b_nn;
+        if (ok) {
+            // ---- B: one thread = 8 consecutive symbols of one read, both streams: characters -> codes -> bits
+            const uint32_t items = Rt * g.G;
+            for (uint32_t idx = tid; idx < items; idx += PK_THREADS) {
+                uint32_t r, gg;
+                fast_divmod(idx, g.G, g.magicG, r, gg);
+                const uint32_t so = meta[4 * r + 1];
+                uint32_t L = meta[4 * r + 2] - so - 1;
+                const uint32_t qo = meta[4 * r + 3];
+                if (L > g.dna_max || meta[4 * r + 4] - qo - 1 != L) { badr = badr < (uint32_t)(r0 + r) ? badr : (uint32_t)(r0 + r); L = 0; }
+                // symbols t = 8gg .. 8gg+7 (t counts from the END of the read) = characters j = L-1-t, i.e. the
+                // 8 bytes ending at position L - 8gg; byte k of the window is character j = j0 + k
+                const int32_t j0 = (int32_t)L - 8 * (int32_t)gg - 8;
+                uint64_t cb8 = lds_load8(stage, (int32_t)so + j0);
+                uint64_t cq8 = lds_load8(stage, (int32_t)qo + j0);
+                if (j0 < 0) {   // window reaches above the first base: those symbols are zero (fill with code-0 characters)
+                    const uint64_t m = j0 <= -8 ? 0ull : (~0ull << (8 * (uint32_t)(-j0)));
+                    cb8 = (cb8 & m) | ((((uint64_t)g.fill_d << 32) | g.fill_d) & ~m);
+                    cq8 = (cq8 & m) | ((((uint64_t)g.fill_q << 32) | g.fill_q) & ~m);
+                }
+                const uint32_t cbw[2] = {(uint32_t)cb8, (uint32_t)(cb8 >> 32)};
+                const uint32_t cqw[2] = {(uint32_t)cq8, (uint32_t)(cq8 >> 32)};
+                // characters 0..3 are the MORE significant half of the group
+                uint32_t ad[2] = {0, 0}, aq[2] = {0, 0};
+                int32_t orall = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t cb = (cbw[k >> 2] >> (8 * (k & 3))) & 255u;
+                    const uint32_t cc = (cqw[k >> 2] >> (8 * (k & 3))) & 255u;
+                    int32_t dc = l_dna[cb];
+                    int32_t qc = l_qual[cc];
+                    if (NTRICK) {
+                        if (dc < 0) { dc = 0; qc = l_nq[cb]; }
+                    }
+                    orall |= dc | qc;
+                    ad[k >> 2] = (ad[k >> 2] << BD) | (uint32_t)dc;
+                    aq[k >> 2] = (aq[k >> 2] << BQ) | (uint32_t)qc;
+                }
+                if (orall < 0) {            // a character without a code: report, keep the row deterministic
+                    badr = badr < (uint32_t)(r0 + r) ? badr : (uint32_t)(r0 + r);
+                    ad[0] = ad[1] = aq[0] = aq[1] = 0;
+                }
+                uint64_t vd = ((uint64_t)ad[0] << (4 * BD)) | ad[1];
+                uint64_t vq = ((uint64_t)aq[0] << (4 * BQ)) | aq[1];
+                if (g.variable) {                                  // sentinel = code 1 at symbol index t = L
+                    const int32_t i = (int32_t)L - 8 * (int32_t)gg;
+                    if (i >= 0 && i < 8) { vd |= 1ull << (BD * i); vq |= 1ull << (BQ * i); }
+                }
+                // 8 symbols of b bits = b whole bytes; byte index counts from the row's LAST byte
+                uint8_t* od = out_d + r * g.Cd + (g.Cd - 1) - BD * gg;
+                uint8_t* oq = out_q + r * g.Cq + (g.Cq - 1) - BQ * gg;
+                const uint32_t nd = g.Cd - BD * gg, nq = g.Cq - BQ * gg;     // bytes left in the row from here up
+#pragma unroll
+                for (int i = 0; i < BD; ++i)
+                    if ((uint32_t)i < nd) od[-i] = (uint8_t)(vd >> (8 * i));
+#pragma unroll
+                for (int i = 0; i < BQ; ++i)
+                    if ((uint32_t)i < nq) oq[-i] = (uint8_t)(vq >> (8 * i));
             }
-            orall |= dc | qc;
-            ad[k >> 2] = (ad[k >> 2] << BD) | (uint32_t)dc;
-            aq[k >> 2] = (aq[k >> 2] << BQ) | (uint32_t)qc;
         }
-        if (orall < 0) {            // a character without a code: report, keep the row deterministic
-            badr = r;
-            ad[0] = ad[1] = aq[0] = aq[1] = 0;
-        }
-        uint64_t vd = ((uint64_t)ad[0] << (4 * BD)) | ad[1];
-        uint64_t vq = ((uint64_t)aq[0] << (4 * BQ)) | aq[1];
-        if (g.variable) {                                  // sentinel = code 1 at symbol index t = L
-            const int32_t i = (int32_t)L - 8 * (int32_t)gg;
-            if (i >= 0 && i < 8) { vd |= 1ull << (BD * i); vq |= 1ull << (BQ * i); }
-        }
-        // 8 symbols of b bits = b whole bytes; byte index bi counts from the row's LAST byte
-        uint8_t* od = out_d + r * g.Cd + (g.Cd - 1) - BD * gg;
-        uint8_t* oq = out_q + r * g.Cq + (g.Cq - 1) - BQ * gg;
-        const uint32_t nd = g.Cd - BD * gg, nq = g.Cq - BQ * gg;     // bytes left in the row from here up
-#pragma unroll
-        for (int i = 0; i < BD; ++i)
-            if ((uint32_t)i < nd) od[-i] = (uint8_t)(vd >> (8 * i));
-#pragma unroll
-        for (int i = 0; i < BQ; ++i)
-            if ((uint32_t)i < nq) oq[-i] = (uint8_t)(vq >> (8 * i));
-    }
-    if (badr != 0xFFFFFFFFu) atomicMin(bad, (unsigned long long)(r0 + badr));
-    __syncthreads();
-
-    // ---- C: coalesced stores of the two packed tiles
-    {
-        const uint64_t nb = (uint64_t)Rt * g.Cd;
-        uint8_t* gdst = dna + r0 * g.Cd;
-        if ((((uintptr_t)gdst) & 15) == 0) {
-            const uint32_t nv = (uint32_t)(nb >> 4);
-            for (uint32_t i = tid; i < nv; i += PK_THREADS) ((uint4*)gdst)[i] = ((const uint4*)out_d)[i];
-            for (uint32_t i = (nv << 4) + tid; i < nb; i += PK_THREADS) gdst[i] = out_d[i];
-        } else {
-            for (uint32_t i = tid; i < nb; i += PK_THREADS) gdst[i] = out_d[i];
+        __syncthreads();
+        if (ok) {
+            // ---- C: coalesced stores of the two packed tiles
+            {
+                const uint64_t nb = (uint64_t)Rt * g.Cd;
+                uint8_t* gdst = dna + r0 * g.Cd;
+                if ((((uintptr_t)gdst) & 15) == 0) {
+                    const uint32_t nv = (uint32_t)(nb >> 4);
+                    for (uint32_t i = tid; i < nv; i += PK_THREADS) ((uint4*)gdst)[i] = ((const uint4*)out_d)[i];
+                    for (uint32_t i = (nv << 4) + tid; i < nb; i += PK_THREADS) gdst[i] = out_d[i];
+                } else {
+                    for (uint32_t i = tid; i < nb; i += PK_THREADS) gdst[i] = out_d[i];
+                }
+            }
+            {
+                const uint64_t nb = (uint64_t)Rt * g.Cq;
+                uint8_t* gdst = qual + r0 * g.Cq;
+                if ((((uintptr_t)gdst) & 15) == 0) {
+                    const uint32_t nv = (uint32_t)(nb >> 4);
+                    for (uint32_t i = tid; i < nv; i += PK_THREADS) ((uint4*)gdst)[i] = ((const uint4*)out_q)[i];
+                    for (uint32_t i = (nv << 4) + tid; i < nb; i += PK_THREADS) gdst[i] = out_q[i];
+                } else {
+                    for (uint32_t i = tid; i < nb; i += PK_THREADS) gdst[i] = out_q[i];
+                }
+            }
         }
     }
-    {
-        const uint64_t nb = (uint64_t)Rt * g.Cq;
-        uint8_t* gdst = qual + r0 * g.Cq;
-        if ((((uintptr_t)gdst) & 15) == 0) {
-            const uint32_t nv = (uint32_t)(nb >> 4);
-            for (uint32_t i = tid; i < nv; i += PK_THREADS) ((uint4*)gdst)[i] = ((const uint4*)out_q)[i];
-            for (uint32_t i = (nv << 4) + tid; i < nb; i += PK_THREADS) gdst[i] = out_q[i];
-        } else {
-            for (uint32_t i = tid; i < nb; i += PK_THREADS) gdst[i] = out_q[i];
-        }
-    }
+    if (badr != 0xFFFFFFFFu) atomicMin(bad, (unsigned long long)badr);
+    if (bad_tile != UQ_NONE) atomicMin(bad, (unsigned long long)bad_tile);
 }
 
 // Exact big-integer form: thread per read, byte-serial addition with carry, straight from HBM.
@@ -299,25 +330,26 @@ extern "C" int uq_pack(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line
     g.fill_q = 0x01010101u * (uint32_t)fill_q;
     const uint32_t rec = (uint32_t)hp->max_record_bytes;
     UQ_REQUIRE(rec >= 4, "uq_pack: max_record_bytes not set (take it from uq_stats)");
-    // LDS budget per workgroup: ~32 KB keeps four to five workgroups (16-20 waves) resident per CU.
-    const uint32_t budget = 32 * 1024;
-    const uint32_t fixed = 3 * 512 + 16 + 64 + 64;
-    const uint32_t per_read = rec + Cd + Cq + 16;
-    UQ_REQUIRE(per_read + fixed + 64 <= 150 * 1024, "uq_pack: a %u-byte record does not fit one LDS tile", rec);
-    uint32_t R = (budget - fixed) / per_read;
+    // A tile is at most PK_NV * 256 * 16 B = 20 KiB of FASTQ (what one workgroup keeps in flight in registers).
+    const uint32_t stage_cap = PK_NV * PK_THREADS * 16;
+    UQ_REQUIRE(rec + 64 <= stage_cap, "uq_pack: a %u-byte record does not fit one %u-byte tile", rec, stage_cap);
+    uint32_t R = (stage_cap - 64) / rec;
+    if (R > (PK_THREADS - 1) / 4) R = (PK_THREADS - 1) / 4;     // 4R + 1 line offsets, one per lane
     if (R >= 16) R &= ~15u;            // keeps every tile's output offset 16-byte aligned
-    if (R > 256) R = 256;
     if (R == 0) R = 1;
     g.R = R;
-    g.stage_bytes = ((R * rec + 48) + 15) & ~15u;
+    g.stage_bytes = stage_cap + 32;
     g.out_bytes = (((R * Cd + 15) & ~15u) + R * Cq + 15) & ~15u;
     const size_t lds = 16 + (size_t)g.stage_bytes + g.out_bytes + (4 * R + 4) * 4 + 3 * 512;
     UQ_REQUIRE(lds <= 160 * 1024, "uq_pack: tile needs %zu bytes of LDS", lds);
     const uint64_t tiles = (nreads + R - 1) / R;
-    UQ_REQUIRE(tiles <= 0x7fffffffu, "uq_pack: too many tiles");
+    uint32_t per_cu = (uint32_t)((160 * 1024) / lds);
+    if (per_cu > 6) per_cu = 6;
+    if (per_cu < 1) per_cu = 1;
+    const uint64_t blocks = tiles < (uint64_t)UQ_NUM_CU * per_cu ? tiles : (uint64_t)UQ_NUM_CU * per_cu;
     PackKernel k = pick_kernel((int)bd, (int)bq, ntrick);
     if (lds > 48 * 1024) UQ_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    k<<<(uint32_t)tiles, PK_THREADS, lds, ctx->stream>>>(d_buf, d_line_start, first_read, nreads, lut, g, d_dna, d_qual,
+    k<<<(uint32_t)blocks, PK_THREADS, lds, ctx->stream>>>(d_buf, d_line_start, first_read, nreads, lut, g, d_dna, d_qual,
                                                          (unsigned long long*)d_bad);
     UQ_LAUNCH_CHECK();
     return 0;
