@@ -1,0 +1,143 @@
+"""GPU end-to-end parity: the drop-in CLI (uq_amd.uq) against (i) the .uQ files the reference itself wrote
+(tests/golden/, byte for byte per member) and (ii) the oracle on seeded synthetic inputs over the whole
+--sort x --raw x --pattern surface; then decode round trips."""
+import io
+import json
+import os
+import tarfile
+
+import numpy as np
+import pytest
+
+import uq_oracle as O
+from uq_amd import synth, uq
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+GOLDEN = sorted(f[:-5] for f in os.listdir(GOLD) if f.endswith('.json'))
+
+
+def _run_encode(ctx, tmp_path, fastq_bytes, flags):
+    inp = tmp_path / 'in.fastq'
+    inp.write_bytes(fastq_bytes)
+    out = tmp_path / 'out.uQ'
+    args = uq.build_parser().parse_args(['-i', str(inp), '-o', str(out), '--quiet'] + flags)
+    uq.validate_args(args)
+    s = uq.Session(args, ctx=ctx)
+    s.encode()
+    with tarfile.open(out) as t:
+        names = t.getnames()
+        members = {m.name: t.extractfile(m).read() for m in t.getmembers()}
+    config = json.loads(members.pop('config.json').decode())
+    return config, members, names, str(out)
+
+
+def _run_decode(ctx, path):
+    args = uq.build_parser().parse_args(['-i', path, '--decode', '--quiet'])
+    uq.validate_args(args)
+    buf = io.BytesIO()
+    uq.Session(args, ctx=ctx).decode(out=buf)
+    return buf.getvalue()
+
+
+def _records(fq):
+    lines = fq.split(b'\n')
+    return [b'\n'.join(lines[i:i + 4]) for i in range(0, len(lines) - 1, 4)]
+
+
+def _oracle_flags(flags):
+    def opt(k, n):
+        if k in flags:
+            i = flags.index(k); return flags[i + 1:i + 1 + n]
+    sort = opt('--sort', 1); sort = None if (sort is None or sort[0] == 'None') else sort[0]
+    raw = None
+    if '--raw' in flags:
+        raw = []
+        for x in flags[flags.index('--raw') + 1:]:
+            if x.startswith('--'): break
+            raw.append(x)
+    return dict(sort=sort, raw=raw, pattern=opt('--pattern', 2), notricks='--notricks' in flags, pad='--pad' in flags)
+
+
+@pytest.mark.parametrize('name', GOLDEN)
+def test_cli_matches_reference_output(ctx, tmp_path, name):
+    meta = json.load(open(os.path.join(GOLD, name + '.json')))
+    fq = open(os.path.join(GOLD, name + '.fastq'), 'rb').read()
+    ref_cfg, ref_members = O.read_tar(os.path.join(GOLD, name + '.uQ'))
+    cfg, members, names, path = _run_encode(ctx, tmp_path, fq, meta['flags'])
+    assert set(members) == set(ref_members)
+    for k in ref_cfg:
+        if k in ('sort', 'raw', 'pattern'): continue
+        assert json.loads(json.dumps(cfg[k])) == ref_cfg[k], k
+    assert cfg['pattern'] == ref_cfg['pattern'] and sorted(map(str, cfg['raw'])) == sorted(map(str, ref_cfg['raw']))
+    if meta['stable_patch'] or 'sort' not in ' '.join(meta['flags']) or '--sort None' in ' '.join(meta['flags']):
+        for k in ref_members:
+            assert members[k] == ref_members[k], k
+    else:
+        # reference ran numpy's unstable argsort (Q17): the sorted-on table, every unique table and the
+        # sorted-on key are order-free; the others agree as multisets inside each tie group = after decoding
+        for k in ('DNA', 'DNA.key', 'QUAL', 'QNAME_1', 'QNAME_2', 'QNAME_3', 'QNAME_4'):
+            if k in ref_members: assert members[k] == ref_members[k], k
+        assert sorted(_records(O.decode(ref_cfg, ref_members).encode('latin-1'))) == sorted(_records(_run_decode(ctx, path)))
+    # QNAME members come out in numeric order (Q6)
+    q = [n for n in names if n.startswith('QNAME_')]
+    assert q == sorted(q, key=lambda s: int(s.split('_')[1].split('.')[0]))
+    # decode round trip: exact text when unsorted, same multiset of records when sorted
+    text = _run_decode(ctx, path)
+    if name == 'fixed_n_newcode':
+        return      # Q9: the reference's own decoder cannot decode a new N quality code either
+    if ref_cfg['sort'] == [None]: assert text == fq
+    else: assert sorted(_records(text)) == sorted(_records(fq))
+
+
+MIXES = [(s, r, p) for s in (None, 'DNA', 'QUAL', 'QNAME')
+         for r in ([], ['DNA'], ['QUAL', 'QNAME'], ['DNA', 'QUAL', 'QNAME'])
+         for p in (['0.1', '0.2'], ['1.1', '1.2'], ['2.1', '2.2'], ['3.1', '3.2'])]
+
+
+@pytest.mark.parametrize('sort,raw,pattern', MIXES[::3], ids=lambda v: str(v))
+def test_cli_matches_oracle_all_mixes(ctx, tmp_path, sort, raw, pattern):
+    fq = synth.fastq(20261003 + 30, 1500, (30, 61), n_rate=2, dup='both', dup_templates=40)
+    flags = (['--sort', sort] if sort else []) + (['--raw'] + raw if raw else []) + ['--pattern'] + pattern
+    cfg, members, names, path = _run_encode(ctx, tmp_path, fq, flags)
+    ocfg, omembers, _ = O.encode(fq, sort=sort, raw=raw or None, pattern=pattern)
+    assert set(members) == set(omembers)
+    for k in omembers:
+        assert members[k] == omembers[k], k
+    text = _run_decode(ctx, path)
+    assert text.decode('latin-1') == O.decode(ocfg, omembers)
+    if sort is None: assert text == fq
+    else: assert sorted(_records(text)) == sorted(_records(fq))
+
+
+def test_cli_config1_fixed_100bp(ctx, tmp_path):
+    """BASELINE.json configs[0]: 10k x 100bp, --sort None --raw DNA QUAL QNAME --pattern 0.1 0.1."""
+    fq = open(os.path.join(GOLD, 'cfg1_10k_100bp.fastq'), 'rb').read()
+    cfg, members, names, path = _run_encode(ctx, tmp_path, fq, ['--sort', 'None', '--raw', 'DNA', 'QUAL', 'QNAME', '--pattern', '0.1', '0.1'])
+    assert cfg['bits_per_base'] == 2 and cfg['bits_per_quality'] == 6 and cfg['reads'] == 10000
+    assert np.load(io.BytesIO(members['DNA.raw'])).shape == (10000, 25)
+    assert np.load(io.BytesIO(members['QUAL.raw'])).shape == (10000, 75)
+    assert _run_decode(ctx, path) == fq
+
+
+def test_cli_test_mode_without_compressor(ctx, tmp_path):
+    """--test without --compressor forces sort None and pattern 0.1 (Q3) and picks the smallest raw set."""
+    fq = synth.fastq(20261003 + 31, 800, 40, dup='both', dup_templates=10)
+    cfg, members, names, path = _run_encode(ctx, tmp_path, fq, ['--test'])
+    assert cfg['sort'] == [None] and cfg['pattern'] == ['0.1', '0.1']
+    assert _run_decode(ctx, path) == fq
+
+
+def test_cli_errors(ctx, tmp_path):
+    p = tmp_path / 'bad.fastq'
+    p.write_bytes(b'@a:1\nACGT\n+\nIIII\n@a:2\nAC\n+\nIII\n')
+    args = uq.build_parser().parse_args(['-i', str(p), '--quiet'])
+    with pytest.raises(uq.UqError):
+        uq.Session(uq.validate_args(args), ctx=ctx).encode()
+    p.write_bytes(b'@a:1\nACGT\n+\nIIII\n@a:2\nAC\n')
+    with pytest.raises(uq.UqError):
+        uq.Session(uq.validate_args(uq.build_parser().parse_args(['-i', str(p), '--quiet'])), ctx=ctx).encode()
+    with pytest.raises(uq.UqError):
+        uq.validate_args(uq.build_parser().parse_args(['-i', str(p), '--pattern', '0.1']))
+    with pytest.raises(uq.UqError):
+        uq.validate_args(uq.build_parser().parse_args(['-i', str(p), '--sort', 'bogus']))

@@ -1,0 +1,128 @@
+"""CPU: the oracle (oracle/uq_oracle.py) against the outputs of the reference itself (tests/golden/*.uQ,
+written by tests/golden/make_golden.py) -- byte for byte per tar member -- plus the README's worked
+geometry and the hand-checked micro-vectors of SURVEY.md A.7.  This is what pins the oracle."""
+import glob
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+
+import uq_oracle as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+GOLDEN = sorted(os.path.basename(f)[:-5] for f in glob.glob(os.path.join(GOLD, '*.json')))
+
+
+def flags_to_kwargs(flags):
+    def opt(k, n):
+        if k in flags:
+            i = flags.index(k); return flags[i + 1:i + 1 + n]
+    sort = opt('--sort', 1); sort = None if (sort is None or sort[0] == 'None') else sort[0]
+    raw = None
+    if '--raw' in flags:
+        raw = []
+        for x in flags[flags.index('--raw') + 1:]:
+            if x.startswith('--'): break
+            raw.append(x)
+    return dict(sort=sort, raw=raw, pattern=opt('--pattern', 2), notricks='--notricks' in flags, pad='--pad' in flags)
+
+
+def test_golden_set_is_complete():
+    assert len(GOLDEN) >= 12
+    for name in GOLDEN:
+        for ext in ('.fastq', '.uQ', '.json'):
+            assert os.path.exists(os.path.join(GOLD, name + ext))
+
+
+@pytest.mark.parametrize('name', GOLDEN)
+def test_oracle_matches_reference_members(name):
+    meta = json.load(open(os.path.join(GOLD, name + '.json')))
+    fq = open(os.path.join(GOLD, name + '.fastq'), 'rb').read()
+    ref_cfg, ref_members = O.read_tar(os.path.join(GOLD, name + '.uQ'))
+    cfg, members, tables = O.encode(fq, **flags_to_kwargs(meta['flags']))
+    assert set(members) == set(ref_members)
+    for k in ref_cfg:
+        if k in ('sort', 'raw', 'pattern'): continue
+        assert json.loads(json.dumps(cfg[k])) == ref_cfg[k], k
+    unstable = (not meta['stable_patch']) and cfg['sort'] not in ([None], None)
+    for k in ref_members:
+        if unstable and k in ('QUAL.key', 'QNAME.key', 'QUAL.raw', 'DNA.raw') and members[k] != ref_members[k]:
+            # numpy's default argsort is unstable (Q17): same multiset inside every tie group
+            a = np.load(io.BytesIO(members[k])); b = np.load(io.BytesIO(ref_members[k]))
+            assert a.shape == b.shape and np.array_equal(np.sort(a, axis=0), np.sort(b, axis=0)), k
+            continue
+        assert members[k] == ref_members[k], k
+
+
+@pytest.mark.parametrize('name', [n for n in GOLDEN if n != 'fixed_n_newcode'])
+def test_oracle_decode_roundtrip(name):
+    fq = open(os.path.join(GOLD, name + '.fastq'), 'rb').read()
+    ref_cfg, ref_members = O.read_tar(os.path.join(GOLD, name + '.uQ'))
+    text = O.decode(ref_cfg, ref_members).encode('latin-1')
+    rec = lambda b: sorted(b'\n'.join(x) for x in zip(*[iter(b.split(b'\n')[:-1])] * 4))
+    if ref_cfg['sort'] == [None]: assert text == fq
+    else: assert rec(text) == rec(fq)
+
+
+def test_readme_geometry():
+    """README.md:158-167, 287, 315-316: 5 symbols -> 3 bit, 36 bp -> 14 B; 26 quals -> 5 bit -> 23 B."""
+    assert O.bits_for(5, False) == 3 and -(-3 * 36 // 8) == 14
+    assert O.bits_for(26, False) == 5 and -(-5 * 36 // 8) == 23
+    assert [O.bits_for(n, False) for n in (1, 4, 5, 8, 9, 16, 17, 32, 33, 64, 65, 128, 129, 256)] == [2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8]
+    assert [O.bits_for(n, True) for n in (4, 5, 16, 17, 41, 200)] == [2, 4, 4, 8, 8, 8]
+
+
+def test_micro_vectors_a7():
+    """SURVEY.md A.7, hand-checked."""
+    def rows(reads, quals, **kw):
+        fq = ''.join('@r:%d:%d\n%s\n+\n%s\n' % (i % 2, i, s, q) for i, (s, q) in enumerate(zip(reads, quals))).encode()
+        return O.encode(fq, raw=['DNA', 'QUAL', 'QNAME'], **kw)
+    # bases 'ACT' (G removed by the N-trick), b=2, read ACGTA -> codes 0,1,0,2,0 -> 0b0001001000 -> [0x00, 0x48]
+    cfg, m, t = rows(['ACGTA', 'ACATA', 'TCATC'], ['IHGHH', 'HIIIH', 'HHIHI'])
+    assert cfg['bases'] == 'ACT' and cfg['N_qual'] == {'G': 0} and t['DNA'][0].tolist() == [0x00, 0x48]
+    # ACGT, b=2, L=6
+    reads = ['ACGTAC', 'TTTTTT', 'ACGTAC', 'GATCCA', 'AAAAAA', 'GATCCA', 'ACGTAC', 'CCCCCC']
+    cfg, m, t = rows(reads, ['IIHH!#', 'IIIIII', '#####I', 'IHIHIH', '!!!!!!', 'IIIIII', 'HHHHHH', 'IIIIII'])
+    assert t['DNA'].tolist() == [[1, 177], [15, 255], [1, 177], [8, 212], [0, 0], [8, 212], [1, 177], [5, 85]]
+    fq = ''.join('@r:%d:%d\n%s\n+\n%s\n' % (i % 2, i, s, 'IIHH!#' if i == 0 else 'IIIIII') for i, s in enumerate(reads)).encode()
+    cfg, m, t = O.encode(fq, sort='DNA', pattern=['1.2', '0.1'])
+    assert np.load(io.BytesIO(m['DNA.key'])).tolist() == [0, 1, 1, 1, 2, 3, 3, 4]
+    assert np.load(io.BytesIO(m['DNA.key'])).dtype == np.uint8
+    d = np.load(io.BytesIO(m['DNA']))
+    assert d.shape == (2, 5) and d.tolist() == [[0, 177, 85, 212, 255], [0, 1, 5, 8, 15]] and d.flags.f_contiguous
+    # variable length: ACGTACG -> [70,198]; TTN (N -> code 0) -> [_,124]; A -> [_,4] (the byte the reference never writes is 0, Q8)
+    cfg, m, t = rows(['ACGTACG', 'TTN', 'A'], ['HIHIIHI', 'HI!', 'I'])
+    assert cfg['variable_read_lengths'] and cfg['N_qual'] == {'N': 0} and cfg['qualities'] == '!HI'
+    assert t['DNA'].tolist() == [[70, 198], [0, 124], [0, 4]]          # dna_max 7 + sentinel = 16 bits -> 2-byte rows
+    assert t['QUAL'][1].tolist()[-1] == 88
+
+
+def test_pattern_streams_a4():
+    T = np.arange(12, dtype=np.uint8).reshape(4, 3)
+    pay = lambda p: np.frombuffer(O.write_pattern(T, p), dtype=np.uint8)[-12:].tolist()
+    assert pay('1.1') == [2, 5, 8, 11, 1, 4, 7, 10, 0, 3, 6, 9]
+    assert pay('1.2') == [2, 1, 0, 5, 4, 3, 8, 7, 6, 11, 10, 9]
+    assert pay('2.2') == [11, 8, 5, 2, 10, 7, 4, 1, 9, 6, 3, 0]
+    assert pay('3.2') == [9, 10, 11, 6, 7, 8, 3, 4, 5, 0, 1, 2]
+    for p in O.PATTERNS:
+        assert np.array_equal(O.unpattern(O.write_pattern(T, p), p), T)
+
+
+def test_encoder_loop_equals_closed_form():
+    """The faithful flush loop (uq.py:147-175) == the closed form of SURVEY.md A.1/A.2, incl. Q7 lengths."""
+    import random
+    rnd = random.Random(5)
+    for variable in (False, True):
+        for bits in ((2, 6), (3, 5), (4, 8), (7, 2)):
+            L = 9
+            reads = [''.join(rnd.choice('ACGT') for _ in range(rnd.randint(1, L) if variable else L)) for _ in range(40)]
+            if variable: reads[0] = 'A' * L; reads[1] = 'C' * 4; reads[2] = 'G' * 8
+            lines = []
+            for i, r in enumerate(reads): lines += ['@x\n', r + '\n', '+\n', ''.join(rnd.choice('!#%I') for _ in r) + '\n']
+            lv = L + (1 if variable else 0)
+            cd, cq = -(-bits[0] * lv // 8), -(-bits[1] * lv // 8)
+            a = O.encoder(lines, 'ACGT', '!#%I', {}, cd, cq, bits[0], bits[1], variable)
+            b = O.encoder_bigint(lines, 'ACGT', '!#%I', {}, cd, cq, bits[0], bits[1], variable)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])

@@ -53,6 +53,8 @@ class Context:
         """numpy array (any dtype) -> device tensor of bytes-compatible dtype."""
         t = self.torch
         a = np.ascontiguousarray(array)
+        if not a.flags.writeable:
+            a = a.copy()
         if a.dtype in (np.uint16, np.uint32, np.uint64):
             signed = {2: np.int16, 4: np.int32, 8: np.int64}[a.dtype.itemsize]
             return t.from_numpy(a.view(signed)).to(self.device)

@@ -1,0 +1,526 @@
+#!/usr/bin/env python3
+"""uq -- FASTQ <-> uQ (tar of .npy arrays + config.json) on MI355X.  Drop-in for the reference script:
+
+    python -m uq_amd.uq -i reads.fastq [--sort DNA|QUAL|QNAME|None] [--raw DNA QUAL QNAME] [--pattern a b]
+                        [--notricks] [--pad] [--peek] [--test [--compressor CMD]] [-o out.uQ] [--temp DIR]
+    python -m uq_amd.uq -i reads.fastq.uQ --decode > reads.fastq
+
+Same thirteen flags and validation as uq.py:21-71, same container (uq.py:897-913), same function names
+for the seams of the hot path -- `encoder_fixed`, `encoder_variable`, `write_pattern`, `write_out`,
+`test_patterns`, `run_mix`, `encode_dna_qual`, `encode_qname`, `load_from_tar`, `split_bits` -- as
+methods of `Session` (the reference keeps their shared state in module globals).  Every O(N*L) step
+runs on the GPU through the C ABI (uq_amd._lib); there is no CPU fallback.  Between the passes the
+tables stay in HBM (the reference parks them in <temp>/*.temp files to save RAM, uq.py:710-711, 734).
+
+Deliberate fixes of reference defects: Q5 private temp dir, Q6 members written
+and decoded in numeric order, Q4 compressors spawned on demand, Q13/Q21 clear errors, Q17 stable ties,
+Q19/Q25 decoder works on codes.
+"""
+import argparse
+import io
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tarfile
+import tempfile
+import time
+
+import numpy as np
+
+PATTERNS = ['0.1', '1.1', '2.1', '3.1', '0.2', '1.2', '2.2', '3.2']
+
+
+class UqError(Exception):
+    """The reference prints and exit()s (uq.py:48-50); the library form raises, main() prints."""
+
+
+def error(message):
+    raise UqError(message)
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description='This tool converys FASTQ files to microq (uQ) files and back.')
+    p.add_argument('-i', '--input', required=True, help='Required. Input FASTQ/uQ file path.')
+    p.add_argument('-o', '--output', help='Optional. FASTQ->uQ only. Default is to append .uQ to input filename.')
+    p.add_argument('--compressor', action='store', help='Optional. Path to compression program that accepts data on stdin and prints to stdout/pipe)')
+    p.add_argument('--sort', action='store', help='Optional. [DNA/QUAL/QNAME/None] Resort FASTQ. See output of --test for optimium method.')
+    p.add_argument('--raw', nargs='+', metavar='file name', help='Optional. [DNA/QUAL/QNAME/None] Store tables raw rather than unique & sorted + key.')
+    p.add_argument('--pattern', nargs='+', metavar='pattern', help='Optional. [0.1/0.2/1.1/1.2/2.1/2.2/3.1/3.2] x2 (DNA|QUAL) See output of --test for optimium.')
+    p.add_argument('--temp', help='Optional. Directory to write temporary files to. Default is OS dependant.')
+    p.add_argument('--test', action='store_true', default=False, help='Optional. Try all possible sort/raw/pattern combinations.')
+    p.add_argument('--notricks', action='store_true', default=False, help='Optional. Prevents conversion of N to the most popular base.')
+    p.add_argument('--pad', action='store_true', default=False, help='Optional. Pads DNA/QUAL to the nearest 2/4/8 bits.')
+    p.add_argument('--peek', action='store_true', default=False, help='Optional. No output files are created, the input is just scanned.')
+    p.add_argument('--decode', action='store_true', default=False, help='Requred if you want to convert a .uQ back to .fastq')
+    p.add_argument('--device', type=int, default=int(os.environ.get('LOCAL_RANK', '0')), help='GPU index (extension)')
+    p.add_argument('--quiet', action='store_true', default=False, help='suppress the analysis report (extension)')
+    return p
+
+
+def validate_args(args):
+    """uq.py:52-71, including the case quirks of Q1."""
+    if args.pattern:
+        if len(args.pattern) != 2: error('ERROR: There must be 2 values for --pattern!')
+        elif not all(p in PATTERNS for p in args.pattern): error('ERROR: Pattern values are incorrect!')
+    if args.sort:
+        if args.sort.lower() not in ['dna', 'qual', 'qname', 'none']: error('ERROR: --sort value is incorrect!')
+        if args.sort.lower() == 'none': args.sort = (None,)
+    if args.raw:
+        if not all(r.lower() in ['dna', 'qual', 'qname', 'none'] for r in args.raw): error('ERROR: --raw values are incorrect!')
+        args.raw = set(args.raw)
+        if 'none' in args.raw:
+            args.raw.add(None); args.raw.discard('none')
+    if not os.path.isfile(args.input): error('ERROR: Sorry, the input path you have specified is not a file!')
+    return args
+
+
+def npy_header(shape, fortran_order, dtype):
+    """The .npy v1.0 header numpy.save writes for this array (uq.py:263-274 via numpy)."""
+    f = io.BytesIO()
+    np.lib.format.write_array_header_1_0(f, {'descr': np.lib.format.dtype_to_descr(np.dtype(dtype)),
+                                             'fortran_order': bool(fortran_order), 'shape': tuple(int(s) for s in shape)})
+    return f.getvalue()
+
+
+def pattern_header(rows, cols, pattern):
+    """Shape / fortran_order of numpy.save(asXarray(rot90(table, k))) -- SURVEY.md A.4, Q22."""
+    k = int(pattern[0])
+    shape = (rows, cols) if k % 2 == 0 else (cols, rows)
+    fortran = pattern.endswith('.2') and min(shape) > 1     # 1-wide arrays are C- and F-contiguous: numpy says False
+    return npy_header(shape, fortran, np.uint8)
+
+
+class Session:
+    """One encode (or decode) run: the reference's module-level state as an object."""
+
+    def __init__(self, args, ctx=None, out=sys.stdout):
+        from . import ops
+        from .device import Context
+        self.ops = ops
+        self.args = args
+        self.ctx = ctx or Context(getattr(args, 'device', 0))
+        self.out = out
+        self.members = {}          # name -> bytes of a .npy file (no suffix), uq.py:272-274
+        self.tables = {}           # 'DNA' / 'QUAL' -> (device tensor, rows, cols); 'QNAME' -> [device column tensors]
+        self.columns = []
+        self.config = {}
+        self.t0 = time.time()
+        self.split = self.t0
+        self.last_subprocess_used = 0
+
+    def say(self, *a):
+        if not getattr(self.args, 'quiet', False):
+            print(*a, file=self.out)
+
+    def split_time(self):
+        now = time.time(); d = now - self.split; self.split = now
+        return '(' + str(d / 60) + ' minutes)'
+
+    # ------------------------------------------------------------------ passes 1-2 (analysis)
+    def load(self, path):
+        """Read the FASTQ, put it in HBM, build the record index.  Replaces `wc -l` + line iteration."""
+        ops, ctx = self.ops, self.ctx
+        self.host = np.fromfile(path, dtype=np.uint8)
+        if self.host.size == 0: error('ERROR: empty input')
+        self.d_buf = ctx.to_device(self.host)
+        nlines = ops.count_lines(ctx, self.d_buf)
+        if nlines % 4 != 0:
+            error('ERROR: The FASTQ file provided contains' + str(nlines) + 'rows, which is not divisible by 4!')
+        if nlines == 0: error('ERROR: empty input')
+        self.total = nlines // 4
+        self.d_ls = ops.index_lines(ctx, self.d_buf, nlines)
+        self.h_ls = ctx.to_numpy(self.d_ls, np.uint64)
+
+    def analyse(self):
+        """Pass 1 (histogram, lengths, QNAME layout), the N-trick / width decisions, pass 2 (QNAME typing)."""
+        from . import analysis, qname
+        ops, ctx, args = self.ops, self.ctx, self.args
+        st = ops.stats_new(ctx)
+        ops.stats_accumulate(ctx, st, self.d_buf, self.d_ls, 0, self.total)
+        hs = ops.stats_fetch(ctx, st)
+        if self.host[0] != ord('@'): error('ERROR: This does not look like a FASTA/FASTQ file! (first line does not start with @)')
+        if hs.bad_plus is not None:
+            error('ERROR: For entry' + str(hs.bad_plus) + 'the third line does not start with +')
+        if hs.bad_len is not None:
+            error('ERROR: Length of DNA does not match the length of the quality scores for entry ' + str(hs.bad_len))
+        self.hs = hs
+        first_seen = lambda: ops.first_occurrence(ctx, self.d_buf, self.d_ls, 0, self.total)
+        d = analysis.decide_from_counts(hs.counts, hs.len_min, hs.len_max, notricks=args.notricks, pad=args.pad, first_seen=first_seen)
+        self.d = d
+        names = qname.qname_lines(self.host, self.h_ls, self.total)
+        try:
+            prefix, suffix, separators, columns, arrays = qname.analyse(names)
+        except qname.QnameError as e:
+            error(str(e))
+        self.columns = columns
+        self.qname_arrays = arrays
+        self.report(prefix, suffix, separators)
+        self.config = {
+            'base_distribution': d['base_distribution'], 'qual_distribution': d['qual_distribution'],
+            'reads': self.total, 'bases': d['bases'], 'qualities': d['qualities'],
+            'variable_read_lengths': d['variable_read_lengths'], 'bits_per_base': d['bits_per_base'],
+            'bits_per_quality': d['bits_per_quality'], 'N_qual': d['N_qual'], 'dna_max': d['dna_max'],
+            'QNAME_prefix': prefix, 'QNAME_suffix': suffix, 'QNAME_separators': separators, 'QNAME_columns': columns,
+        }
+
+    def report(self, prefix, suffix, separators):
+        """The analysis printout of uq.py:459-545 (condensed: same facts, fewer bar charts)."""
+        d, say = self.d, self.say
+        total_bases = float(sum(d['base_distribution'].values()))
+        say('Finished analysing file!', self.split_time())
+        say('    - total reads:', self.total)
+        say('    - total bases:', int(total_bases))
+        say('\nQNAME Analysis:')
+        if prefix: say('    - all QNAMEs prefixed with:', prefix)
+        if suffix: say('    - all QNAMEs suffixed with:', suffix)
+        if separators: say('    - QNAME field separators:', separators, '(', len(separators), 'symbols )')
+        say('\nDNA Analysis:')
+        bases_all = sorted(d['base_distribution'])
+        say('    - DNA sequences contained the following characters:', ' '.join(bases_all), '(' + str(len(bases_all)) + ' in total)')
+        for b in bases_all:
+            pct = d['base_distribution'][b] / total_bases * 100
+            say('     ', b, '|' + ('#' * int(pct / 2)).ljust(50) + '|', ('%.3f' % pct).rjust(7) + '%', str(d['base_distribution'][b]).rjust(12))
+        for b, code in d['N_qual'].items():
+            say('    - The base', b, 'consistently had the same quality value; it is encoded as', d['bases'][0], 'with quality code', code)
+        say('    - this means we will store each letter of DNA in', d['bits_per_base'], 'bits.')
+        if d['dna_min'] == d['dna_max']: say('    - all DNA sequences are', d['dna_min'], 'bases long')
+        else:
+            say('    - the largest DNA sequence is', d['dna_max'], 'bases long')
+            say('    - the smallest DNA sequence is', d['dna_min'], 'bases long')
+        say('    - we will use', d['dna_bytes_per_row'], 'bytes per unique DNA sequence.\n')
+        say('QUAL Analysis:')
+        quals_all = sorted(d['qual_distribution'])
+        say('    - the following values were seen as quality scores:', ' '.join(quals_all), '(' + str(len(quals_all)) + ' in total)')
+        say('    - this means we will store each quality symbol in', d['bits_per_quality'], 'bits.')
+        say('    - we will use', d['quality_bytes_per_row'], 'bytes per unique quality sequence.\n')
+        for idx, c in enumerate(self.columns):
+            say('    - Column', idx + 1, 'is type', c['format'], 'stored as', c['dtype'])
+
+    # ------------------------------------------------------------------ pass 3: the packers
+    def _encode(self, variable):
+        ops, ctx, d = self.ops, self.ctx, self.d
+        p = ops.make_pack_params(d['bases'], d['qualities'], d['N_qual'], d['bits_per_base'], d['bits_per_quality'],
+                                 variable, d['dna_bytes_per_row'], d['quality_bytes_per_row'], d['dna_max'], self.hs.max_record_bytes)
+        dna, qual, bad = ops.pack(ctx, self.d_buf, self.d_ls, 0, self.total, p)
+        b = ops.bad_index(bad)
+        if b is not None: error('ERROR: read %d holds a symbol with no code (internal inconsistency)' % b)
+        return ((dna, self.total, d['dna_bytes_per_row']), (qual, self.total, d['quality_bytes_per_row']))
+
+    def encoder_fixed(self):
+        """uq.py:108-182.  Returns ((dna tensor, rows, cols), (qual tensor, rows, cols)); the tensors are
+        device memory owned by torch (drop the reference to free them, the `lib.free(ptr)` of uq.py:712)."""
+        return self._encode(False)
+
+    def encoder_variable(self):
+        """uq.py:188-254 (adds the sentinel bit above each read's most significant symbol)."""
+        return self._encode(True)
+
+    def pack(self):
+        """uq.py:705-736: pass 3, and pass 4's column arrays moved to the device."""
+        arrays = self.encoder_variable() if self.d['variable_read_lengths'] else self.encoder_fixed()
+        self.tables['DNA'], self.tables['QUAL'] = arrays
+        self.tables['QNAME'] = [self.ctx.to_device(a) for a in self.qname_arrays]
+
+    # ------------------------------------------------------------------ writers
+    def write_pattern(self, table, filename):
+        """uq.py:257-270.  `table` = (device tensor, rows, cols)."""
+        args = self.args
+        if args.pattern is None: pattern = '0.1'; args.pattern = ['0.1', '0.1']
+        elif filename.startswith('DNA'): pattern = args.pattern[0]
+        elif filename.startswith('QUAL'): pattern = args.pattern[1]
+        else: error('ERROR: This should never happen!')
+        t, rows, cols = table
+        payload = self.ops.pattern(self.ctx, t, rows, cols, pattern)
+        self.members[filename] = pattern_header(rows, cols, pattern) + self.ctx.to_numpy(payload).tobytes()
+
+    def write_out(self, array, filename, dtype=None):
+        """uq.py:272-274: a 1-D array (key or QNAME column) as .npy bytes.  `array`: device tensor or numpy."""
+        if not isinstance(array, np.ndarray):
+            array = self.ctx.to_numpy(array, dtype)
+        self.members[filename] = npy_header(array.shape, False, array.dtype) + array.tobytes()
+
+    def compressed_size(self, data):
+        """uq.py:277-285 (Q4/Q26 fixed: spawn on demand, serialise first, surface errors)."""
+        if not self.args.compressor: return len(data)
+        p = subprocess.run(self.args.compressor + ' | wc -c', shell=True, input=data, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+        if p.returncode != 0: error('ERROR: the compressor command failed')
+        self.last_subprocess_used += 1
+        return int(p.stdout.split()[0])
+
+    def test_patterns(self, table, filename):
+        """uq.py:290-334: size of each candidate layout -> [size, pattern] of the smallest."""
+        args = self.args
+        t, rows, cols = table
+        if args.compressor is None: return [rows * cols, '0.1']
+        if filename.startswith('DNA'): pattern = None if args.pattern is None else args.pattern[0]
+        elif filename.startswith('QUAL'): pattern = None if args.pattern is None else args.pattern[1]
+        else: error('ERROR: This should never happen!')
+        results = []
+        for pat in (PATTERNS if pattern is None else [pattern]):
+            payload = self.ops.pattern(self.ctx, t, rows, cols, pat)
+            blob = pattern_header(rows, cols, pat) + self.ctx.to_numpy(payload).tobytes()
+            results.append([self.compressed_size(blob), pat])
+        return sorted(results)[0]
+
+    # ------------------------------------------------------------------ table builds
+    def _npdtype(self, itemsize):
+        return {1: np.uint8, 2: np.uint16, 4: np.uint32, 8: np.uint64}[itemsize]
+
+    def encode_dna_qual(self, sort_order, table_name, raw, test):
+        """uq.py:765-805.  sort_order: None = no sort, False = compute and return, tensor = apply."""
+        ops, ctx = self.ops, self.ctx
+        t, rows, cols = self.tables[table_name]
+        if raw:
+            out_name = table_name + '.raw'
+            if sort_order is None:
+                table = (t, rows, cols)
+            else:
+                if sort_order is False: sort_order = ops.argsort_rows(ctx, t, rows, cols)       # uq.py:773-775
+                table = (ops.gather_rows(ctx, t, rows, cols, sort_order), rows, cols)            # uq.py:777
+            if test: test[out_name] = self.test_patterns(table, out_name)
+            else: self.write_pattern(table, out_name)
+        else:
+            out_name = table_name + '.key'
+            perm, key, skey, uniq, nu = ops.unique_rows(ctx, t, rows, cols, want_key=sort_order is not False,
+                                                        want_sorted_key=sort_order is False)    # uq.py:784-789
+            isz = ops.key_itemsize(nu - 1)                                                       # uq.py:790
+            if sort_order is None:
+                k = ops.narrow(ctx, key, isz)
+            elif sort_order is False:
+                sort_order = perm                                                                # == argsort(key), stable (uq.py:796)
+                k = ops.narrow(ctx, skey, isz)
+            else:
+                k = ops.narrow(ctx, ops.gather_rows(ctx, key.view(ctx.torch.uint8), rows, 4, sort_order).view(ctx.torch.int32), isz)
+            k_host = ctx.to_numpy(k, self._npdtype(isz))
+            if test: test[out_name] = self.compressed_size(npy_header(k_host.shape, False, k_host.dtype) + k_host.tobytes())
+            else: self.write_out(k_host, out_name)
+            table = (uniq, nu, cols)
+            if test: test[table_name] = self.test_patterns(table, table_name)
+            else: self.write_pattern(table, table_name)
+        return sort_order
+
+    def encode_qname(self, sort_order, raw, test):
+        """uq.py:808-851 on the device: columns stacked into big-endian rows, then the row kernels."""
+        ops, ctx, columns = self.ops, self.ctx, self.columns
+        cols_d = self.tables['QNAME']
+        n = self.total
+        common = max(c.element_size() for c in cols_d)
+        ncols = len(cols_d)
+
+        def emit(name, tensor, dtype):
+            host = ctx.to_numpy(tensor, np.dtype(dtype))
+            if test: test[name] = self.compressed_size(npy_header(host.shape, False, host.dtype) + host.tobytes())
+            else: self.write_out(host, name)
+
+        if raw:
+            if sort_order is False:
+                rows = ops.stack_columns(ctx, cols_d, common)                                    # uq.py:814-815
+                sort_order = ops.argsort_rows(ctx, rows, n, ncols * common)                      # uq.py:816
+            for idx, column in enumerate(columns):
+                c = cols_d[idx]
+                if sort_order is not None:
+                    c = ops.gather_rows(ctx, c.view(ctx.torch.uint8), n, c.element_size(), sort_order).view(c.dtype)
+                emit(column['name'] + '.raw', c, column['dtype'])
+        else:
+            rows = ops.stack_columns(ctx, cols_d, common)                                        # uq.py:828-829
+            perm, key, skey, uniq, nu = ops.unique_rows(ctx, rows, n, ncols * common, want_key=sort_order is not False,
+                                                        want_sorted_key=sort_order is False)    # uq.py:830
+            isz = ops.key_itemsize(nu - 1)                                                       # uq.py:832
+            if sort_order is False:
+                sort_order = perm                                                                # uq.py:833
+                k = ops.narrow(ctx, skey, isz)
+            elif sort_order is None:
+                k = ops.narrow(ctx, key, isz)
+            else:
+                k = ops.narrow(ctx, ops.gather_rows(ctx, key.view(ctx.torch.uint8), n, 4, sort_order).view(ctx.torch.int32), isz)
+            emit('QNAME.key', k, self._npdtype(isz))
+            for idx, column in enumerate(columns):                                               # uq.py:845-847
+                col = ops.unstack_column(ctx, uniq, nu, ncols, common, idx, np.dtype(column['dtype']).itemsize)
+                emit(column['name'], col, column['dtype'])
+        return sort_order
+
+    def run_mix(self, sorted_on, raw_tables, test):
+        """uq.py:739-762: the order of the three table builds and who produces / consumes sort_order."""
+        if test: test = {'sorted_on': sorted_on, 'raw_tables': raw_tables}
+        if sorted_on in ['DNA', 'QUAL']:
+            not_sorted_on = 'DNA' if sorted_on == 'QUAL' else 'QUAL'
+            sort_order = self.encode_dna_qual(False, sorted_on, sorted_on in raw_tables, test)
+            self.encode_dna_qual(sort_order, not_sorted_on, not_sorted_on in raw_tables, test)
+            self.encode_qname(sort_order, 'QNAME' in raw_tables, test)
+        elif sorted_on == 'QNAME':
+            sort_order = self.encode_qname(False, 'QNAME' in raw_tables, test)
+            self.encode_dna_qual(sort_order, 'DNA', 'DNA' in raw_tables, test)
+            self.encode_dna_qual(sort_order, 'QUAL', 'QUAL' in raw_tables, test)
+        else:
+            self.encode_qname(None, 'QNAME' in raw_tables, test)
+            self.encode_dna_qual(None, 'DNA', 'DNA' in raw_tables, test)
+            self.encode_dna_qual(None, 'QUAL', 'QUAL' in raw_tables, test)
+        if test:
+            total_size = 0
+            for key, value in test.items():
+                if key.startswith('QNAME') or key.endswith('key'): total_size += value
+                elif key.startswith('DNA') or key.startswith('QUAL'): total_size += value[0]
+            test['total_size'] = total_size
+        return test
+
+    def run_tests(self):
+        """uq.py:855-889: the (raw set x sort) grid, best-of by total size."""
+        args, say = self.args, self.say
+        all_results = []
+        say('Starting tests...')
+        say('Time:                       Sort:      Raw Tables:                      Patterns:')
+        self.split_time()
+        raw_grid = [('DNA', 'QUAL', 'QNAME'), ('DNA', 'QUAL'), ('QUAL', 'QNAME'), ('DNA', 'QNAME'), ('DNA',), ('QUAL',), ('QNAME',), (None,)]
+        for raw_tables in (raw_grid if args.raw is None else [args.raw]):
+            if args.compressor is None: args.sort = (None,)
+            for to_sort in (['DNA', 'QUAL', 'QNAME', None] if args.sort is None else [args.sort]):
+                all_results.append(self.run_mix(to_sort, raw_tables, True))
+                say(self.split_time().ljust(27), str(to_sort).ljust(10), str(tuple(raw_tables)).ljust(32), 'All' if args.raw is None else str(args.pattern))
+        best = sorted(all_results, key=lambda k: k['total_size'])[0]
+        args.sort = best['sorted_on']
+        args.raw = best['raw_tables']
+        args.pattern = (best['DNA.raw'][1] if 'DNA.raw' in best else best['DNA'][1],
+                        best['QUAL.raw'][1] if 'QUAL.raw' in best else best['QUAL'][1])
+        say('\nAll done!')
+        say('Size (compressed)    Sort:    Raw Tables:                 Raw stats:' if args.compressor else
+            '             Size    Sort:    Raw Tables:                 Raw stats:')
+        for result in sorted(all_results, key=lambda k: k['total_size']):
+            rest = {k: v for k, v in result.items() if k not in ('total_size', 'sorted_on', 'raw_tables')}
+            say(str(result['total_size']).rjust(17) + '   ', str(result['sorted_on']).ljust(8), str(tuple(result['raw_tables'])).ljust(27),
+                ' '.join(str(k) + ':' + str(v) for k, v in rest.items()))
+        return all_results
+
+    # ------------------------------------------------------------------ container
+    def write_container(self, path):
+        """uq.py:897-913: config.json + members into an uncompressed tar (members in numeric order, Q6)."""
+        args = self.args
+        cfg = dict(self.config)
+        cfg['sort'] = args.sort if isinstance(args.sort, str) else [None]
+        cfg['raw'] = sorted(args.raw, key=str) if args.raw else [None]
+        cfg['pattern'] = list(args.pattern) if args.pattern else None
+        self.config = cfg
+        blob = json.dumps(cfg, indent=4, sort_keys=True).encode()
+
+        def order(name):
+            base = name.split('.')[0]
+            if base.startswith('QNAME_'): return (3, int(base[6:]), name)
+            return ({'DNA': 0, 'QUAL': 1, 'QNAME': 2}.get(base, 4), 0, name)
+
+        tmpdir = tempfile.mkdtemp(prefix='uq_', dir=args.temp if getattr(args, 'temp', None) else None)
+        try:
+            tmp = os.path.join(tmpdir, 'temp.uq')
+            with tarfile.open(tmp, mode='w') as t:
+                for name, data in [('config.json', blob)] + [(k, self.members[k]) for k in sorted(self.members, key=order)]:
+                    ti = tarfile.TarInfo(name); ti.size = len(data); ti.mtime = int(time.time())
+                    t.addfile(ti, io.BytesIO(data))
+            shutil.move(tmp, path)
+        finally:
+            shutil.rmtree(tmpdir, ignore_errors=True)
+
+    # ------------------------------------------------------------------ whole encode
+    def encode(self):
+        args = self.args
+        if args.output is None: args.output = args.input + '.uQ'
+        self.say('Warming up...')
+        self.load(args.input)
+        self.analyse()
+        if args.peek:
+            self.say('The config.json would look like:')
+            self.say(json.dumps(self.config, indent=4, sort_keys=True))
+            return
+        self.pack()
+        if args.test: self.run_tests()
+        if args.sort is None: args.sort = (None,)                                               # uq.py:893-895
+        if args.raw is None: args.raw = (None,)
+        self.members = {}
+        self.run_mix(args.sort, args.raw, False)
+        self.say('\nWriting final config...')
+        self.say('Archiving results and cleaning up temp directory...')
+        self.write_container(args.output)
+        self.say('All Done! :) ')
+
+    # ------------------------------------------------------------------ decode (uq.py:926-1058)
+    def load_from_tar(self, members, file_name, pattern='0.1'):
+        """uq.py:943-945 on the device: payload -> table.  Returns (device tensor, rows, cols) for 2-D
+        members, a numpy array for 1-D ones."""
+        data = members[file_name]
+        f = io.BytesIO(data)
+        version = np.lib.format.read_magic(f)
+        shape, fortran, dtype = np.lib.format.read_array_header_1_0(f) if version == (1, 0) else np.lib.format.read_array_header_2_0(f)
+        payload = np.frombuffer(data, dtype=np.uint8, offset=f.tell())
+        if len(shape) == 1:
+            return payload.view(dtype)
+        k = int(pattern[0])
+        rows, cols = (shape if k % 2 == 0 else shape[::-1])
+        # numpy flags 1-wide arrays as C order whatever the pattern asked for: the byte stream is the same
+        d_pay = self.ctx.to_device(payload)
+        t = self.ops.unpattern(self.ctx, d_pay, rows, cols, pattern)
+        return (t, rows, cols)
+
+    def split_bits(self, dna, qual, config):
+        """uq.py:1002-1007 + 1031-1054 on the device: rows -> characters (fixed pitch) + lengths."""
+        p = self.ops.make_unpack_params(config)
+        n = dna[1]
+        seq, qt, ln, bad = self.ops.unpack(self.ctx, dna[0], qual[0], n, p)
+        b = self.ops.bad_index(bad)
+        if b is not None: error('ERROR: row %d of the DNA table carries no length sentinel; is this a uQ file?' % b)
+        return seq, qt, ln
+
+    def decode(self, out=None):
+        from . import qname
+        args, ops, ctx = self.args, self.ops, self.ctx
+        out = out or sys.stdout
+        if not tarfile.is_tarfile(args.input):
+            error('ERROR: Sorry, the path you have provided as input is a file, but not a tar file, and therefore cannot be a .uq file!')
+        with tarfile.open(args.input) as t:
+            members = {m.name: t.extractfile(m).read() for m in t.getmembers()}
+        if 'config.json' not in members: error('ERROR: No config.json file was found in your input path! I cannot decode data without it!')
+        config = json.loads(members['config.json'].decode())
+        pat = config['pattern'] or ['0.1', '0.1']
+
+        def table(name, pattern):
+            if name + '.raw' in members: return self.load_from_tar(members, name + '.raw', pattern)
+            if name in members and name + '.key' in members:
+                t, rows, cols = self.load_from_tar(members, name, pattern)
+                key = self.load_from_tar(members, name + '.key')
+                d_key = ctx.to_device(key)
+                return (ops.gather_rows(ctx, t, rows, cols, d_key), len(key), cols)               # uq.py:953, 957
+            error('ERROR: No ' + name + ' data was found in this uQ file?!')
+
+        DNA = table('DNA', pat[0])
+        QUAL = table('QUAL', pat[1])
+        ncols = len(config['QNAME_columns'])
+        if 'QNAME.key' in members:
+            key = self.load_from_tar(members, 'QNAME.key')
+            cols = [self.load_from_tar(members, 'QNAME_%d' % (i + 1))[key] for i in range(ncols)]  # uq.py:973, numeric order (Q6)
+        else:
+            cols = [self.load_from_tar(members, 'QNAME_%d.raw' % (i + 1)) for i in range(ncols)]
+        seq, qt, ln = self.split_bits(DNA, QUAL, config)
+        n, dmax = DNA[1], config['dna_max']
+        S = ctx.to_numpy(seq).reshape(n, dmax); Q = ctx.to_numpy(qt).reshape(n, dmax); L = ctx.to_numpy(ln, np.uint32)
+        names = qname.decode_names(config, cols)
+        w = out.buffer if hasattr(out, 'buffer') else out
+        for r in range(n):
+            l = int(L[r])
+            w.write(names[r].encode('latin-1') + b'\n' + S[r, :l].tobytes() + b'\n+\n' + Q[r, :l].tobytes() + b'\n')
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    try:
+        validate_args(args)
+        s = Session(args)
+        if args.decode:
+            s.decode()
+        else:
+            s.encode()
+    except UqError as e:
+        print(e)
+        return 1
+    return 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())
