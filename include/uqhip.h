@@ -107,6 +107,12 @@ int uq_unpattern(uq_ctx* ctx, const uint8_t* d_payload, uint64_t rows, uint32_t 
  * numpy.argsort(axis=0) (uq.py:773-775).  d_perm[j] = index of the j-th smallest row. */
 int uq_argsort_rows(uq_ctx* ctx, const uint8_t* d_table, uint64_t rows, uint32_t cols, uint32_t* d_perm);
 
+/* ---- multi-GPU --sort: d_pos[k] = index of the first row of the memcmp-SORTED table that is
+ * >= probe row k (numpy.searchsorted(side='left') on void rows).  Splits a locally sorted shard at the
+ * splitter rows of the sample sort before the all-to-all. */
+int uq_lower_bound_rows(uq_ctx* ctx, const uint8_t* d_sorted_table, uint64_t rows, uint32_t cols,
+                        const uint8_t* d_probes, uint64_t nprobes, uint64_t* d_pos);
+
 /* ---- a5 / a6 / a7 / a11: out[j] = table[index[j]].  Replaces table[sort_order] (uq.py:777),
  * key[sort_order] (798), columns_data[idx][sort_order] (822), table[key] on decode (953, 957, 973).
  * index_itemsize in {1,2,4,8} (keys are stored narrowed, uq.py:790). */

@@ -141,6 +141,26 @@ def test_qname_column_stack_sort_unique(ctx):
         assert np.array_equal(ctx.to_numpy(col, cols[c].dtype), ru[:, c].astype(cols[c].dtype))
 
 
+def test_lower_bound_rows_and_single_rank_global_sort(ctx):
+    from uq_amd import dist as uqdist
+    rng = np.random.RandomState(21)
+    n, C = 20000, 38
+    T = _rows_with_dups(rng, n, C, 3000)
+    order = O.argsort_rows(T)
+    S = T[order]
+    probes = np.concatenate([S[::997], rng.randint(0, 256, size=(40, C)).astype(np.uint8), np.zeros((1, C), np.uint8), np.full((1, C), 255, np.uint8)])
+    pos = ops.lower_bound_rows(ctx, _dev(ctx, S.ravel()), n, C, _dev(ctx, probes.ravel()), len(probes))
+    keys = [bytes(r) for r in S]
+    import bisect
+    assert ctx.to_numpy(pos).tolist() == [bisect.bisect_left(keys, bytes(p)) for p in probes]
+    res = uqdist.global_sort_rows(uqdist.HipRows(ctx), _dev(ctx, T.ravel()), n, C, 1000)
+    assert res['rows'] == n and res['offset'] == 0
+    assert np.array_equal(ctx.to_numpy(res['gidx']), order + 1000)
+    assert np.array_equal(ctx.to_numpy(res['table']).reshape(n, C), S)
+    g = uqdist.dist_gather_rows(uqdist.HipRows(ctx), _dev(ctx, T.ravel()), n, C, [1000, 1000 + n], res['gidx'])
+    assert np.array_equal(ctx.to_numpy(g).reshape(n, C), S)
+
+
 UNPACK_CASES = [('fixed', 2000, 100, {}, {}), ('var_ntrick', 3000, (36, 301), dict(n_rate=1), {}),
                 ('var_notricks', 2000, (20, 150), dict(n_rate=2), dict(notricks=True)),
                 ('var_pad', 500, (1, 40), dict(n_rate=2), dict(notricks=True, pad=True)), ('len1', 50, 1, {}, {})]

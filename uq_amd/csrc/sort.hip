@@ -198,6 +198,24 @@ __global__ void keys_from_groups_kernel(const uint8_t* __restrict__ heads, const
     if (uidx && heads[j]) uidx[g] = row;
 }
 
+__global__ void lower_bound_rows_kernel(const uint8_t* __restrict__ table, uint64_t rows, uint32_t C, const uint8_t* __restrict__ probes,
+                                        uint64_t nprobes, uint64_t* __restrict__ pos) {
+    uint64_t k = (uint64_t)blockIdx.x * ST + threadIdx.x;
+    if (k >= nprobes) return;
+    const uint8_t* p = probes + k * C;
+    uint64_t lo = 0, hi = rows;
+    while (lo < hi) {
+        const uint64_t mid = lo + ((hi - lo) >> 1);
+        const uint8_t* r = table + mid * C;
+        int cmp = 0;
+        for (uint32_t i = 0; i < C; ++i) {
+            if (r[i] != p[i]) { cmp = r[i] < p[i] ? -1 : 1; break; }
+        }
+        if (cmp < 0) lo = mid + 1; else hi = mid;
+    }
+    pos[k] = lo;
+}
+
 template <typename T>
 __global__ void narrow_kernel(const uint32_t* __restrict__ in, uint64_t n, T* __restrict__ out) {
     uint64_t i = (uint64_t)blockIdx.x * ST + threadIdx.x;
@@ -258,6 +276,16 @@ extern "C" int uq_unique_rows(uq_ctx* ctx, const uint8_t* d_table, uint64_t rows
     UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     *h_nunique = ctx->h_pinned[0];
     if (d_unique) UQ_TRY(uq_gather_rows_internal(ctx, d_table, rows, cols, uidx, 4, *h_nunique, d_unique));
+    return 0;
+}
+
+extern "C" int uq_lower_bound_rows(uq_ctx* ctx, const uint8_t* d_sorted_table, uint64_t rows, uint32_t cols,
+                                   const uint8_t* d_probes, uint64_t nprobes, uint64_t* d_pos) {
+    UQ_REQUIRE(ctx && cols >= 1, "uq_lower_bound_rows: bad argument");
+    if (nprobes == 0) return 0;
+    UQ_REQUIRE(d_probes && d_pos && (rows == 0 || d_sorted_table), "uq_lower_bound_rows: null buffer");
+    lower_bound_rows_kernel<<<blocks_for(nprobes), ST, 0, ctx->stream>>>(d_sorted_table, rows, cols, d_probes, nprobes, d_pos);
+    UQ_LAUNCH_CHECK();
     return 0;
 }
 

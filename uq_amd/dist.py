@@ -68,3 +68,133 @@ def allreduce_stats(ctx, d_stats, read_offset=0):
     allreduce_stats_tensors(counts, mins, lmin, lmax, rmax)
     tail[0:1].copy_(lmin.to(t.int32)); tail[1:2].copy_(lmax.to(t.int32)); tail[2:3].copy_(rmax.to(t.int32))
     return ops.stats_fetch(ctx, d_stats)
+
+
+# --------------------------------------------------------------------------- global --sort
+class HipRows:
+    """Row operations of one rank, on the GPU through the C ABI (the product backend)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.torch = ctx.torch
+        self.device = ctx.device
+
+    def argsort_rows(self, table, rows, cols):
+        from . import ops
+        return ops.argsort_rows(self.ctx, table, rows, cols)
+
+    def gather_rows(self, table, rows, cols, index):
+        from . import ops
+        return ops.gather_rows(self.ctx, table, rows, cols, index)
+
+    def lower_bound_rows(self, sorted_table, rows, cols, probes, nprobes):
+        from . import ops
+        return ops.lower_bound_rows(self.ctx, sorted_table, rows, cols, probes, nprobes)
+
+
+def exchange_v(parts, dist, torch, device, dtype, group=None):
+    """all-to-all(v): parts[d] (1-D tensor) goes to rank d; returns the list received from every source.
+    Built from batched point-to-point sends/receives (what NCCL/RCCL's all-to-all is made of, and it also
+    runs on gloo), after an all-gather of the counts."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    counts = torch.tensor([int(p.numel()) for p in parts], dtype=torch.int64, device=device)
+    allc = [torch.empty_like(counts) for _ in range(world)]
+    dist.all_gather(allc, counts, group=group)
+    recv = [torch.empty(int(allc[s][rank].item()), dtype=dtype, device=device) for s in range(world)]
+    ops_ = []
+    for peer in range(world):
+        if peer == rank:
+            recv[rank].copy_(parts[rank])
+            continue
+        if parts[peer].numel(): ops_.append(dist.P2POp(dist.isend, parts[peer].contiguous(), peer, group))
+        if recv[peer].numel(): ops_.append(dist.P2POp(dist.irecv, recv[peer], peer, group))
+    if ops_:
+        for req in dist.batch_isend_irecv(ops_): req.wait()
+    return recv
+
+
+def choose_splitters(samples, cols, world):
+    """Host: W-1 splitter rows from the gathered sample rows (numpy; a few KB of control data)."""
+    s = np.asarray(samples, dtype=np.uint8).reshape(-1, cols)
+    if len(s) == 0:
+        return np.zeros((world - 1, cols), dtype=np.uint8)
+    order = np.lexsort([s[:, c] for c in range(cols - 1, -1, -1)])
+    s = s[order]
+    pick = [min(len(s) - 1, (k * len(s)) // world) for k in range(1, world)]
+    return s[pick]
+
+
+def global_sort_rows(be, table, rows, cols, read_offset, group=None, samples_per_rank=None):
+    """Sample sort of row shards over the process group.  Every rank passes its shard (`rows` x `cols`
+    bytes, records [read_offset, read_offset + rows) of the file) and gets back a contiguous range of the
+    globally sorted order: dict(table=sorted rows, rows=m, gidx=int64 global read index of each row,
+    offset=global position of the first row).  Stable: equal rows keep file order (they all land on one
+    rank, arrive grouped by source rank, and the final local sort is stable)."""
+    dist, rank, world = _world()
+    torch = be.torch
+    perm = be.argsort_rows(table, rows, cols)
+    local_sorted = be.gather_rows(table, rows, cols, perm)
+    gidx = perm.to(torch.int64) & 0xFFFFFFFF
+    gidx += int(read_offset)
+    if world == 1:
+        return dict(table=local_sorted, rows=rows, gidx=gidx, offset=0)
+    # 1. samples -> splitters (identical on every rank)
+    k = samples_per_rank or max(1, min(rows, 32 * world))
+    pick = torch.tensor([min(rows - 1, (i * rows) // k) for i in range(k)] if rows else [], dtype=torch.int32, device=be.device)
+    samp = be.gather_rows(local_sorted, rows, cols, pick) if rows else torch.empty(0, dtype=torch.uint8, device=be.device)
+    gathered = exchange_v([samp for _ in range(world)], dist, torch, be.device, torch.uint8, group)
+    allsamp = torch.cat(gathered).cpu().numpy()
+    split = choose_splitters(allsamp, cols, world)
+    d_split = torch.from_numpy(split.reshape(-1).copy()).to(be.device)
+    # 2. cut the sorted shard at the splitters: rows < splitter_k stay below cut k (lower bound: equal rows go up together)
+    cuts = be.lower_bound_rows(local_sorted, rows, cols, d_split, world - 1).cpu().tolist() if rows else [0] * (world - 1)
+    bounds = [0] + [int(c) for c in cuts] + [rows]
+    row_parts = [local_sorted[bounds[d] * cols:bounds[d + 1] * cols] for d in range(world)]
+    idx_parts = [gidx[bounds[d]:bounds[d + 1]] for d in range(world)]
+    # 3. all-to-all(v) of rows and their global indices
+    recv_rows = exchange_v(row_parts, dist, torch, be.device, torch.uint8, group)
+    recv_idx = exchange_v(idx_parts, dist, torch, be.device, torch.int64, group)
+    merged = torch.cat(recv_rows)
+    midx = torch.cat(recv_idx)
+    m = int(midx.numel())
+    # 4. stable local sort of the received runs (source-rank order = file order inside ties)
+    if m:
+        perm2 = be.argsort_rows(merged, m, cols)
+        out = be.gather_rows(merged, m, cols, perm2)
+        oidx = be.gather_rows(midx.view(torch.uint8), m, 8, perm2).view(torch.int64)
+    else:
+        out, oidx = merged, midx
+    counts = torch.tensor([m], dtype=torch.int64, device=be.device)
+    allm = [torch.empty_like(counts) for _ in range(world)]
+    dist.all_gather(allm, counts, group=group)
+    offset = sum(int(allm[r].item()) for r in range(rank))
+    return dict(table=out, rows=m, gidx=oidx, offset=offset)
+
+
+def dist_gather_rows(be, table, rows, cols, shard_starts, gidx, group=None):
+    """out[j] = global_table[gidx[j]] where the global table is sharded by records: rank r owns global rows
+    [shard_starts[r], shard_starts[r+1]).  Requests travel to the owners, rows travel back."""
+    dist, rank, world = _world()
+    torch = be.torch
+    n = int(gidx.numel())
+    if world == 1:
+        return be.gather_rows(table, rows, cols, (gidx - int(shard_starts[0])).to(torch.int32))
+    starts = torch.tensor(list(shard_starts), dtype=torch.int64, device=be.device)
+    owner = (torch.bucketize(gidx, starts[1:-1], right=True)).to(torch.uint8)          # plumbing on indices only
+    order = be.argsort_rows(owner, n, 1) if n else torch.empty(0, dtype=torch.int32, device=be.device)
+    sorted_idx = be.gather_rows(gidx.view(torch.uint8), n, 8, order).view(torch.int64) if n else gidx
+    sorted_owner = be.gather_rows(owner, n, 1, order) if n else owner
+    probes = torch.arange(1, world, dtype=torch.uint8, device=be.device)
+    cuts = be.lower_bound_rows(sorted_owner, n, 1, probes, world - 1).cpu().tolist() if n else [0] * (world - 1)
+    bounds = [0] + [int(c) for c in cuts] + [n]
+    req = exchange_v([sorted_idx[bounds[d]:bounds[d + 1]] for d in range(world)], dist, torch, be.device, torch.int64, group)
+    replies = []
+    for s in range(world):
+        want = (req[s] - int(shard_starts[rank])).to(torch.int32)
+        replies.append(be.gather_rows(table, rows, cols, want) if want.numel() else torch.empty(0, dtype=torch.uint8, device=be.device))
+    got = torch.cat(exchange_v(replies, dist, torch, be.device, torch.uint8, group))
+    # rows came back in `order`; undo it: out[order[j]] = got[j]
+    inv = torch.empty(n, dtype=torch.int32, device=be.device)
+    inv[order.to(torch.int64) & 0xFFFFFFFF] = torch.arange(n, dtype=torch.int32, device=be.device)
+    return be.gather_rows(got, n, cols, inv) if n else got

@@ -120,6 +120,14 @@ def argsort_rows(ctx, table, rows, cols):
     return perm
 
 
+def lower_bound_rows(ctx, sorted_table, rows, cols, probes, nprobes):
+    """int64 tensor [nprobes]: first row index of the sorted table that is >= each probe row."""
+    t = ctx.torch
+    pos = t.empty(nprobes, dtype=t.int64, device=ctx.device)
+    call('uq_lower_bound_rows', ctx.h, _p(sorted_table), rows, cols, _p(probes), nprobes, _p(pos))
+    return pos
+
+
 def gather_rows(ctx, table, table_rows, cols, index, n_out=None, out=None):
     t = ctx.torch
     if n_out is None: n_out = index.numel()
