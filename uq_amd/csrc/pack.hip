@@ -42,14 +42,43 @@ struct PackGeom {
     uint32_t magicG;       // for division by G
     uint32_t dna_max;      // longest read the geometry was sized for
     uint32_t fill_d, fill_q;  // the characters with code 0 (bases[0], qualities[0]) replicated in 4 bytes
+    uint32_t P, magicP;    // lanes per read in phase B, and the magic for tid / P
+    // fast path (bases == "ACGT", qualities a contiguous ASCII range below 128, at most one N-trick base)
+    uint32_t q_addlo, q_addhi;   // (0x80 - qmin) and (0x80 - qmin - nq), replicated in 4 bytes
+    uint32_t n_char, n_code;     // the N-trick base and its quality code, replicated in 4 bytes
 };
 
-// 8 consecutive bytes at LDS byte offset `o` (any alignment) from two aligned 8-byte reads.
-__device__ __forceinline__ uint64_t lds_load8(const uint8_t* base, int32_t o) {
-    const uint64_t* p = (const uint64_t*)(base + (o & ~7));
-    const uint64_t q0 = p[0], q1 = p[1];
-    const uint32_t sh = (uint32_t)(o & 7) * 8;
-    return sh ? (q0 >> sh) | (q1 << (64 - sh)) : q0;
+// 8 consecutive bytes at LDS byte offset `o` (any alignment, may be slightly negative) as two dwords:
+// three aligned ds_read_b32 + two v_alignbyte.
+__device__ __forceinline__ void lds_window8(const uint8_t* base, int32_t o, uint32_t& lo, uint32_t& hi) {
+    const uint32_t* p = (const uint32_t*)(base + (o & ~3));
+    const uint32_t a = p[0], b = p[1], c = p[2];
+    const uint32_t sh = (uint32_t)o & 3u;
+    lo = __builtin_amdgcn_alignbyte(b, a, sh);
+    hi = __builtin_amdgcn_alignbyte(c, b, sh);
+}
+// bytes k < nbad of the 8-byte window are above the first base: byte masks of the bytes to KEEP
+__device__ __forceinline__ void window_masks(uint32_t nbad, uint32_t& mlo, uint32_t& mhi) {
+    mlo = nbad >= 4 ? 0u : (0xFFFFFFFFu << (8 * nbad));
+    mhi = nbad >= 8 ? 0u : (nbad > 4 ? (0xFFFFFFFFu << (8 * (nbad - 4))) : 0xFFFFFFFFu);
+}
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }
+// 0xFF in every byte of x that is non-zero
+__device__ __forceinline__ uint32_t nonzero_bytes(uint32_t x) {
+    const uint32_t nz = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+    return (nz - (nz >> 7)) | nz;
+}
+// four ACGT characters -> four 2-bit codes (A0 C1 G2 T3), one per byte
+__device__ __forceinline__ uint32_t acgt_codes(uint32_t w) { return ((w ^ (w >> 1)) >> 1) & 0x03030303u; }
+// the characters those codes stand for (v_perm_b32 picks bytes of "ACGT")
+__device__ __forceinline__ uint32_t acgt_chars(uint32_t codes) { return __builtin_amdgcn_perm(0u, 0x54474341u, codes); }
+// four B-bit codes (one per byte, first character in byte 0) -> 4*B bits, first character most significant
+template <int B>
+__device__ __forceinline__ uint32_t pack4(uint32_t x) {
+    if (B == 8) return __builtin_amdgcn_perm(0u, x, 0x00010203u);
+    if (B == 2) return (x * 0x40100401u) >> 24;
+    const uint32_t c0 = x & ((1u << B) - 1), c1 = (x >> 8) & ((1u << B) - 1), c2 = (x >> 16) & ((1u << B) - 1), c3 = x >> 24;
+    return (((((c0 << B) | c1) << B) | c2) << B) | c3;
 }
 
 constexpr int PK_NV = 5;   // 16-byte loads per lane per tile: a tile spans at most PK_NV * 256 * 16 = 20 KiB
@@ -58,7 +87,7 @@ constexpr int PK_NV = 5;   // 16-byte loads per lane per tile: a tile spans at m
 // Workgroups are persistent: each walks tiles b, b + S, b + 2S, ... with a software pipeline -- the
 // next tile's bytes and line offsets are loaded into registers (in flight) while the current tile is
 // packed out of LDS; span bounds are requested two tiles ahead.
-template <int BD, int BQ, bool NTRICK>
+template <int BD, int BQ, bool NTRICK, bool FAST>
 __global__ __launch_bounds__(PK_THREADS) void pack_tile_kernel(const uint8_t* __restrict__ buf,
                                                                const uint64_t* __restrict__ ls, uint64_t first,
                                                                uint64_t n, PackLut lut, PackGeom g,
@@ -110,6 +139,8 @@ __global__ __launch_bounds__(PK_THREADS) void pack_tile_kernel(const uint8_t* __
         return x;
     };
 
+    uint32_t rr, pp;                                  // this lane packs groups pp, pp + P, ... of read rr of every tile
+    fast_divmod(tid, g.P, g.magicP, rr, pp);
     uint64_t t = blockIdx.x;
     Bounds b_next = load_bounds(t + S);
     Regs cur = issue(t, load_bounds(t));
@@ -133,63 +164,99 @@ __global__ __launch_bounds__(PK_THREADS) void pack_tile_kernel(const uint8_t* __
         cur = issue(t + S, b_next);
         b_next = b_nn;
         if (ok) {
-            // ---- B: one thread = 8 consecutive symbols of one read, both streams: characters -> codes -> bits
-            const uint32_t items = Rt * g.G;
-            for (uint32_t idx = tid; idx < items; idx += PK_THREADS) {
-                uint32_t r, gg;
-                fast_divmod(idx, g.G, g.magicG, r, gg);
+            // ---- B: P lanes per read; a lane owns groups of 8 consecutive symbols, both streams:
+            //         characters -> codes -> bits (8 symbols of b bits = b whole bytes)
+            if (rr < Rt) {
+                const uint32_t r = rr;
                 const uint32_t so = meta[4 * r + 1];
                 uint32_t L = meta[4 * r + 2] - so - 1;
                 const uint32_t qo = meta[4 * r + 3];
                 if (L > g.dna_max || meta[4 * r + 4] - qo - 1 != L) { badr = badr < (uint32_t)(r0 + r) ? badr : (uint32_t)(r0 + r); L = 0; }
-                // symbols t = 8gg .. 8gg+7 (t counts from the END of the read) = characters j = L-1-t, i.e. the
-                // 8 bytes ending at position L - 8gg; byte k of the window is character j = j0 + k
-                const int32_t j0 = (int32_t)L - 8 * (int32_t)gg - 8;
-                uint64_t cb8 = lds_load8(stage, (int32_t)so + j0);
-                uint64_t cq8 = lds_load8(stage, (int32_t)qo + j0);
-                if (j0 < 0) {   // window reaches above the first base: those symbols are zero (fill with code-0 characters)
-                    const uint64_t m = j0 <= -8 ? 0ull : (~0ull << (8 * (uint32_t)(-j0)));
-                    cb8 = (cb8 & m) | ((((uint64_t)g.fill_d << 32) | g.fill_d) & ~m);
-                    cq8 = (cq8 & m) | ((((uint64_t)g.fill_q << 32) | g.fill_q) & ~m);
-                }
-                const uint32_t cbw[2] = {(uint32_t)cb8, (uint32_t)(cb8 >> 32)};
-                const uint32_t cqw[2] = {(uint32_t)cq8, (uint32_t)(cq8 >> 32)};
-                // characters 0..3 are the MORE significant half of the group
-                uint32_t ad[2] = {0, 0}, aq[2] = {0, 0};
-                int32_t orall = 0;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const uint32_t cb = (cbw[k >> 2] >> (8 * (k & 3))) & 255u;
-                    const uint32_t cc = (cqw[k >> 2] >> (8 * (k & 3))) & 255u;
-                    int32_t dc = l_dna[cb];
-                    int32_t qc = l_qual[cc];
-                    if (NTRICK) {
-                        if (dc < 0) { dc = 0; qc = l_nq[cb]; }
+                uint8_t* orow_d = out_d + r * g.Cd + (g.Cd - 1);
+                uint8_t* orow_q = out_q + r * g.Cq + (g.Cq - 1);
+                for (uint32_t gg = pp; gg < g.G; gg += g.P) {
+                    // symbols t = 8gg .. 8gg+7 (t counts from the END of the read) = characters j = L-1-t, i.e. the
+                    // 8 bytes ending at position L - 8gg; byte k of the window is character j = j0 + k
+                    const int32_t j0 = (int32_t)L - 8 * (int32_t)gg - 8;
+                    uint32_t b_lo, b_hi, q_lo, q_hi;
+                    lds_window8(stage, (int32_t)so + j0, b_lo, b_hi);
+                    lds_window8(stage, (int32_t)qo + j0, q_lo, q_hi);
+                    if (j0 < 0) {   // window reaches above the first base: those symbols are zero (fill with code-0 characters)
+                        uint32_t mlo, mhi;
+                        window_masks((uint32_t)(-j0), mlo, mhi);
+                        b_lo = bfi(mlo, b_lo, g.fill_d); b_hi = bfi(mhi, b_hi, g.fill_d);
+                        q_lo = bfi(mlo, q_lo, g.fill_q); q_hi = bfi(mhi, q_hi, g.fill_q);
                     }
-                    orall |= dc | qc;
-                    ad[k >> 2] = (ad[k >> 2] << BD) | (uint32_t)dc;
-                    aq[k >> 2] = (aq[k >> 2] << BQ) | (uint32_t)qc;
-                }
-                if (orall < 0) {            // a character without a code: report, keep the row deterministic
-                    badr = badr < (uint32_t)(r0 + r) ? badr : (uint32_t)(r0 + r);
-                    ad[0] = ad[1] = aq[0] = aq[1] = 0;
-                }
-                uint64_t vd = ((uint64_t)ad[0] << (4 * BD)) | ad[1];
-                uint64_t vq = ((uint64_t)aq[0] << (4 * BQ)) | aq[1];
-                if (g.variable) {                                  // sentinel = code 1 at symbol index t = L
-                    const int32_t i = (int32_t)L - 8 * (int32_t)gg;
-                    if (i >= 0 && i < 8) { vd |= 1ull << (BD * i); vq |= 1ull << (BQ * i); }
-                }
-                // 8 symbols of b bits = b whole bytes; byte index counts from the row's LAST byte
-                uint8_t* od = out_d + r * g.Cd + (g.Cd - 1) - BD * gg;
-                uint8_t* oq = out_q + r * g.Cq + (g.Cq - 1) - BQ * gg;
-                const uint32_t nd = g.Cd - BD * gg, nq = g.Cq - BQ * gg;     // bytes left in the row from here up
+                    uint32_t ad0, ad1, aq0, aq1;      // 4 symbols each; *0 = the more significant half
+                    bool generic = !FAST;
+                    if (FAST) {
+                        uint32_t c0 = acgt_codes(b_lo), c1 = acgt_codes(b_hi);
+                        const uint32_t e0 = acgt_chars(c0) ^ b_lo, e1 = acgt_chars(c1) ^ b_hi;      // non-zero byte = not ACGT
+                        uint32_t u0 = q_lo + g.q_addlo, u1 = q_hi + g.q_addlo;
+                        uint32_t bq0 = (q_lo | (q_lo + g.q_addhi) | ~u0) & 0x80808080u;
+                        uint32_t bq1 = (q_hi | (q_hi + g.q_addhi) | ~u1) & 0x80808080u;
+                        uint32_t x0 = u0 & 0x7F7F7F7Fu, x1 = u1 & 0x7F7F7F7Fu;
+                        if (e0 | e1) {
+                            if (NTRICK && !((q_lo | q_hi) & 0x80808080u)) {
+                                const uint32_t m0 = nonzero_bytes(e0), m1 = nonzero_bytes(e1);
+                                if (((b_lo ^ g.n_char) & m0) | ((b_hi ^ g.n_char) & m1)) generic = true;   // not the N-trick base
+                                c0 &= ~m0; c1 &= ~m1;
+                                x0 = bfi(m0, g.n_code, x0); x1 = bfi(m1, g.n_code, x1);
+                                bq0 &= ~m0; bq1 &= ~m1;
+                            } else generic = true;
+                        }
+                        if (bq0 | bq1) generic = true;
+                        ad0 = pack4<BD>(c0); ad1 = pack4<BD>(c1);
+                        aq0 = pack4<BQ>(x0); aq1 = pack4<BQ>(x1);
+                    }
+                    if (generic) {
+                        const uint32_t cbw[2] = {b_lo, b_hi};
+                        const uint32_t cqw[2] = {q_lo, q_hi};
+                        uint32_t ad[2] = {0, 0}, aq[2] = {0, 0};
+                        int32_t orall = 0;
 #pragma unroll
-                for (int i = 0; i < BD; ++i)
-                    if ((uint32_t)i < nd) od[-i] = (uint8_t)(vd >> (8 * i));
+                        for (int k = 0; k < 8; ++k) {
+                            const uint32_t cb = (cbw[k >> 2] >> (8 * (k & 3))) & 255u;
+                            const uint32_t cc = (cqw[k >> 2] >> (8 * (k & 3))) & 255u;
+                            int32_t dc = l_dna[cb];
+                            int32_t qc = l_qual[cc];
+                            if (NTRICK) {
+                                if (dc < 0) { dc = 0; qc = l_nq[cb]; }
+                            }
+                            orall |= dc | qc;
+                            ad[k >> 2] = (ad[k >> 2] << BD) | (uint32_t)dc;
+                            aq[k >> 2] = (aq[k >> 2] << BQ) | (uint32_t)qc;
+                        }
+                        if (orall < 0) {            // a character without a code: report, keep the row deterministic
+                            badr = badr < (uint32_t)(r0 + r) ? badr : (uint32_t)(r0 + r);
+                            ad[0] = ad[1] = aq[0] = aq[1] = 0;
+                        }
+                        ad0 = ad[0]; ad1 = ad[1]; aq0 = aq[0]; aq1 = aq[1];
+                    }
+                    uint64_t vd = ((uint64_t)ad0 << (4 * BD)) | ad1;
+                    uint64_t vq = ((uint64_t)aq0 << (4 * BQ)) | aq1;
+                    if (g.variable) {                                  // sentinel = code 1 at symbol index t = L
+                        const int32_t i = (int32_t)L - 8 * (int32_t)gg;
+                        if (i >= 0 && i < 8) { vd |= 1ull << (BD * i); vq |= 1ull << (BQ * i); }
+                    }
+                    // byte index counts from the row's LAST byte; only the top group can stick out of the row
+                    uint8_t* od = orow_d - BD * gg;
+                    uint8_t* oq = orow_q - BQ * gg;
+                    if (gg + 1 < g.G) {
 #pragma unroll
-                for (int i = 0; i < BQ; ++i)
-                    if ((uint32_t)i < nq) oq[-i] = (uint8_t)(vq >> (8 * i));
+                        for (int i = 0; i < BD; ++i) od[-i] = (uint8_t)(vd >> (8 * i));
+#pragma unroll
+                        for (int i = 0; i < BQ; ++i) oq[-i] = (uint8_t)(vq >> (8 * i));
+                    } else {
+                        const uint32_t nd = g.Cd - BD * gg, nq = g.Cq - BQ * gg;     // bytes left in the row from here up
+#pragma unroll
+                        for (int i = 0; i < BD; ++i)
+                            if ((uint32_t)i < nd) od[-i] = (uint8_t)(vd >> (8 * i));
+#pragma unroll
+                        for (int i = 0; i < BQ; ++i)
+                            if ((uint32_t)i < nq) oq[-i] = (uint8_t)(vq >> (8 * i));
+                    }
+                }
             }
         }
         __syncthreads();
@@ -262,22 +329,25 @@ __global__ __launch_bounds__(256) void pack_carry_kernel(const uint8_t* __restri
 typedef void (*PackKernel)(const uint8_t*, const uint64_t*, uint64_t, uint64_t, PackLut, PackGeom, uint8_t*, uint8_t*, unsigned long long*);
 
 template <int BD, int BQ>
-PackKernel pick_nt(bool ntrick) { return ntrick ? pack_tile_kernel<BD, BQ, true> : pack_tile_kernel<BD, BQ, false>; }
+PackKernel pick_nt(bool ntrick, bool fast) {
+    if (BD == 2 && fast) return ntrick ? pack_tile_kernel<2, BQ, true, true> : pack_tile_kernel<2, BQ, false, true>;
+    return ntrick ? pack_tile_kernel<BD, BQ, true, false> : pack_tile_kernel<BD, BQ, false, false>;
+}
 
 template <int BD>
-PackKernel pick_bq(int bq, bool ntrick) {
+PackKernel pick_bq(int bq, bool ntrick, bool fast) {
     switch (bq) {
-        case 1: return pick_nt<BD, 1>(ntrick); case 2: return pick_nt<BD, 2>(ntrick); case 3: return pick_nt<BD, 3>(ntrick);
-        case 4: return pick_nt<BD, 4>(ntrick); case 5: return pick_nt<BD, 5>(ntrick); case 6: return pick_nt<BD, 6>(ntrick);
-        case 7: return pick_nt<BD, 7>(ntrick); default: return pick_nt<BD, 8>(ntrick);
+        case 1: return pick_nt<BD, 1>(ntrick, fast); case 2: return pick_nt<BD, 2>(ntrick, fast); case 3: return pick_nt<BD, 3>(ntrick, fast);
+        case 4: return pick_nt<BD, 4>(ntrick, fast); case 5: return pick_nt<BD, 5>(ntrick, fast); case 6: return pick_nt<BD, 6>(ntrick, fast);
+        case 7: return pick_nt<BD, 7>(ntrick, fast); default: return pick_nt<BD, 8>(ntrick, fast);
     }
 }
 
-PackKernel pick_kernel(int bd, int bq, bool ntrick) {
+PackKernel pick_kernel(int bd, int bq, bool ntrick, bool fast) {
     switch (bd) {
-        case 1: return pick_bq<1>(bq, ntrick); case 2: return pick_bq<2>(bq, ntrick); case 3: return pick_bq<3>(bq, ntrick);
-        case 4: return pick_bq<4>(bq, ntrick); case 5: return pick_bq<5>(bq, ntrick); case 6: return pick_bq<6>(bq, ntrick);
-        case 7: return pick_bq<7>(bq, ntrick); default: return pick_bq<8>(bq, ntrick);
+        case 1: return pick_bq<1>(bq, ntrick, fast); case 2: return pick_bq<2>(bq, ntrick, fast); case 3: return pick_bq<3>(bq, ntrick, fast);
+        case 4: return pick_bq<4>(bq, ntrick, fast); case 5: return pick_bq<5>(bq, ntrick, fast); case 6: return pick_bq<6>(bq, ntrick, fast);
+        case 7: return pick_bq<7>(bq, ntrick, fast); default: return pick_bq<8>(bq, ntrick, fast);
     }
 }
 }  // namespace
@@ -347,7 +417,30 @@ extern "C" int uq_pack(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line
     if (per_cu > 6) per_cu = 6;
     if (per_cu < 1) per_cu = 1;
     const uint64_t blocks = tiles < (uint64_t)UQ_NUM_CU * per_cu ? tiles : (uint64_t)UQ_NUM_CU * per_cu;
-    PackKernel k = pick_kernel((int)bd, (int)bq, ntrick);
+    // phase B: P lanes per read
+    uint32_t P = PK_THREADS / R;
+    if (P > g.G) P = g.G;
+    if (P < 1) P = 1;
+    g.P = P; g.magicP = magic_u32(P);
+    // fast path: bases == "ACGT", qualities one contiguous ASCII range below 128, at most one N-trick base
+    bool fast = bd == 2 && hp->dna_code['A'] == 0 && hp->dna_code['C'] == 1 && hp->dna_code['G'] == 2 && hp->dna_code['T'] == 3;
+    int nbases = 0, nq = 0, qmin = 256, qmaxc = -1, ntrick_bases = 0, nchar = 0;
+    for (int i = 0; i < 256; ++i) {
+        if (hp->dna_code[i] >= 0) ++nbases;
+        if (hp->qual_code[i] >= 0) { ++nq; if (i < qmin) qmin = i; if (i > qmaxc) qmaxc = i; }
+        if (hp->dna_code[i] < 0 && hp->n_qual[i] >= 0) { ++ntrick_bases; nchar = i; }
+    }
+    fast = fast && nbases == 4 && nq >= 1 && qmaxc - qmin + 1 == nq && qmaxc < 128 && ntrick_bases <= 1 &&
+           (ntrick_bases == 0 || hp->n_qual[nchar] < 128);
+    if (fast)
+        for (int i = qmin; i <= qmaxc; ++i) fast = fast && hp->qual_code[i] == i - qmin;
+    g.q_addlo = g.q_addhi = g.n_char = g.n_code = 0;
+    if (fast) {
+        g.q_addlo = 0x01010101u * (uint32_t)(0x80 - qmin);
+        g.q_addhi = 0x01010101u * (uint32_t)(0x80 - qmin - nq);
+        if (ntrick_bases == 1) { g.n_char = 0x01010101u * (uint32_t)nchar; g.n_code = 0x01010101u * (uint32_t)hp->n_qual[nchar]; }
+    }
+    PackKernel k = pick_kernel((int)bd, (int)bq, ntrick, fast);
     if (lds > 48 * 1024) UQ_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     k<<<(uint32_t)blocks, PK_THREADS, lds, ctx->stream>>>(d_buf, d_line_start, first_read, nreads, lut, g, d_dna, d_qual,
                                                          (unsigned long long*)d_bad);
