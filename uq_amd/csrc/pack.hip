@@ -22,6 +22,7 @@
 // the reference's `+=` carry into the neighbouring symbol; that case is packed by a plain
 // thread-per-read big-integer addition so the bytes still match.
 #include "common.h"
+#include "swar.h"
 
 namespace {
 constexpr int PK_THREADS = 256;
@@ -48,26 +49,6 @@ struct PackGeom {
     uint32_t n_char, n_code;     // the N-trick base and its quality code, replicated in 4 bytes
 };
 
-// 8 consecutive bytes at LDS byte offset `o` (any alignment, may be slightly negative) as two dwords:
-// three aligned ds_read_b32 + two v_alignbyte.
-__device__ __forceinline__ void lds_window8(const uint8_t* base, int32_t o, uint32_t& lo, uint32_t& hi) {
-    const uint32_t* p = (const uint32_t*)(base + (o & ~3));
-    const uint32_t a = p[0], b = p[1], c = p[2];
-    const uint32_t sh = (uint32_t)o & 3u;
-    lo = __builtin_amdgcn_alignbyte(b, a, sh);
-    hi = __builtin_amdgcn_alignbyte(c, b, sh);
-}
-// bytes k < nbad of the 8-byte window are above the first base: byte masks of the bytes to KEEP
-__device__ __forceinline__ void window_masks(uint32_t nbad, uint32_t& mlo, uint32_t& mhi) {
-    mlo = nbad >= 4 ? 0u : (0xFFFFFFFFu << (8 * nbad));
-    mhi = nbad >= 8 ? 0u : (nbad > 4 ? (0xFFFFFFFFu << (8 * (nbad - 4))) : 0xFFFFFFFFu);
-}
-__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }
-// 0xFF in every byte of x that is non-zero
-__device__ __forceinline__ uint32_t nonzero_bytes(uint32_t x) {
-    const uint32_t nz = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
-    return (nz - (nz >> 7)) | nz;
-}
 // four ACGT characters -> four 2-bit codes (A0 C1 G2 T3), one per byte
 __device__ __forceinline__ uint32_t acgt_codes(uint32_t w) { return ((w ^ (w >> 1)) >> 1) & 0x03030303u; }
 // the characters those codes stand for (v_perm_b32 picks bytes of "ACGT")

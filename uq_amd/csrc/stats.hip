@@ -15,12 +15,14 @@
 // straight from HBM.
 // Algorithmic HBM bytes: the record bytes once + 32 B of line offsets per record.
 #include "common.h"
+#include "swar.h"
 
 namespace {
 constexpr int ST_THREADS = 256;
 constexpr uint32_t ST_BBASE = 64;          // base bytes with an LDS counter: [64, 128)
 constexpr uint32_t ST_NB = 64, ST_NQ = 64;
-constexpr uint32_t ST_CAP = 12 * 1024;     // staging bytes per tile
+constexpr int ST_NV = 5;                  // 16-byte loads per lane per tile
+constexpr uint32_t ST_CAP = ST_NV * 256 * 16;   // staging bytes per tile (20 KiB)
 constexpr uint32_t ST_RMAX = 64;           // records per tile, upper bound (4 * ST_RMAX + 1 <= 2 * ST_THREADS)
 
 __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p) {
@@ -66,11 +68,10 @@ struct Acc {
 
 __global__ __launch_bounds__(ST_THREADS) void stats_kernel(const uint8_t* __restrict__ buf, uint64_t nbytes,
                                                            const uint64_t* __restrict__ ls, uint64_t first,
-                                                           uint64_t n, uint32_t R, uint32_t qbase, uq_stats* __restrict__ st) {
+                                                           uint64_t n, uint32_t R, uint32_t qbase, uint32_t P, uint32_t magicP, uq_stats* __restrict__ st) {
     __shared__ uint32_t hist[ST_NB * ST_NQ];
     __shared__ __align__(16) uint8_t stage[ST_CAP + 32];
     __shared__ uint32_t meta[4 * ST_RMAX + 4];
-    __shared__ uint32_t tile_lmax;
     for (int i = threadIdx.x; i < (int)(ST_NB * ST_NQ); i += ST_THREADS) hist[i] = 0;
     __syncthreads();
 
@@ -80,13 +81,16 @@ __global__ __launch_bounds__(ST_THREADS) void stats_kernel(const uint8_t* __rest
     constexpr uint32_t NHW = 2 * (ST_THREADS / 64);
     Acc acc;
     const uint64_t ntiles = (n + R - 1) / R;
+    uint32_t rr, pp;                                  // this lane counts groups pp, pp + P, ... of read rr of every tile
+    fast_divmod(tid, P, magicP, rr, pp);
+    const uint32_t q_addlo = 0x01010101u * (0x80u - qbase), q_addhi = 0x01010101u * (0x80u - qbase - ST_NQ);
 
     // Software pipeline over this workgroup's tiles t, t + S, t + 2S, ... (S = gridDim.x):
     //   span bounds are requested two tiles ahead, the tile's bytes + line offsets one tile ahead (they
     //   stay in registers, in flight, while the current tile is counted out of LDS).
     const uint64_t S = gridDim.x;
     struct Bounds { uint64_t g0, g1; };
-    struct Regs { uint4 v[3]; uint64_t m0, m1; uint64_t g0; uint32_t skew, nvec, Rt; bool exists, staged; };
+    struct Regs { uint4 v[ST_NV]; uint64_t m0, m1; uint64_t g0; uint32_t skew, nvec, Rt; bool exists, staged; };
     auto load_bounds = [&](uint64_t tt) {
         Bounds b{0, 0};
         if (tt < ntiles) {
@@ -98,7 +102,7 @@ __global__ __launch_bounds__(ST_THREADS) void stats_kernel(const uint8_t* __rest
     auto issue = [&](uint64_t tt, Bounds b) {
         Regs x;
         x.exists = tt < ntiles; x.staged = false; x.m0 = x.m1 = 0; x.g0 = b.g0; x.skew = 0; x.nvec = 0; x.Rt = 0;
-        x.v[0] = x.v[1] = x.v[2] = make_uint4(0, 0, 0, 0);
+        for (int u = 0; u < ST_NV; ++u) x.v[u] = make_uint4(0, 0, 0, 0);
         if (!x.exists) return x;
         x.Rt = (uint32_t)((n - tt * R) < R ? (n - tt * R) : R);
         const uint64_t a0 = ((uint64_t)(uintptr_t)buf + b.g0) & ~uint64_t(15);
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(ST_THREADS) void stats_kernel(const uint8_t* __rest
         x.nvec = (uint32_t)((span + 15) >> 4);
         const uint4* src = (const uint4*)(uintptr_t)a0;
 #pragma unroll
-        for (int u = 0; u < 3; ++u) { const uint32_t i = u * ST_THREADS + tid; if (i < x.nvec) x.v[u] = src[i]; }
+        for (int u = 0; u < ST_NV; ++u) { const uint32_t i = u * ST_THREADS + tid; if (i < x.nvec) x.v[u] = src[i]; }
         const uint64_t* lsp = ls + 4 * (first + tt * R);
         if (tid <= 4 * x.Rt) x.m0 = lsp[tid];
         if (tid + ST_THREADS <= 4 * x.Rt) x.m1 = lsp[tid + ST_THREADS];
@@ -126,39 +130,44 @@ __global__ __launch_bounds__(ST_THREADS) void stats_kernel(const uint8_t* __rest
         if (cur.staged) {
             if (tid <= 4 * Rt) meta[tid] = (uint32_t)(cur.m0 - cur.g0) + cur.skew;
             if (tid + ST_THREADS <= 4 * Rt) meta[tid + ST_THREADS] = (uint32_t)(cur.m1 - cur.g0) + cur.skew;
-            if (tid == 0) tile_lmax = 0;
 #pragma unroll
-            for (int u = 0; u < 3; ++u) { const uint32_t i = u * ST_THREADS + tid; if (i < cur.nvec) ((uint4*)stage)[i] = cur.v[u]; }
+            for (int u = 0; u < ST_NV; ++u) { const uint32_t i = u * ST_THREADS + tid; if (i < cur.nvec) ((uint4*)stage)[i] = cur.v[u]; }
         }
         __syncthreads();
         const bool staged = cur.staged;
         cur = issue(t + S, b_next);          // next tile's loads fly while this one is counted
         b_next = b_nn;
         if (staged) {
-            // per-record checks (one lane per record) and the longest read of the tile
-            for (uint32_t r = tid; r < Rt; r += ST_THREADS) {
+            // P lanes per read: lane pp == 0 does the per-record checks, every lane counts groups of 8 positions
+            if (rr < Rt) {
+                const uint32_t r = rr;
                 const uint32_t p0 = meta[4 * r], s = meta[4 * r + 1], e1 = meta[4 * r + 2], q = meta[4 * r + 3], e2 = meta[4 * r + 4];
                 const uint32_t L = e1 - s - 1, Lq = e2 - q - 1;
-                acc.record(r0 + r, stage[e1] == '+', L, Lq, e2 - p0);
-                atomicMax(&tile_lmax, L < Lq ? L : Lq);
-            }
-            __syncthreads();
-            // pairs: one lane per group of 8 consecutive positions of one record
-            const uint32_t G8 = (tile_lmax + 7) >> 3;
-            const float rcpG = 1.0f / (float)(G8 ? G8 : 1);
-            const uint32_t items = Rt * G8;
-            for (uint32_t idx = tid; idx < items; idx += ST_THREADS) {
-                uint32_t r = (uint32_t)((float)idx * rcpG);
-                uint32_t gg = idx - r * G8;
-                if ((int32_t)gg < 0) { --r; gg += G8; } else if (gg >= G8) { ++r; gg -= G8; }
-                const uint32_t s = meta[4 * r + 1], e1 = meta[4 * r + 2], q = meta[4 * r + 3], e2 = meta[4 * r + 4];
-                const uint32_t L = e1 - s - 1, Lq = e2 - q - 1;
+                if (pp == 0) acc.record(r0 + r, stage[e1] == '+', L, Lq, e2 - p0);
                 const uint32_t Lc = L < Lq ? L : Lq;
-                const uint32_t j = 8 * gg;
-                if (j >= Lc) continue;
-                const uint32_t cnt = Lc - j;
-                count_quad(lds_load4(stage, s + j), lds_load4(stage, q + j), cnt, qbase, hist, st);
-                if (cnt > 4) count_quad(lds_load4(stage, s + j + 4), lds_load4(stage, q + j + 4), cnt - 4, qbase, hist, st);
+                for (uint32_t j = 8 * pp; j < Lc; j += 8 * P) {
+                    uint32_t b_lo, b_hi, q_lo, q_hi;
+                    lds_window8(stage, (int32_t)(s + j), b_lo, b_hi);
+                    lds_window8(stage, (int32_t)(q + j), q_lo, q_hi);
+                    const uint32_t cnt = Lc - j;
+                    // byte - window base, valid when the top bits vanish: bases 64..127, qualities qbase..qbase+63
+                    const uint32_t sb0 = b_lo ^ 0x40404040u, sb1 = b_hi ^ 0x40404040u;
+                    const uint32_t u0 = q_lo + q_addlo, u1 = q_hi + q_addlo;
+                    const uint32_t bad = ((sb0 | sb1) & 0xC0C0C0C0u) |
+                                         ((q_lo | (q_lo + q_addhi) | ~u0 | q_hi | (q_hi + q_addhi) | ~u1) & 0x80808080u);
+                    if (cnt >= 8 && bad == 0) {
+                        const uint32_t sq0 = (u0 & 0x7F7F7F7Fu) << 2, sq1 = (u1 & 0x7F7F7F7Fu) << 2;   // quality slot * 4 per byte
+                        uint8_t* hb = (uint8_t*)hist;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            atomicAdd((uint32_t*)(hb + ((((sb0 >> (8 * k)) & 0xFFu) << 8) | ((sq0 >> (8 * k)) & 0xFFu))), 1u);
+                            atomicAdd((uint32_t*)(hb + ((((sb1 >> (8 * k)) & 0xFFu) << 8) | ((sq1 >> (8 * k)) & 0xFFu))), 1u);
+                        }
+                    } else {
+                        count_quad(b_lo, q_lo, cnt, qbase, hist, st);
+                        if (cnt > 4) count_quad(b_hi, q_hi, cnt - 4, qbase, hist, st);
+                    }
+                }
             }
         } else {
             // oversize tile: straight from HBM, one record per half-wave
@@ -266,8 +275,11 @@ extern "C" int uq_stats_accumulate(uq_ctx* ctx, const uint8_t* d_buf, const uint
     if (R > ST_RMAX) R = ST_RMAX;
     if (R < 1) R = 1;
     const uint64_t ntiles = (nreads + R - 1) / R;
-    uint32_t blocks = (uint32_t)(ntiles < UQ_NUM_CU * 5 ? ntiles : UQ_NUM_CU * 5);
-    stats_kernel<<<blocks, ST_THREADS, 0, ctx->stream>>>(d_buf, nbytes, d_line_start, first_read, nreads, (uint32_t)R, qbase, d_stats);
+    uint32_t blocks = (uint32_t)(ntiles < UQ_NUM_CU * 4 ? ntiles : UQ_NUM_CU * 4);
+    uint32_t P = ST_THREADS / (uint32_t)R;
+    if (P > 16) P = 16;
+    if (P < 1) P = 1;
+    stats_kernel<<<blocks, ST_THREADS, 0, ctx->stream>>>(d_buf, nbytes, d_line_start, first_read, nreads, (uint32_t)R, qbase, P, magic_u32(P), d_stats);
     UQ_LAUNCH_CHECK();
     return 0;
 }

@@ -1,0 +1,24 @@
+// swar.h -- byte-parallel (SIMD-within-a-register) helpers shared by the pack and stats kernels.
+#pragma once
+#include "common.h"
+
+// 8 consecutive bytes at LDS byte offset `o` (any alignment, may be slightly negative) as two dwords:
+// three aligned ds_read_b32 + two v_alignbyte.
+__device__ __forceinline__ void lds_window8(const uint8_t* base, int32_t o, uint32_t& lo, uint32_t& hi) {
+    const uint32_t* p = (const uint32_t*)(base + (o & ~3));
+    const uint32_t a = p[0], b = p[1], c = p[2];
+    const uint32_t sh = (uint32_t)o & 3u;
+    lo = __builtin_amdgcn_alignbyte(b, a, sh);
+    hi = __builtin_amdgcn_alignbyte(c, b, sh);
+}
+// bytes k < nbad of the 8-byte window are above the first base: byte masks of the bytes to KEEP
+__device__ __forceinline__ void window_masks(uint32_t nbad, uint32_t& mlo, uint32_t& mhi) {
+    mlo = nbad >= 4 ? 0u : (0xFFFFFFFFu << (8 * nbad));
+    mhi = nbad >= 8 ? 0u : (nbad > 4 ? (0xFFFFFFFFu << (8 * (nbad - 4))) : 0xFFFFFFFFu);
+}
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }
+// 0xFF in every byte of x that is non-zero
+__device__ __forceinline__ uint32_t nonzero_bytes(uint32_t x) {
+    const uint32_t nz = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+    return (nz - (nz >> 7)) | nz;
+}
