@@ -38,7 +38,7 @@ def host_decide(hs, notricks=False, pad=False):
     return analysis.decide_from_counts(hs.counts, hs.len_min, hs.len_max, notricks=notricks, pad=pad)
 
 
-def cpu_baseline(sample_bytes, n_sample):
+def cpu_baseline(sample_bytes, n_sample, d):
     """Oracle legs on the host: the per-base Python loops the reference runs (one core), and the C port."""
     sys.path.insert(0, os.path.join(HERE, 'oracle'))
     sys.path.insert(0, os.path.join(HERE, 'tests'))
@@ -56,7 +56,7 @@ def cpu_baseline(sample_bytes, n_sample):
             try: sq[b][c] += 1
             except KeyError:
                 sq.setdefault(b, {}); sq[b][c] = sq[b].get(c, 0) + 1
-    d = O.decide(sq, dmin, dmax)
+    # decisions: the whole-file ones of the GPU run (a sample may see fewer symbols / shorter reads)
     dna, qual = O.encoder(lines, d['bases'], d['qualities'], d['N_qual'], d['dna_bytes_per_row'], d['quality_bytes_per_row'],
                           d['bits_per_base'], d['bits_per_quality'], d['variable_read_lengths'])
     t_py = time.perf_counter() - t0
@@ -88,6 +88,9 @@ def main():
     ap.add_argument('--reads', type=int, default=10_000_000, help='reads per GPU (default: BASELINE configs[1])')
     ap.add_argument('--length', type=int, default=150)
     ap.add_argument('--cpu-sample', type=int, default=100_000, help='reads timed on the host for cpu_baseline (0 = skip)')
+    ap.add_argument('--workload', default='cfg2', choices=['cfg2', 'cfg5-notricks', 'cfg5-ntrick'],
+                    help='cfg2 = BASELINE configs[1] (the bench line the driver reads); cfg5-* = configs[4]: variable length 36-301 bp '
+                         'with 1%% N, 3-bit ACGNT path (--notricks) or 2-bit N-trick path -- parity/measurement extras')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -107,7 +110,11 @@ def main():
     ctx = Context(local_rank)
 
     n = args.reads
-    spec = synth.Spec(SEED, args.length)
+    notricks = args.workload == 'cfg5-notricks'
+    if args.workload == 'cfg2':
+        spec = synth.Spec(SEED, args.length)
+    else:
+        spec = synth.Spec(20261003 + 5, (36, 301), n_rate=1)
     d_buf = ops.synth_fastq(ctx, spec, rank * n, n)           # resident in HBM before timing
     fastq_bytes = d_buf.numel()
     ctx.sync()
@@ -128,7 +135,7 @@ def main():
             hs = ops.stats_fetch(ctx, st)
         if hs.bad_plus is not None or hs.bad_len is not None:
             raise RuntimeError('malformed FASTQ record')
-        d = host_decide(hs)
+        d = host_decide(hs, notricks=notricks)
         p = ops.make_pack_params(d['bases'], d['qualities'], d['N_qual'], d['bits_per_base'], d['bits_per_quality'],
                                  d['variable_read_lengths'], d['dna_bytes_per_row'], d['quality_bytes_per_row'],
                                  d['dna_max'], hs.max_record_bytes)
@@ -170,7 +177,7 @@ def main():
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            if tj.get('reads') == nreads and tj.get('length') == args.length:
+            if args.workload == 'cfg2' and tj.get('reads') == nreads and tj.get('length') == args.length:
                 traffic = tj.get('hbm_bytes_per_launch')
         except Exception:
             traffic = None
@@ -182,9 +189,12 @@ def main():
         'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic',
         'reads_per_s': round(world * nreads / (dt / args.steps), 1),
-        'config': {'workload': 'BASELINE configs[1]: %d x %dbp synth-v1 FASTQ per GPU (%.3f GB), --sort None --raw DNA QUAL QNAME '
-                               '--pattern 0.1 0.1; step = census + index + stats + decisions + 2-bit DNA / %d-bit QUAL pack'
-                               % (nreads, args.length, fastq_bytes / 1e9, d['bits_per_quality']),
+        'config': {'workload': ('BASELINE configs[1]: %d x %dbp synth-v1 FASTQ per GPU (%.3f GB), --sort None --raw DNA QUAL QNAME '
+                                '--pattern 0.1 0.1; step = census + index + stats + decisions + %d-bit DNA / %d-bit QUAL pack'
+                                % (nreads, args.length, fastq_bytes / 1e9, d['bits_per_base'], d['bits_per_quality'])) if args.workload == 'cfg2' else
+                               ('BASELINE configs[4] (%s): %d x 36-301bp synth-v1 FASTQ with 1%% N per GPU (%.3f GB); step = census + index + '
+                                'stats + decisions + %d-bit DNA / %d-bit QUAL variable-length pack'
+                                % (args.workload, nreads, fastq_bytes / 1e9, d['bits_per_base'], d['bits_per_quality'])),
                    'reads_per_gpu': nreads, 'read_length': args.length, 'fastq_bytes_per_gpu': fastq_bytes,
                    'sharding': 'record-parallel, %d shard(s)' % world},
         'roofline': {'bound': 'hbm', 'kernel': 'pack_tile_kernel', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
@@ -196,7 +206,7 @@ def main():
         ns = min(args.cpu_sample, nreads)
         end = int(state['ls'][4 * ns].item())
         sample = bytes(d_buf[:end].cpu().numpy().tobytes())
-        cb, (rd, rq) = cpu_baseline(sample, ns)
+        cb, (rd, rq) = cpu_baseline(sample, ns, d)
         gd = state['dna'][:ns * d['dna_bytes_per_row']].cpu().numpy().reshape(ns, -1)
         gq = state['qual'][:ns * d['quality_bytes_per_row']].cpu().numpy().reshape(ns, -1)
         cb['gpu_rows_match_oracle_on_sample'] = bool(np.array_equal(gd, rd) and np.array_equal(gq, rq))

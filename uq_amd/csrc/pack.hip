@@ -62,6 +62,26 @@ __device__ __forceinline__ uint32_t pack4(uint32_t x) {
     return (((((c0 << B) | c1) << B) | c2) << B) | c3;
 }
 
+// LDS tile (16-byte aligned) -> global span, with the widest stores the destination alignment allows.
+__device__ __noinline__ void store_tile(uint8_t* gdst, const uint8_t* lsrc, uint32_t nb, uint32_t tid) {
+    const uint32_t mis = (uint32_t)(uintptr_t)gdst;
+    if ((mis & 15) == 0) {
+        const uint32_t nv = nb >> 4;
+        for (uint32_t i = tid; i < nv; i += 256) ((uint4*)gdst)[i] = ((const uint4*)lsrc)[i];
+        for (uint32_t i = (nv << 4) + tid; i < nb; i += 256) gdst[i] = lsrc[i];
+    } else if ((mis & 7) == 0) {
+        const uint32_t nv = nb >> 3;
+        for (uint32_t i = tid; i < nv; i += 256) ((uint2*)gdst)[i] = ((const uint2*)lsrc)[i];
+        for (uint32_t i = (nv << 3) + tid; i < nb; i += 256) gdst[i] = lsrc[i];
+    } else if ((mis & 3) == 0) {
+        const uint32_t nv = nb >> 2;
+        for (uint32_t i = tid; i < nv; i += 256) ((uint32_t*)gdst)[i] = ((const uint32_t*)lsrc)[i];
+        for (uint32_t i = (nv << 2) + tid; i < nb; i += 256) gdst[i] = lsrc[i];
+    } else {
+        for (uint32_t i = tid; i < nb; i += 256) gdst[i] = lsrc[i];
+    }
+}
+
 constexpr int PK_NV = 5;   // 16-byte loads per lane per tile: a tile spans at most PK_NV * 256 * 16 = 20 KiB
 
 // LDS carve (dynamic): [16 B guard][stage][out_d | out_q][meta u32 x (4R+4)][luts 3 x 512 B]
@@ -69,7 +89,7 @@ constexpr int PK_NV = 5;   // 16-byte loads per lane per tile: a tile spans at m
 // next tile's bytes and line offsets are loaded into registers (in flight) while the current tile is
 // packed out of LDS; span bounds are requested two tiles ahead.
 template <int BD, int BQ, bool NTRICK, bool FAST>
-__global__ __launch_bounds__(PK_THREADS) void pack_tile_kernel(const uint8_t* __restrict__ buf,
+__global__ __launch_bounds__(PK_THREADS, 5) void pack_tile_kernel(const uint8_t* __restrict__ buf,
                                                                const uint64_t* __restrict__ ls, uint64_t first,
                                                                uint64_t n, PackLut lut, PackGeom g,
                                                                uint8_t* __restrict__ dna, uint8_t* __restrict__ qual,
@@ -242,29 +262,9 @@ __global__ __launch_bounds__(PK_THREADS) void pack_tile_kernel(const uint8_t* __
         }
         __syncthreads();
         if (ok) {
-            // ---- C: coalesced stores of the two packed tiles
-            {
-                const uint64_t nb = (uint64_t)Rt * g.Cd;
-                uint8_t* gdst = dna + r0 * g.Cd;
-                if ((((uintptr_t)gdst) & 15) == 0) {
-                    const uint32_t nv = (uint32_t)(nb >> 4);
-                    for (uint32_t i = tid; i < nv; i += PK_THREADS) ((uint4*)gdst)[i] = ((const uint4*)out_d)[i];
-                    for (uint32_t i = (nv << 4) + tid; i < nb; i += PK_THREADS) gdst[i] = out_d[i];
-                } else {
-                    for (uint32_t i = tid; i < nb; i += PK_THREADS) gdst[i] = out_d[i];
-                }
-            }
-            {
-                const uint64_t nb = (uint64_t)Rt * g.Cq;
-                uint8_t* gdst = qual + r0 * g.Cq;
-                if ((((uintptr_t)gdst) & 15) == 0) {
-                    const uint32_t nv = (uint32_t)(nb >> 4);
-                    for (uint32_t i = tid; i < nv; i += PK_THREADS) ((uint4*)gdst)[i] = ((const uint4*)out_q)[i];
-                    for (uint32_t i = (nv << 4) + tid; i < nb; i += PK_THREADS) gdst[i] = out_q[i];
-                } else {
-                    for (uint32_t i = tid; i < nb; i += PK_THREADS) gdst[i] = out_q[i];
-                }
-            }
+            // ---- C: coalesced stores of the two packed tiles (widest vector the tile's byte offset allows)
+            store_tile(dna + r0 * g.Cd, out_d, Rt * g.Cd, tid);
+            store_tile(qual + r0 * g.Cq, out_q, Rt * g.Cq, tid);
         }
     }
     if (badr != 0xFFFFFFFFu) atomicMin(bad, (unsigned long long)badr);
@@ -386,7 +386,12 @@ extern "C" int uq_pack(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line
     UQ_REQUIRE(rec + 64 <= stage_cap, "uq_pack: a %u-byte record does not fit one %u-byte tile", rec, stage_cap);
     uint32_t R = (stage_cap - 64) / rec;
     if (R > (PK_THREADS - 1) / 4) R = (PK_THREADS - 1) / 4;     // 4R + 1 line offsets, one per lane
-    if (R >= 16) R &= ~15u;            // keeps every tile's output offset 16-byte aligned
+    // R a multiple of 16 keeps every tile's output offset 16-byte aligned (uint4 stores); when that would waste
+    // more than ~15 % of the tile, settle for a multiple of 8 or 4 (8- / 4-byte stores)
+    if (R >= 4) {
+        const uint32_t r16 = R & ~15u, r8 = R & ~7u, r4 = R & ~3u;
+        if (r16 * 100 >= R * 85) R = r16; else if (r8 * 100 >= R * 85) R = r8; else R = r4;
+    }
     if (R == 0) R = 1;
     g.R = R;
     g.stage_bytes = stage_cap + 32;
