@@ -158,6 +158,20 @@ int uq_unpack(uq_ctx* ctx, const uint8_t* d_dna, const uint8_t* d_qual, uint64_t
               const uq_unpack_params* h_params, uint8_t* d_seq, uint8_t* d_qualtxt, uint32_t* d_len,
               uint64_t* d_bad /* smallest row with no sentinel (variable) or UQ_NONE */);
 
+/* ---- f1: the QNAME passes, native on the HOST (no GPU involved).  Replaces the per-line Python of
+ * uq.py:348-352, 394-444 (prefix / suffix / separator inference), 555-678 (column typing) and 717-736
+ * (column encoding) with the same sequential semantics.  h_buf / h_line_start are HOST copies of the
+ * FASTQ bytes and of the record index.  *h_status: 0 = done (*out valid); 1 = outside what the native
+ * code reproduces exactly (regex-special separators, integers beyond int64, separators out of order):
+ * use the Python implementation; 2 = the reference refuses this input too (uq_last_error() has its message).
+ * uq_qname_json: {"prefix","suffix","separators","columns":[...]} as config.json stores them (uq.py:692-695).
+ * uq_qname_column: column `col` as little-endian unsigned integers of the column's dtype, nreads entries. */
+typedef struct uq_qname uq_qname;
+int uq_qname_analyse(const uint8_t* h_buf, const uint64_t* h_line_start, uint64_t nreads, uq_qname** out, int* h_status);
+int uq_qname_json(const uq_qname* q, const char** h_json);
+int uq_qname_column(const uq_qname* q, int col, void* h_out, uint64_t capacity_bytes);
+int uq_qname_free(uq_qname* q);
+
 /* ---- synthetic FASTQ ("synth-v1"): workload generation for tests and bench.py.
  * Byte-identical to uq_amd/synth.py.  uq_synth_size: total bytes of reads [first, first+n).
  * uq_synth_fastq: writes them to d_out (capacity >= that size). */

@@ -84,6 +84,34 @@ def test_qname_passes_match_oracle():
         assert qname.decode_names(cfg, arrs) == names
 
 
+def test_qname_native_host_path_matches_python():
+    """uq_qname_analyse (C++ on the host, row f1) == uq_amd/qname.py == the oracle, statement for statement."""
+    import oracle_c
+    cases = [synth.fastq(5, 3000, 50), synth.fastq(6, 25000, 8), open(os.path.join(REPO, 'tests', 'golden', 'cfg1_10k_100bp.fastq'), 'rb').read(),
+             b''.join(b'@m%d#x:%d:%s#1\nA\n+\nI\n' % (i % 7, i % 300, b'ab' if i % 3 else b'c') for i in range(500)),
+             b''.join(b'@r %d/%d\nA\n+\nI\n' % (i * 7919 % 100000, i % 2 + 1) for i in range(30000)),
+             b''.join(b'@x:%d: %03d:%d\nA\n+\nI\n' % (i % 3, i % 500, i * 1000003 % 5000000000) for i in range(2500))]
+    for fq in cases:
+        host = np.frombuffer(fq, dtype=np.uint8)
+        ls = oracle_c.index_lines(host)
+        n = (len(ls) - 1) // 4
+        lines = O.read_lines(fq)
+        p1 = O.pass1(lines)
+        ocols = O.qname_columns(lines, p1['prefix'], p1['suffix'], p1['separators'])
+        oarr = O.qname_encode(lines, p1['prefix'], p1['suffix'], p1['separators'], ocols)
+        got = qname.analyse_native(host, ls, n)
+        assert got is not None
+        assert got[:3] == (p1['prefix'], p1['suffix'], p1['separators'])
+        assert got[3] == ocols
+        assert all(np.array_equal(a, b) and a.dtype == b.dtype for a, b in zip(got[4], oarr))
+    # regex-special separators are handed to the Python implementation, hopeless inputs are refused like the reference does
+    host = np.frombuffer(b'@a.1.x\nA\n+\nI\n@a.2.y\nA\n+\nI\n@a.3.z\nA\n+\nI\n', dtype=np.uint8)
+    assert qname.analyse_native(host, oracle_c.index_lines(host), 3) is None
+    host = np.frombuffer(b'@r1\nA\n+\nI\n@r2\nA\n+\nI\n', dtype=np.uint8)
+    with pytest.raises(qname.QnameError):
+        qname.analyse_native(host, oracle_c.index_lines(host), 2)
+
+
 def test_qname_without_separators_is_refused():
     with pytest.raises(qname.QnameError):
         qname.analyse(['@r1', '@r2', '@r3'])

@@ -75,6 +75,10 @@ SIGNATURES = {
     'uq_stack_columns': [_vp, _P(_vp), _P(_int), _int, _u64, _int, _vp],
     'uq_unstack_column': [_vp, _vp, _u64, _int, _int, _int, _int, _vp],
     'uq_unpack': [_vp, _vp, _vp, _u64, _P(UnpackParams), _vp, _vp, _vp, _vp],
+    'uq_qname_analyse': [_vp, _vp, _u64, _P(_vp), _P(_int)],
+    'uq_qname_json': [_vp, _P(C.c_char_p)],
+    'uq_qname_column': [_vp, _int, _vp, _u64],
+    'uq_qname_free': [_vp],
     'uq_synth_size': [_vp, _P(SynthSpec), _u64, _u64, _P(_u64)],
     'uq_synth_fastq': [_vp, _P(SynthSpec), _u64, _u64, _vp, _u64],
 }

@@ -176,6 +176,35 @@ def encode_columns(fields, columns):
     return out
 
 
+def analyse_native(host_bytes, line_start, nreads):
+    """The same passes through libuqhip.so's host-side C++ (uq_qname_analyse).  Returns the 5-tuple of
+    analyse(), or None when the native code asks for the Python implementation (status 1)."""
+    import ctypes as C
+    import json
+    from ._lib import call
+    buf = np.ascontiguousarray(host_bytes)
+    ls = np.ascontiguousarray(line_start, dtype=np.uint64)
+    q = C.c_void_p(); status = C.c_int()
+    call('uq_qname_analyse', buf.ctypes.data_as(C.c_void_p), ls.ctypes.data_as(C.c_void_p), int(nreads), C.byref(q), C.byref(status))
+    if status.value == 1:
+        return None
+    if status.value != 0:
+        from ._lib import load
+        raise QnameError(load().uq_last_error().decode('latin-1'))
+    try:
+        js = C.c_char_p()
+        call('uq_qname_json', q, C.byref(js))
+        meta = json.loads(js.value.decode('ascii'))
+        arrays = []
+        for i, c in enumerate(meta['columns']):
+            a = np.empty(nreads, dtype=np.dtype(c['dtype']))
+            call('uq_qname_column', q, i, a.ctypes.data_as(C.c_void_p), a.nbytes)
+            arrays.append(a)
+    finally:
+        call('uq_qname_free', q)
+    return meta['prefix'], meta['suffix'], meta['separators'], meta['columns'], arrays
+
+
 def analyse(names):
     """Passes 1 (QNAME part), 2 and 4 in one go -> (prefix, suffix, separators, columns, column arrays)."""
     prefix, suffix, separators = infer_layout(names)

@@ -149,9 +149,11 @@ class Session:
         first_seen = lambda: ops.first_occurrence(ctx, self.d_buf, self.d_ls, 0, self.total)
         d = analysis.decide_from_counts(hs.counts, hs.len_min, hs.len_max, notricks=args.notricks, pad=args.pad, first_seen=first_seen)
         self.d = d
-        names = qname.qname_lines(self.host, self.h_ls, self.total)
         try:
-            prefix, suffix, separators, columns, arrays = qname.analyse(names)
+            res = qname.analyse_native(self.host, self.h_ls, self.total)          # C++ host path
+            if res is None:                                                        # regex-special separators etc.: Python path
+                res = qname.analyse(qname.qname_lines(self.host, self.h_ls, self.total))
+            prefix, suffix, separators, columns, arrays = res
         except qname.QnameError as e:
             error(str(e))
         self.columns = columns
