@@ -113,6 +113,27 @@ def test_allreduce_stats(world):
         assert o['c'] == 3 and o['mins'] == [1001, -1] and o['lmin'] == 100 and o['lmax'] == 150 and o['rmax'] == 341
 
 
+def _stats_struct_job(rank, world):
+    import ctypes
+    from uq_amd._lib import Stats
+    s = Stats()
+    s.counts[65 * 256 + 73] = 10 * (rank + 1); s.counts[255 * 256 + 255] = 1
+    s.bad_plus = (1 << 64) - 1 if rank == 0 else 7
+    s.bad_len = (1 << 64) - 1
+    s.len_min = 0xFFFFFFFF if rank == 1 else 36; s.len_max = 100 + rank; s.max_record_bytes = 500 - rank
+    buf = torch.frombuffer(bytearray(bytes(s)), dtype=torch.uint8).clone()
+    uqdist.allreduce_stats_inplace(torch, buf, read_offset=1000 * rank)
+    out = Stats.from_buffer_copy(buf.numpy().tobytes())
+    return dict(c=int(out.counts[65 * 256 + 73]), c2=int(out.counts[255 * 256 + 255]), bp=int(out.bad_plus), bl=int(out.bad_len),
+                lmin=int(out.len_min), lmax=int(out.len_max), rmax=int(out.max_record_bytes))
+
+
+def test_allreduce_stats_struct():
+    outs = _run(2, _stats_struct_job)
+    for o in outs:
+        assert o == dict(c=30, c2=2, bp=1007, bl=(1 << 64) - 1, lmin=36, lmax=101, rmax=500)
+
+
 def test_shard_ranges_cover():
     for total in (0, 1, 7, 1000):
         for world in (1, 2, 3, 8):

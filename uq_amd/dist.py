@@ -49,24 +49,27 @@ def allreduce_stats_tensors(counts_i64, mins_u64_as_i64, len_min, len_max, rec_m
     len_max.copy_(mx[0]); rec_max.copy_(mx[1])
 
 
-def allreduce_stats(ctx, d_stats, read_offset=0):
-    """All-reduce a device `uq_stats` over the process group and fetch it.  `read_offset` = global index
-    of this rank's first read (so that bad-record indices are global)."""
-    from . import ops
-    t = ctx.torch
+def allreduce_stats_inplace(t, stats_bytes, read_offset=0):
+    """All-reduce the bytes of a `uq_stats` struct (a uint8 tensor on any device) over the process group,
+    in place.  `read_offset` = global index of this rank's first read (bad-record indices become global)."""
     nbytes = C.sizeof(Stats)
-    i64 = d_stats[:nbytes - nbytes % 8].view(t.int64)
+    i64 = stats_bytes[:nbytes - nbytes % 8].view(t.int64)
     counts = i64[:65536]
     mins = i64[65536:65538]
     if read_offset:
-        none = t.tensor(-1, dtype=t.int64, device=ctx.device)
-        mins.copy_(t.where(mins == none, mins, mins + read_offset))
-    tail = d_stats[65538 * 8:65538 * 8 + 16].view(t.int32)       # len_min, len_max, max_record_bytes, reserved
+        mins.copy_(t.where(mins == -1, mins, mins + int(read_offset)))
+    tail = stats_bytes[65538 * 8:65538 * 8 + 16].view(t.int32)   # len_min, len_max, max_record_bytes, reserved
     lmin = tail[0:1].to(t.int64) & 0xFFFFFFFF
     lmax = tail[1:2].to(t.int64)
     rmax = tail[2:3].to(t.int64)
     allreduce_stats_tensors(counts, mins, lmin, lmax, rmax)
     tail[0:1].copy_(lmin.to(t.int32)); tail[1:2].copy_(lmax.to(t.int32)); tail[2:3].copy_(rmax.to(t.int32))
+
+
+def allreduce_stats(ctx, d_stats, read_offset=0):
+    """All-reduce a device `uq_stats` over the process group and fetch it."""
+    from . import ops
+    allreduce_stats_inplace(ctx.torch, d_stats, read_offset)
     return ops.stats_fetch(ctx, d_stats)
 
 
