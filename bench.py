@@ -124,10 +124,8 @@ def main():
 
     def step(timed):
         nlines = ops.count_lines(ctx, d_buf)
-        ls = ops.index_lines(ctx, d_buf, nlines)
         nreads = nlines // 4
-        st = ops.stats_new(ctx)
-        ops.stats_accumulate(ctx, st, d_buf, ls, 0, nreads)
+        ls, st = ops.index_and_stats(ctx, d_buf, nlines)      # record index, then pass-1 statistics
         if world > 1:
             from uq_amd import dist as uqdist
             hs = uqdist.allreduce_stats(ctx, st)

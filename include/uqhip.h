@@ -70,6 +70,14 @@ typedef struct uq_stats {
 int uq_stats_init(uq_ctx* ctx, uq_stats* d_stats);
 int uq_stats_accumulate(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start,
                         uint64_t first_read, uint64_t nreads, uq_stats* d_stats);
+/* Record index AND pass-1 statistics in one pass over the stream (reads the FASTQ once instead of twice):
+ * equivalent to uq_index_lines(...) followed by uq_stats_accumulate(..., 0, nlines / 4, ...).  Needs
+ * nlines % 4 == 0 (from uq_count_lines on the same buffer).  *h_fused = 1 when done; 0 when the input
+ * is outside what the fused kernel handles (nlines % 4 != 0, or a 16 KiB tile holding more than 2048
+ * newlines): d_line_start / d_stats are then unspecified and the caller runs the two calls above
+ * (after uq_stats_init). */
+int uq_index_stats(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint64_t nlines, uint64_t* d_line_start,
+                   uq_stats* d_stats, int* h_fused);
 /* First occurrence of each base byte: d_first[b] = min over pairs of (read_index << 20 | position),
  * or UQ_NONE.  Only needed to order N-trick candidates as the reference's dict does (uq.py:480). */
 int uq_first_occurrence(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start,

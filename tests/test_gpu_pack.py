@@ -111,6 +111,51 @@ def test_stats_unusual_bytes_and_bad_records(ctx):
     assert np.array_equal(hs2.counts, ref['counts']) and hs2.bad_plus == 1 and hs2.bad_len == 2
 
 
+def _check_fused(ctx, host, misalign=0):
+    t = ctx.torch
+    backing = ctx.empty(host.size + 64)
+    d_buf = backing[misalign:misalign + host.size]
+    d_buf.copy_(t.from_numpy(host))
+    nlines = ops.count_lines(ctx, d_buf)
+    hls = oracle_c.index_lines(host)
+    assert nlines == len(hls) - 1
+    ls, st = ops.index_and_stats(ctx, d_buf, nlines, fused=True)
+    assert np.array_equal(ctx.to_numpy(ls, np.uint64), hls)
+    hs = ops.stats_fetch(ctx, st)
+    n = nlines // 4
+    ref = oracle_c.stats(host, hls, 0, n)
+    assert np.array_equal(hs.counts, ref['counts'])
+    assert (hs.len_min, hs.len_max, hs.max_record_bytes) == (ref['len_min'], ref['len_max'], ref['max_record_bytes'])
+    assert (hs.bad_plus, hs.bad_len) == (ref['bad_plus'], ref['bad_len'])
+
+
+@pytest.mark.parametrize('n,length,kw,mis', [
+    (1, 5, {}, 0), (3, 7, {}, 3), (20000, 100, {}, 0), (30000, 150, {}, 9), (9000, (36, 301), dict(n_rate=1), 15),
+    (4000, (1, 9), {}, 1), (700, 50, dict(n_rate=3, n_qual_exclusive=False), 0),
+])
+def test_fused_index_stats(ctx, n, length, kw, mis):
+    _check_fused(ctx, synth.fastq_array(synth.Spec(S + 7, length, **kw), n), mis)
+
+
+def test_fused_index_stats_hard_inputs(ctx):
+    rng = np.random.RandomState(3)
+    # reads far longer than the 4 KiB halo (counted from HBM), mixed with short ones
+    recs = []
+    for i in range(60):
+        L = int(rng.choice([5, 3000, 9000, 40, 17000]))
+        seq = ''.join('ACGTN'[k] for k in rng.randint(0, 5, L)); q = ''.join(chr(33 + k) for k in rng.randint(0, 41, L))
+        recs.append('@long:%d:%d\n%s\n+\n%s\n' % (i % 3, i, seq, q))
+    _check_fused(ctx, np.frombuffer(''.join(recs).encode(), dtype=np.uint8).copy(), 5)
+    # unusual bytes (outside both LDS windows), a bad '+' line and a length mismatch
+    recs = [b'@r:1:1\nACGTZ\x80\xff\n+\n!~\x01\x02\xfe\xff\x7f\n', b'@r:2:2\nAC\n-\nII\n', b'@r:3:3\nACG\n+\nII\n', b'@r:4:4\nA\n+\nI\n'] * 300
+    _check_fused(ctx, np.frombuffer(b''.join(recs), dtype=np.uint8).copy())
+    # thousands of one-byte lines per tile: the fused kernel declines, the wrapper falls back to two passes
+    _check_fused(ctx, np.frombuffer(b'@\nA\n+\nI\n' * 20000, dtype=np.uint8).copy(), 2)
+    # Phred+64 style qualities (window moves) and lower-case bases
+    recs = [('@p:%d\n%s\n+\n%s\n' % (i, 'acgtn' * 8, ''.join(chr(64 + (i + k) % 41) for k in range(40)))).encode() for i in range(3000)]
+    _check_fused(ctx, np.frombuffer(b''.join(recs), dtype=np.uint8).copy(), 11)
+
+
 PACK_CASES = [
     ('fixed100', 3000, 100, {}, {}),
     ('fixed150', 4096 + 37, 150, {}, {}),

@@ -123,6 +123,17 @@ int run_count(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint64_t* nblo
 }
 }  // namespace
 
+// For fused.hip: make sure ctx->idx_partials holds the exclusive scan of the per-tile newline counts
+// of this buffer (reusing the census of uq_count_lines when `have_scanned`).
+int uq_index_run_census(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint64_t* nblocks_out, bool have_scanned) {
+    const uint32_t mis = (uint32_t)((uintptr_t)d_buf & 15);
+    const uint64_t nvec = (nbytes + mis + 15) / 16;
+    if (have_scanned) { *nblocks_out = (nvec * 16 + IDX_TILE - 1) / IDX_TILE; return 0; }
+    UQ_TRY(run_count(ctx, d_buf, nbytes, nblocks_out));
+    UQ_TRY(uq_scan_exclusive_u32(ctx, ctx->idx_partials, ctx->idx_partials, *nblocks_out, nullptr));
+    return 0;
+}
+
 extern "C" int uq_count_lines(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint64_t* h_nlines) {
     UQ_REQUIRE(ctx && h_nlines, "uq_count_lines: null argument");
     ctx->idx_buf = nullptr;

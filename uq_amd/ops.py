@@ -51,6 +51,25 @@ def stats_accumulate(ctx, d_stats, buf, line_start, first_read, nreads):
     call('uq_stats_accumulate', ctx.h, _p(buf), _p(line_start), first_read, nreads, _p(d_stats))
 
 
+def index_and_stats(ctx, buf, nlines, fused=False):
+    """Record index + pass-1 statistics of the whole buffer.  Returns (line_start tensor, device uq_stats).
+    fused=True uses the one-pass kernel (uq_index_stats: one HBM read less; on MI355X it is currently
+    VALU-bound and no faster than the two kernels, so it is not the default) and falls back to the
+    two-pass form when that kernel declines the input."""
+    t = ctx.torch
+    ls = t.empty(nlines + 1, dtype=t.int64, device=ctx.device)
+    st = stats_new(ctx)
+    done = C.c_int(0)
+    if fused:
+        call('uq_index_stats', ctx.h, _p(buf), buf.numel(), nlines, _p(ls), _p(st), C.byref(done))
+    if not done.value:
+        call('uq_index_lines', ctx.h, _p(buf), buf.numel(), nlines, _p(ls))
+        call('uq_stats_init', ctx.h, _p(st))
+        if nlines >= 4:
+            call('uq_stats_accumulate', ctx.h, _p(buf), _p(ls), 0, nlines // 4, _p(st))
+    return ls, st
+
+
 def stats_fetch(ctx, d_stats):
     s = Stats()
     call('uq_d2h', ctx.h, C.byref(s), _p(d_stats), C.sizeof(Stats))

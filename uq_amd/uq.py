@@ -130,16 +130,14 @@ class Session:
             error('ERROR: The FASTQ file provided contains' + str(nlines) + 'rows, which is not divisible by 4!')
         if nlines == 0: error('ERROR: empty input')
         self.total = nlines // 4
-        self.d_ls = ops.index_lines(ctx, self.d_buf, nlines)
+        self.d_ls, self.d_stats = ops.index_and_stats(ctx, self.d_buf, nlines)   # record index + pass-1 statistics
         self.h_ls = ctx.to_numpy(self.d_ls, np.uint64)
 
     def analyse(self):
         """Pass 1 (histogram, lengths, QNAME layout), the N-trick / width decisions, pass 2 (QNAME typing)."""
         from . import analysis, qname
         ops, ctx, args = self.ops, self.ctx, self.args
-        st = ops.stats_new(ctx)
-        ops.stats_accumulate(ctx, st, self.d_buf, self.d_ls, 0, self.total)
-        hs = ops.stats_fetch(ctx, st)
+        hs = ops.stats_fetch(ctx, self.d_stats)
         if self.host[0] != ord('@'): error('ERROR: This does not look like a FASTA/FASTQ file! (first line does not start with @)')
         if hs.bad_plus is not None:
             error('ERROR: For entry' + str(hs.bad_plus) + 'the third line does not start with +')
