@@ -88,6 +88,7 @@ def main():
     ap.add_argument('--reads', type=int, default=10_000_000, help='reads per GPU (default: BASELINE configs[1])')
     ap.add_argument('--length', type=int, default=150)
     ap.add_argument('--cpu-sample', type=int, default=100_000, help='reads timed on the host for cpu_baseline (0 = skip)')
+    ap.add_argument('--force-dist', action='store_true', help='initialise the process group and run the collectives even with one rank')
     ap.add_argument('--workload', default='cfg2', choices=['cfg2', 'cfg5-notricks', 'cfg5-ntrick'],
                     help='cfg2 = BASELINE configs[1] (the bench line the driver reads); cfg5-* = configs[4]: variable length 36-301 bp '
                          'with 1%% N, 3-bit ACGNT path (--notricks) or 2-bit N-trick path -- parity/measurement extras')
@@ -101,11 +102,13 @@ def main():
 
     import torch
     import torch.distributed as dist
+    use_dist = world > 1 or args.force_dist          # --force-dist: exercise the RCCL path with a single rank
     from uq_amd import ops, synth
     from uq_amd.device import Context
 
-    if world > 1:
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
     ctx = Context(local_rank)
 
@@ -126,7 +129,7 @@ def main():
         nlines = ops.count_lines(ctx, d_buf)
         nreads = nlines // 4
         ls, st = ops.index_and_stats(ctx, d_buf, nlines)      # record index, then pass-1 statistics
-        if world > 1:
+        if use_dist:
             from uq_amd import dist as uqdist
             hs = uqdist.allreduce_stats(ctx, st)
         else:
@@ -148,7 +151,7 @@ def main():
         step(False)
 
     def fence():
-        if world > 1: dist.barrier()
+        if use_dist: dist.barrier()
         torch.cuda.synchronize()
 
     fence()
@@ -157,7 +160,7 @@ def main():
         step(True)
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=ctx.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -213,7 +216,7 @@ def main():
         result['cpu_baseline'] = cb
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -128,6 +128,41 @@ def test_cli_test_mode_without_compressor(ctx, tmp_path):
     assert _run_decode(ctx, path) == fq
 
 
+def test_cli_test_mode_with_compressor(ctx, tmp_path):
+    """--test --compressor: the 8-layout sweep per table and the (raw set x sort) grid run on the device
+    kernels; whatever wins must still decode to the input (as a multiset when a sort won)."""
+    import shutil
+    if shutil.which('gzip') is None: pytest.skip('no gzip')
+    fq = synth.fastq(20261003 + 32, 600, 36, dup='both', dup_templates=8)
+    cfg, members, names, path = _run_encode(ctx, tmp_path, fq, ['--test', '--compressor', 'gzip -1', '--raw', 'DNA', 'QNAME'])
+    assert cfg['pattern'][0] in uq.PATTERNS and cfg['pattern'][1] in uq.PATTERNS
+    text = _run_decode(ctx, path)
+    assert sorted(_records(text)) == sorted(_records(fq))
+    # and the oracle builds the same members for the mix the sweep chose
+    ocfg, omembers, _ = O.encode(fq, sort=cfg['sort'] if isinstance(cfg['sort'], str) else None, raw=[r for r in cfg['raw'] if r], pattern=cfg['pattern'])
+    assert set(members) == set(omembers) and all(members[k] == omembers[k] for k in omembers)
+
+
+def test_cli_edge_inputs(ctx, tmp_path):
+    # one record; two records with the minimum of structure; a file without the final newline (Q21: refused)
+    for fq in (b'@a:1:7\nACGTN\n+\nIHIH#\n@a:2:9\nACGTA\n+\nHIHII\n', b'@q:1:5\nA\n+\nI\n@q:2:6\nA\n+\nH\n'):
+        cfg, members, names, path = _run_encode(ctx, tmp_path, fq, ['--raw', 'DNA', 'QUAL', 'QNAME'])
+        ocfg, omembers, _ = O.encode(fq, raw=['DNA', 'QUAL', 'QNAME'])
+        assert all(members[k] == omembers[k] for k in omembers)
+        assert _run_decode(ctx, path) == fq
+    p = tmp_path / 'nonl.fastq'
+    p.write_bytes(b'@q:1:5\nA\n+\nI\n@q:2:6\nC\n+\nI')
+    with pytest.raises(uq.UqError):
+        uq.Session(uq.validate_args(uq.build_parser().parse_args(['-i', str(p), '--quiet'])), ctx=ctx).encode()
+    # a read longer than one LDS tile is refused with a clear message, not a fault
+    L = 30000
+    p.write_bytes(b'@q:1:5\n' + b'A' * L + b'\n+\n' + b'I' * L + b'\n@q:2:6\n' + b'C' * L + b'\n+\n' + b'H' * L + b'\n')
+    from uq_amd._lib import UqHipError
+    with pytest.raises((uq.UqError, UqHipError)) as e:
+        uq.Session(uq.validate_args(uq.build_parser().parse_args(['-i', str(p), '--quiet'])), ctx=ctx).encode()
+    assert 'tile' in str(e.value)
+
+
 def test_cli_errors(ctx, tmp_path):
     p = tmp_path / 'bad.fastq'
     p.write_bytes(b'@a:1\nACGT\n+\nIIII\n@a:2\nAC\n+\nIII\n')

@@ -32,21 +32,19 @@ def shard_range(total, rank, world):
 
 
 def allreduce_stats_tensors(counts_i64, mins_u64_as_i64, len_min, len_max, rec_max, dist=None):
-    """All-reduce the pieces of uq_stats.  `counts_i64`: SUM.  `mins_u64_as_i64`: unsigned MIN (done as
-    a signed MIN after flipping the sign bit, which preserves unsigned order).  Scalars: MIN / MAX."""
+    """All-reduce the pieces of uq_stats with TWO collectives: SUM over the 512 KiB count table, and one
+    MAX over five scalars.  The minima ride in the MAX as bitwise complements (MIN(x) = ~MAX(~x));
+    `mins_u64_as_i64` are unsigned, so their sign bit is flipped first (signed order == unsigned order)."""
     import torch
     if dist is None:
         dist, _, _ = _world()
     if dist is None:
         return
     dist.all_reduce(counts_i64, op=dist.ReduceOp.SUM)
-    mins_u64_as_i64 ^= _SIGN
-    dist.all_reduce(mins_u64_as_i64, op=dist.ReduceOp.MIN)
-    mins_u64_as_i64 ^= _SIGN
-    dist.all_reduce(len_min, op=dist.ReduceOp.MIN)
-    mx = torch.stack([len_max.reshape(()), rec_max.reshape(())])
-    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-    len_max.copy_(mx[0]); rec_max.copy_(mx[1])
+    pack = torch.cat([~(mins_u64_as_i64 ^ _SIGN), ~len_min.reshape(1), len_max.reshape(1), rec_max.reshape(1)])
+    dist.all_reduce(pack, op=dist.ReduceOp.MAX)
+    mins_u64_as_i64.copy_((~pack[0:2]) ^ _SIGN)
+    len_min.copy_(~pack[2:3]); len_max.copy_(pack[3:4]); rec_max.copy_(pack[4:5])
 
 
 def allreduce_stats_inplace(t, stats_bytes, read_offset=0):
