@@ -180,6 +180,27 @@ int uq_qname_json(const uq_qname* q, const char** h_json);
 int uq_qname_column(const uq_qname* q, int col, void* h_out, uint64_t capacity_bytes);
 int uq_qname_free(uq_qname* q);
 
+/* ---- f3: FASTQ text assembled on the device.  Replaces the decoder's exec-compiled convert_qname
+ * (uq.py:1010-1026) and its four prints per read (uq.py:1042-1045).  Inputs: the fixed-pitch text and
+ * lengths uq_unpack produced, and the QNAME columns (device arrays, one value per read, little-endian
+ * unsigned of itemsize[c] bytes).  Integer columns print str(value + add[c]) (add = 'min' when the
+ * column has an offset); mapping columns copy string number `value` of a flattened table
+ * (h_d_map_chars[c], h_d_map_offs[c][nmap + 1]; both NULL for integer columns).
+ * Record = prefix + fields joined by separators[c] + suffix '\n' SEQ '\n' '+' '\n' QUAL '\n'.
+ * d_offsets: uint64[nreads + 1] workspace (record offsets on return).  With d_out == NULL only the total
+ * size is computed (*h_total). */
+typedef struct uq_emit_params {
+    uint8_t prefix[256];
+    uint8_t suffix[256];
+    uint8_t separators[32];
+    int32_t prefix_len, suffix_len, ncols, dna_max;
+    int32_t itemsize[32];
+    int64_t add[32];
+} uq_emit_params;
+int uq_emit_fastq(uq_ctx* ctx, const uq_emit_params* h_params, const void* const* h_d_cols, const uint8_t* const* h_d_map_chars,
+                  const uint32_t* const* h_d_map_offs, const uint8_t* d_seq, const uint8_t* d_qual, const uint32_t* d_len,
+                  uint64_t nreads, uint64_t* d_offsets, uint8_t* d_out, uint64_t capacity, uint64_t* h_total);
+
 /* ---- synthetic FASTQ ("synth-v1"): workload generation for tests and bench.py.
  * Byte-identical to uq_amd/synth.py.  uq_synth_size: total bytes of reads [first, first+n).
  * uq_synth_fastq: writes them to d_out (capacity >= that size). */

@@ -163,6 +163,28 @@ def test_cli_edge_inputs(ctx, tmp_path):
     assert 'tile' in str(e.value)
 
 
+def test_device_text_emit_matches_oracle_decode(ctx, tmp_path):
+    """uq_emit_fastq: mapping columns (string table), integer columns with and without offset, negative
+    numbers, a suffix, variable lengths -- the decoded text equals the oracle's decode and the input."""
+    import random
+    rnd = random.Random(11)
+    recs = []
+    for i in range(3000):
+        L = rnd.randint(5, 60)
+        seq = ''.join(rnd.choice('ACGT') for _ in range(L)); q = ''.join(rnd.choice('#5AI') for _ in range(L))
+        recs.append('@run7 %s:%d:%d:%d/%s\n%s\n+\n%s\n' % (rnd.choice(['ab', 'c', 'Zed']), 70000 + i * 3, rnd.randint(-50, 50), i % 7, 'x1', seq, q))
+    fq = ''.join(recs).encode()
+    for flags in (['--raw', 'DNA', 'QUAL', 'QNAME'], ['--sort', 'None']):
+        cfg, members, names, path = _run_encode(ctx, tmp_path, fq, flags)
+        kinds = [(c['format'], c.get('offset')) for c in cfg['QNAME_columns']]
+        assert ('mapping', None) in kinds and ('integers', True) in kinds and ('integers', False) in kinds
+        ocfg, omembers, _ = O.encode(fq, raw=[f for f in flags[1:] if f not in ('None',)] if flags[0] == '--raw' else None)
+        assert all(members[k] == omembers[k] for k in omembers)
+        text = _run_decode(ctx, path)
+        assert text.decode('latin-1') == O.decode(ocfg, omembers)
+        assert text == fq
+
+
 def test_cli_errors(ctx, tmp_path):
     p = tmp_path / 'bad.fastq'
     p.write_bytes(b'@a:1\nACGT\n+\nIIII\n@a:2\nAC\n+\nIII\n')

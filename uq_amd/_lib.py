@@ -34,6 +34,12 @@ class UnpackParams(C.Structure):
                 ('dna_bytes_per_row', C.c_int32), ('quality_bytes_per_row', C.c_int32), ('dna_max', C.c_int32)]
 
 
+class EmitParams(C.Structure):
+    _fields_ = [('prefix', C.c_uint8 * 256), ('suffix', C.c_uint8 * 256), ('separators', C.c_uint8 * 32),
+                ('prefix_len', C.c_int32), ('suffix_len', C.c_int32), ('ncols', C.c_int32), ('dna_max', C.c_int32),
+                ('itemsize', C.c_int32 * 32), ('add', C.c_int64 * 32)]
+
+
 class SynthSpec(C.Structure):
     _fields_ = [('seed', C.c_uint64), ('len_lo', C.c_int32), ('len_hi', C.c_int32), ('n_rate', C.c_int32),
                 ('n_qual_exclusive', C.c_int32), ('dup', C.c_int32), ('dup_templates', C.c_int32),
@@ -80,6 +86,7 @@ SIGNATURES = {
     'uq_qname_json': [_vp, _P(C.c_char_p)],
     'uq_qname_column': [_vp, _int, _vp, _u64],
     'uq_qname_free': [_vp],
+    'uq_emit_fastq': [_vp, _P(EmitParams), _P(_vp), _P(_vp), _P(_vp), _vp, _vp, _vp, _u64, _vp, _vp, _u64, _P(_u64)],
     'uq_synth_size': [_vp, _P(SynthSpec), _u64, _u64, _P(_u64)],
     'uq_synth_fastq': [_vp, _P(SynthSpec), _u64, _u64, _vp, _u64],
 }

@@ -227,6 +227,45 @@ def unpack(ctx, dna, qual, nreads, params):
     return seq, qtxt, ln, bad
 
 
+# ------------------------------------------------------------------ FASTQ text emit (decode)
+def emit_fastq(ctx, config, column_tensors, seq, qual, ln, nreads):
+    """Device-side FASTQ text: returns a uint8 tensor with the whole decoded file.
+    `column_tensors`: one device tensor per QNAME column (values per read, the column's dtype)."""
+    from ._lib import EmitParams
+    t = ctx.torch
+    cols = config['QNAME_columns']
+    if len(cols) > 32: raise ValueError('more than 32 QNAME columns')
+    p = EmitParams()
+    pre = config['QNAME_prefix'].encode('latin-1'); suf = config['QNAME_suffix'].encode('latin-1')
+    seps = config['QNAME_separators'].encode('latin-1')
+    if len(pre) > 256 or len(suf) > 256: raise ValueError('QNAME prefix / suffix longer than 256 bytes')
+    for i, b in enumerate(pre): p.prefix[i] = b
+    for i, b in enumerate(suf): p.suffix[i] = b
+    for i, b in enumerate(seps[:32]): p.separators[i] = b
+    p.prefix_len = len(pre); p.suffix_len = len(suf); p.ncols = len(cols); p.dna_max = config['dna_max']
+    keep = []
+    d_cols = (C.c_void_p * 32)(); d_chars = (C.c_void_p * 32)(); d_offs = (C.c_void_p * 32)()
+    for i, c in enumerate(cols):
+        p.itemsize[i] = column_tensors[i].element_size()
+        p.add[i] = int(c['min']) if (c['format'] != 'mapping' and c.get('offset')) else 0
+        d_cols[i] = column_tensors[i].data_ptr()
+        if c['format'] == 'mapping':
+            strs = [s.encode('latin-1') for s in c['map']]
+            offs = np.zeros(len(strs) + 1, dtype=np.uint32)
+            offs[1:] = np.cumsum([len(s) for s in strs])
+            chars = ctx.to_device(np.frombuffer(b''.join(strs) + b'\0', dtype=np.uint8))
+            offt = ctx.to_device(offs)
+            keep += [chars, offt]
+            d_chars[i] = chars.data_ptr(); d_offs[i] = offt.data_ptr()
+    offsets = t.empty(nreads + 1, dtype=t.int64, device=ctx.device)
+    total = C.c_uint64()
+    call('uq_emit_fastq', ctx.h, C.byref(p), d_cols, d_chars, d_offs, _p(seq), _p(qual), _p(ln), nreads, _p(offsets), None, 0, C.byref(total))
+    out = t.empty(total.value, dtype=t.uint8, device=ctx.device)
+    call('uq_emit_fastq', ctx.h, C.byref(p), d_cols, d_chars, d_offs, _p(seq), _p(qual), _p(ln), nreads, _p(offsets), _p(out), total.value, C.byref(total))
+    del keep
+    return out
+
+
 # ------------------------------------------------------------------ synthetic input
 def synth_spec(spec):
     """uq_amd.synth.Spec -> C struct."""

@@ -498,13 +498,20 @@ class Session:
         else:
             cols = [self.load_from_tar(members, 'QNAME_%d.raw' % (i + 1)) for i in range(ncols)]
         seq, qt, ln = self.split_bits(DNA, QUAL, config)
-        n, dmax = DNA[1], config['dna_max']
-        S = ctx.to_numpy(seq).reshape(n, dmax); Q = ctx.to_numpy(qt).reshape(n, dmax); L = ctx.to_numpy(ln, np.uint32)
-        names = qname.decode_names(config, cols)
+        n = DNA[1]
         w = out.buffer if hasattr(out, 'buffer') else out
-        for r in range(n):
-            l = int(L[r])
-            w.write(names[r].encode('latin-1') + b'\n' + S[r, :l].tobytes() + b'\n+\n' + Q[r, :l].tobytes() + b'\n')
+        if len(config['QNAME_columns']) <= 32 and len(config['QNAME_prefix']) <= 256 and len(config['QNAME_suffix']) <= 256:
+            # the text is assembled on the device (uq_emit_fastq) and leaves as one buffer
+            d_cols = [ctx.to_device(np.ascontiguousarray(c)) for c in cols]
+            text = ops.emit_fastq(ctx, config, d_cols, seq, qt, ln, n)
+            w.write(ctx.to_numpy(text).tobytes())
+        else:
+            dmax = config['dna_max']
+            S = ctx.to_numpy(seq).reshape(n, dmax); Q = ctx.to_numpy(qt).reshape(n, dmax); L = ctx.to_numpy(ln, np.uint32)
+            names = qname.decode_names(config, cols)
+            for r in range(n):
+                l = int(L[r])
+                w.write(names[r].encode('latin-1') + b'\n' + S[r, :l].tobytes() + b'\n+\n' + Q[r, :l].tobytes() + b'\n')
 
 
 def main(argv=None):
