@@ -180,6 +180,51 @@ int uq_qname_json(const uq_qname* q, const char** h_json);
 int uq_qname_column(const uq_qname* q, int col, void* h_out, uint64_t capacity_bytes);
 int uq_qname_free(uq_qname* q);
 
+/* ---- f1 on the DEVICE: the same passes as reductions + one tokenising kernel over the FASTQ already in HBM.
+ * uq_qname_layout (uq.py:348-352, 394-413): per character c of the first QNAME (candidate slot k, ch[k]):
+ *   entry[k]    = first record whose common prefix with line 1 is <= the last position of c in line 1
+ *                 (the record at which the reference's shrinking prefix sheds a c and starts counting it; UQ_NONE = never)
+ *   lastviol[k] = last record whose count of c differs from line 1's (0 = none)
+ *   c survives the reference's loop  <=>  entry[k] != UQ_NONE and lastviol[k] < entry[k].
+ *   min_lcp / min_lcs = lengths of the common prefix / suffix.  flags bit0: some QNAME is a proper prefix or
+ *   suffix of line 1 (the reference may raise IndexError there), bit1: a QNAME longer than 255 bytes -- in
+ *   both cases use uq_qname_analyse.
+ * uq_qname_tokenise (uq.py:555-565, 717-736): splits QNAME[prefix_len : len - suffix_len] of every read at the
+ *   ordered separators and writes, per column c, h_d_vals[c][read] = int(field) (0 if not an integer) and
+ *   h_d_strs[c][read] = the field as 8 bytes in text order, zero padded (fields longer than 8 bytes that are
+ *   canonical non-negative integers: 0x80 | value, big-endian).  Reductions per column: first_nonint (UQ_NONE if
+ *   every field is [+-]digits), vmin / vmax over the integer fields, any_long bit0 = a field that does not fit
+ *   the 8-byte key (long and not a canonical integer, or holding NUL / non-ASCII), bit1 = long canonical integer
+ *   seen.  flags: bit0 separators missing / out of order / extra, bit1 whitespace inside a field (Python's int()
+ *   strips it), bit2 more than 18 digits, bit3 QNAME shorter than prefix + suffix -- any flag: use uq_qname_analyse.
+ * uq_prefix_distinct (uq.py:609-625, the `len(map) > entries_read / 10` checkpoints): from a STABLE argsort
+ *   (d_perm) and the group ids in sorted order (d_sorted_key; both from uq_unique_rows), the number of distinct
+ *   rows among rows [0, T] for each threshold T.
+ * uq_encode_int (uq.py:724-733): d_out[i] = (unsigned itemsize)(d_val[i] - sub). */
+typedef struct uq_qname_layout_result {
+    uint32_t min_lcp, min_lcs;
+    uint32_t flags;
+    uint32_t nch;
+    uint64_t entry[64];
+    uint64_t lastviol[64];
+    uint8_t ch[64];
+} uq_qname_layout_result;
+typedef struct uq_qname_cols_result {
+    uint64_t first_nonint[32];
+    int64_t vmin[32], vmax[32];
+    uint32_t any_long[32];
+    uint32_t flags;
+    uint32_t reserved;
+} uq_qname_cols_result;
+int uq_qname_layout(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start, uint64_t nreads,
+                    const uint8_t* h_line1, uint32_t line1_len, uq_qname_layout_result* h_out);
+int uq_qname_tokenise(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start, uint64_t nreads, uint32_t prefix_len,
+                      uint32_t suffix_len, const uint8_t* h_separators, uint32_t nsep, int64_t* const* h_d_vals,
+                      uint64_t* const* h_d_strs, uq_qname_cols_result* h_out);
+int uq_prefix_distinct(uq_ctx* ctx, const uint32_t* d_perm, const uint32_t* d_sorted_key, uint64_t n,
+                       const uint64_t* h_thresholds, int nthresholds, uint64_t* h_counts);
+int uq_encode_int(uq_ctx* ctx, const int64_t* d_val, uint64_t n, int64_t sub, int itemsize, void* d_out);
+
 /* ---- f3: FASTQ text assembled on the device.  Replaces the decoder's exec-compiled convert_qname
  * (uq.py:1010-1026) and its four prints per read (uq.py:1042-1045).  Inputs: the fixed-pitch text and
  * lengths uq_unpack produced, and the QNAME columns (device arrays, one value per read, little-endian

@@ -60,7 +60,7 @@ def main():
         enc = time.perf_counter() - t0
         res = {'op': 'cli_encode', 'reads': args.reads, 'fastq_MB': round(nbytes / 1e6, 1), 'flags': args.flags, 'seconds': round(enc, 3),
                'MBps': round(nbytes / 1e6 / enc, 1), 'reads_per_s': round(args.reads / enc), 'stages_s': stages,
-               'uq_MB': round(os.path.getsize(out) / 1e6, 1)}
+               'uq_MB': round(os.path.getsize(out) / 1e6, 1), 'qname_path': s.qname_path}
         print(json.dumps(res), flush=True)
         if args.decode:
             a2 = uq.validate_args(uq.build_parser().parse_args(['-i', out, '--decode', '--quiet']))

@@ -40,6 +40,16 @@ class EmitParams(C.Structure):
                 ('itemsize', C.c_int32 * 32), ('add', C.c_int64 * 32)]
 
 
+class QnameLayoutResult(C.Structure):
+    _fields_ = [('min_lcp', C.c_uint32), ('min_lcs', C.c_uint32), ('flags', C.c_uint32), ('nch', C.c_uint32),
+                ('entry', C.c_uint64 * 64), ('lastviol', C.c_uint64 * 64), ('ch', C.c_uint8 * 64)]
+
+
+class QnameColsResult(C.Structure):
+    _fields_ = [('first_nonint', C.c_uint64 * 32), ('vmin', C.c_int64 * 32), ('vmax', C.c_int64 * 32),
+                ('any_long', C.c_uint32 * 32), ('flags', C.c_uint32), ('reserved', C.c_uint32)]
+
+
 class SynthSpec(C.Structure):
     _fields_ = [('seed', C.c_uint64), ('len_lo', C.c_int32), ('len_hi', C.c_int32), ('n_rate', C.c_int32),
                 ('n_qual_exclusive', C.c_int32), ('dup', C.c_int32), ('dup_templates', C.c_int32),
@@ -86,6 +96,10 @@ SIGNATURES = {
     'uq_qname_json': [_vp, _P(C.c_char_p)],
     'uq_qname_column': [_vp, _int, _vp, _u64],
     'uq_qname_free': [_vp],
+    'uq_qname_layout': [_vp, _vp, _vp, _u64, _vp, _u32, _P(QnameLayoutResult)],
+    'uq_qname_tokenise': [_vp, _vp, _vp, _u64, _u32, _u32, _vp, _u32, _P(_vp), _P(_vp), _P(QnameColsResult)],
+    'uq_prefix_distinct': [_vp, _vp, _vp, _u64, _P(_u64), _int, _P(_u64)],
+    'uq_encode_int': [_vp, _vp, _u64, C.c_int64, _int, _vp],
     'uq_emit_fastq': [_vp, _P(EmitParams), _P(_vp), _P(_vp), _P(_vp), _vp, _vp, _vp, _u64, _vp, _vp, _u64, _P(_u64)],
     'uq_synth_size': [_vp, _P(SynthSpec), _u64, _u64, _P(_u64)],
     'uq_synth_fastq': [_vp, _P(SynthSpec), _u64, _u64, _vp, _u64],

@@ -199,6 +199,45 @@ def unstack_column(ctx, rows, n, ncols, common_itemsize, col, out_itemsize):
     return out
 
 
+# ------------------------------------------------------------------ QNAME passes on the device
+def qname_layout(ctx, buf, line_start, nreads, line1):
+    """`line1`: bytes of the first QNAME line.  Returns the QnameLayoutResult structure."""
+    from ._lib import QnameLayoutResult
+    res = QnameLayoutResult()
+    l1 = (C.c_uint8 * len(line1)).from_buffer_copy(line1)
+    call('uq_qname_layout', ctx.h, _p(buf), _p(line_start), nreads, l1, len(line1), C.byref(res))
+    return res
+
+
+def qname_tokenise(ctx, buf, line_start, nreads, prefix_len, suffix_len, separators):
+    """Returns (vals [ncols int64 tensors], strs [ncols int64 tensors holding 8 text bytes], QnameColsResult)."""
+    from ._lib import QnameColsResult
+    t = ctx.torch
+    ncols = len(separators) + 1
+    vals = [t.empty(nreads, dtype=t.int64, device=ctx.device) for _ in range(ncols)]
+    strs = [t.empty(nreads, dtype=t.int64, device=ctx.device) for _ in range(ncols)]
+    pv = (C.c_void_p * ncols)(*[v.data_ptr() for v in vals])
+    ps = (C.c_void_p * ncols)(*[s.data_ptr() for s in strs])
+    seps = (C.c_uint8 * len(separators)).from_buffer_copy(separators)
+    res = QnameColsResult()
+    call('uq_qname_tokenise', ctx.h, _p(buf), _p(line_start), nreads, prefix_len, suffix_len, seps, len(separators), pv, ps, C.byref(res))
+    return vals, strs, res
+
+
+def prefix_distinct(ctx, perm, sorted_key, n, thresholds):
+    th = (C.c_uint64 * len(thresholds))(*thresholds)
+    out = (C.c_uint64 * len(thresholds))()
+    call('uq_prefix_distinct', ctx.h, _p(perm), _p(sorted_key), n, th, len(thresholds), out)
+    return list(out)
+
+
+def encode_int(ctx, val, sub, itemsize):
+    t = ctx.torch
+    out = t.empty(val.numel(), dtype=getattr(t, _NARROW_DT[itemsize]), device=ctx.device)
+    call('uq_encode_int', ctx.h, _p(val), val.numel(), int(sub), itemsize, _p(out))
+    return out
+
+
 # ------------------------------------------------------------------ unpack
 def make_unpack_params(config):
     p = UnpackParams()

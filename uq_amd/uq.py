@@ -56,6 +56,7 @@ def build_parser():
     p.add_argument('--decode', action='store_true', default=False, help='Requred if you want to convert a .uQ back to .fastq')
     p.add_argument('--device', type=int, default=int(os.environ.get('LOCAL_RANK', '0')), help='GPU index (extension)')
     p.add_argument('--quiet', action='store_true', default=False, help='suppress the analysis report (extension)')
+    p.add_argument('--host-qname', action='store_true', default=False, help='run the QNAME passes sequentially on the host (extension)')
     return p
 
 
@@ -131,7 +132,21 @@ class Session:
         if nlines == 0: error('ERROR: empty input')
         self.total = nlines // 4
         self.d_ls, self.d_stats = ops.index_and_stats(ctx, self.d_buf, nlines)   # record index + pass-1 statistics
-        self.h_ls = ctx.to_numpy(self.d_ls, np.uint64)
+
+    def analyse_qname(self):
+        """QNAME passes 1 / 2 / 4: per-read work on the device (qname_device), or -- for QNAMEs outside the
+        subset that path reproduces exactly, and with --host-qname -- sequentially on the host."""
+        from . import qname, qname_device
+        self.qname_path = 'device'
+        res = None if getattr(self.args, 'host_qname', False) else qname_device.analyse_device(self.ctx, self.d_buf, self.d_ls, self.total)
+        if res is None:
+            self.qname_path = 'host-native'
+            h_ls = self.ctx.to_numpy(self.d_ls, np.uint64)
+            res = qname.analyse_native(self.host, h_ls, self.total)               # C++ host path
+            if res is None:                                                        # regex-special separators etc.: Python path
+                self.qname_path = 'host-python'
+                res = qname.analyse(qname.qname_lines(self.host, h_ls, self.total))
+        return res
 
     def analyse(self):
         """Pass 1 (histogram, lengths, QNAME layout), the N-trick / width decisions, pass 2 (QNAME typing)."""
@@ -148,10 +163,7 @@ class Session:
         d = analysis.decide_from_counts(hs.counts, hs.len_min, hs.len_max, notricks=args.notricks, pad=args.pad, first_seen=first_seen)
         self.d = d
         try:
-            res = qname.analyse_native(self.host, self.h_ls, self.total)          # C++ host path
-            if res is None:                                                        # regex-special separators etc.: Python path
-                res = qname.analyse(qname.qname_lines(self.host, self.h_ls, self.total))
-            prefix, suffix, separators, columns, arrays = res
+            prefix, suffix, separators, columns, arrays = self.analyse_qname()
         except qname.QnameError as e:
             error(str(e))
         self.columns = columns
@@ -221,7 +233,7 @@ class Session:
         """uq.py:705-736: pass 3, and pass 4's column arrays moved to the device."""
         arrays = self.encoder_variable() if self.d['variable_read_lengths'] else self.encoder_fixed()
         self.tables['DNA'], self.tables['QUAL'] = arrays
-        self.tables['QNAME'] = [self.ctx.to_device(a) for a in self.qname_arrays]
+        self.tables['QNAME'] = [a if self.ctx.torch.is_tensor(a) else self.ctx.to_device(a) for a in self.qname_arrays]
 
     # ------------------------------------------------------------------ writers
     def write_pattern(self, table, filename):
