@@ -102,8 +102,10 @@ class Session:
         self.ops = ops
         self.args = args
         self.ctx = ctx or Context(getattr(args, 'device', 0))
+        from .hostio import Staging
+        self.io = Staging(self.ctx)
         self.out = out
-        self.members = {}          # name -> bytes of a .npy file (no suffix), uq.py:272-274
+        self.members = {}          # name -> (npy header bytes, payload: device tensor or numpy array), uq.py:272-274
         self.tables = {}           # 'DNA' / 'QUAL' -> (device tensor, rows, cols); 'QNAME' -> [device column tensors]
         self.columns = []
         self.config = {}
@@ -123,15 +125,22 @@ class Session:
     def load(self, path):
         """Read the FASTQ, put it in HBM, build the record index.  Replaces `wc -l` + line iteration."""
         ops, ctx = self.ops, self.ctx
-        self.host = np.fromfile(path, dtype=np.uint8)
-        if self.host.size == 0: error('ERROR: empty input')
-        self.d_buf = ctx.to_device(self.host)
+        if os.path.getsize(path) == 0: error('ERROR: empty input')
+        self.path, self._host = path, None
+        self.d_buf = self.io.file_to_device(path)                                # pinned, chunked, overlapped with the reads (row f2)
         nlines = ops.count_lines(ctx, self.d_buf)
         if nlines % 4 != 0:
             error('ERROR: The FASTQ file provided contains' + str(nlines) + 'rows, which is not divisible by 4!')
         if nlines == 0: error('ERROR: empty input')
         self.total = nlines // 4
         self.d_ls, self.d_stats = ops.index_and_stats(ctx, self.d_buf, nlines)   # record index + pass-1 statistics
+
+    @property
+    def host(self):
+        """Host copy of the FASTQ bytes: only the sequential QNAME fallback needs it."""
+        if self._host is None:
+            self._host = np.fromfile(self.path, dtype=np.uint8)
+        return self._host
 
     def analyse_qname(self):
         """QNAME passes 1 / 2 / 4: per-read work on the device (qname_device), or -- for QNAMEs outside the
@@ -153,7 +162,7 @@ class Session:
         from . import analysis, qname
         ops, ctx, args = self.ops, self.ctx, self.args
         hs = ops.stats_fetch(ctx, self.d_stats)
-        if self.host[0] != ord('@'): error('ERROR: This does not look like a FASTA/FASTQ file! (first line does not start with @)')
+        if int(self.d_buf[0]) != ord('@'): error('ERROR: This does not look like a FASTA/FASTQ file! (first line does not start with @)')
         if hs.bad_plus is not None:
             error('ERROR: For entry' + str(hs.bad_plus) + 'the third line does not start with +')
         if hs.bad_len is not None:
@@ -245,13 +254,21 @@ class Session:
         else: error('ERROR: This should never happen!')
         t, rows, cols = table
         payload = self.ops.pattern(self.ctx, t, rows, cols, pattern)
-        self.members[filename] = pattern_header(rows, cols, pattern) + self.ctx.to_numpy(payload).tobytes()
+        self.members[filename] = (pattern_header(rows, cols, pattern), payload)      # stays in HBM until write_container streams it
 
     def write_out(self, array, filename, dtype=None):
-        """uq.py:272-274: a 1-D array (key or QNAME column) as .npy bytes.  `array`: device tensor or numpy."""
-        if not isinstance(array, np.ndarray):
-            array = self.ctx.to_numpy(array, dtype)
-        self.members[filename] = npy_header(array.shape, False, array.dtype) + array.tobytes()
+        """uq.py:272-274: a 1-D array (key or QNAME column) as a .npy member.  `array`: device tensor (with the
+        numpy dtype its bytes stand for) or numpy."""
+        if isinstance(array, np.ndarray):
+            self.members[filename] = (npy_header(array.shape, False, array.dtype), array)
+        else:
+            self.members[filename] = (npy_header((array.numel(),), False, dtype or self._npdtype(array.element_size())), array)
+
+    def member_bytes(self, name):
+        """One member as the bytes numpy.save would have written (tests, --test sizing)."""
+        header, payload = self.members[name]
+        if not isinstance(payload, np.ndarray): payload = self.ctx.to_numpy(payload)
+        return header + payload.tobytes()
 
     def compressed_size(self, data):
         """uq.py:277-285 (Q4/Q26 fixed: spawn on demand, serialise first, surface errors)."""
@@ -305,9 +322,10 @@ class Session:
                 k = ops.narrow(ctx, skey, isz)
             else:
                 k = ops.narrow(ctx, ops.gather_rows(ctx, key.view(ctx.torch.uint8), rows, 4, sort_order).view(ctx.torch.int32), isz)
-            k_host = ctx.to_numpy(k, self._npdtype(isz))
-            if test: test[out_name] = self.compressed_size(npy_header(k_host.shape, False, k_host.dtype) + k_host.tobytes())
-            else: self.write_out(k_host, out_name)
+            if test:
+                k_host = ctx.to_numpy(k, self._npdtype(isz))
+                test[out_name] = self.compressed_size(npy_header(k_host.shape, False, k_host.dtype) + k_host.tobytes())
+            else: self.write_out(k, out_name, self._npdtype(isz))
             table = (uniq, nu, cols)
             if test: test[table_name] = self.test_patterns(table, table_name)
             else: self.write_pattern(table, table_name)
@@ -322,9 +340,10 @@ class Session:
         ncols = len(cols_d)
 
         def emit(name, tensor, dtype):
-            host = ctx.to_numpy(tensor, np.dtype(dtype))
-            if test: test[name] = self.compressed_size(npy_header(host.shape, False, host.dtype) + host.tobytes())
-            else: self.write_out(host, name)
+            if test:
+                host = ctx.to_numpy(tensor, np.dtype(dtype))
+                test[name] = self.compressed_size(npy_header(host.shape, False, host.dtype) + host.tobytes())
+            else: self.write_out(tensor, name, np.dtype(dtype))
 
         if raw:
             if sort_order is False:
@@ -420,13 +439,38 @@ class Session:
             if base.startswith('QNAME_'): return (3, int(base[6:]), name)
             return ({'DNA': 0, 'QUAL': 1, 'QNAME': 2}.get(base, 4), 0, name)
 
-        tmpdir = tempfile.mkdtemp(prefix='uq_', dir=args.temp if getattr(args, 'temp', None) else None)
+        # private temp dir (Q5); beside the output unless --temp says otherwise, so the final move is a rename
+        tmpdir = tempfile.mkdtemp(prefix='uq_', dir=args.temp if getattr(args, 'temp', None) else (os.path.dirname(os.path.abspath(path)) or None))
+
+        def pwrite_all(fd, data, pos):
+            mv = memoryview(data).cast('B')
+            done = 0
+            while done < len(mv): done += os.pwrite(fd, mv[done:], pos + done)
+
         try:
             tmp = os.path.join(tmpdir, 'temp.uq')
-            with tarfile.open(tmp, mode='w') as t:
-                for name, data in [('config.json', blob)] + [(k, self.members[k]) for k in sorted(self.members, key=order)]:
-                    ti = tarfile.TarInfo(name); ti.size = len(data); ti.mtime = int(time.time())
-                    t.addfile(ti, io.BytesIO(data))
+            # The tar stream tarfile.open(mode='w').addfile() would write (header block, data, padding to 512,
+            # two zero blocks, padding to RECORDSIZE), with the payloads streamed HBM -> pinned -> pwrite.
+            fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+            try:
+                pos = 0
+                for name, (header, payload) in [('config.json', (blob, np.zeros(0, np.uint8)))] + [(k, self.members[k]) for k in sorted(self.members, key=order)]:
+                    nbytes = payload.nbytes if isinstance(payload, np.ndarray) else payload.numel() * payload.element_size()
+                    ti = tarfile.TarInfo(name); ti.size = len(header) + nbytes; ti.mtime = int(time.time())
+                    head = ti.tobuf(tarfile.DEFAULT_FORMAT, tarfile.ENCODING, 'surrogateescape') + header
+                    pwrite_all(fd, head, pos); pos += len(head)
+                    if isinstance(payload, np.ndarray):
+                        if nbytes: pwrite_all(fd, np.ascontiguousarray(payload), pos)
+                    else:
+                        self.io.device_to_fd(payload, fd, pos)
+                    pos += nbytes
+                    pad = -ti.size % tarfile.BLOCKSIZE
+                    if pad: pwrite_all(fd, b'\0' * pad, pos); pos += pad
+                end = 2 * tarfile.BLOCKSIZE
+                end += -(pos + end) % tarfile.RECORDSIZE
+                pwrite_all(fd, b'\0' * end, pos)
+            finally:
+                os.close(fd)
             shutil.move(tmp, path)
         finally:
             shutil.rmtree(tmpdir, ignore_errors=True)
@@ -455,19 +499,23 @@ class Session:
 
     # ------------------------------------------------------------------ decode (uq.py:926-1058)
     def load_from_tar(self, members, file_name, pattern='0.1'):
-        """uq.py:943-945 on the device: payload -> table.  Returns (device tensor, rows, cols) for 2-D
-        members, a numpy array for 1-D ones."""
-        data = members[file_name]
-        f = io.BytesIO(data)
+        """uq.py:943-945 on the device: payload -> table.  `members`: name -> (offset, size) inside the tar
+        `self.tar_path`; the payload streams file -> pinned -> HBM.  Returns (device tensor, rows, cols) for
+        2-D members; for 1-D ones a device tensor typed by width (its bytes are the member's dtype)."""
+        offset, size = members[file_name]
+        with open(self.tar_path, 'rb') as fh:
+            fh.seek(offset)
+            f = io.BytesIO(fh.read(min(size, 65536)))
         version = np.lib.format.read_magic(f)
         shape, fortran, dtype = np.lib.format.read_array_header_1_0(f) if version == (1, 0) else np.lib.format.read_array_header_2_0(f)
-        payload = np.frombuffer(data, dtype=np.uint8, offset=f.tell())
+        hdr = f.tell()
+        d_pay = self.io.file_to_device(self.tar_path, offset + hdr, size - hdr)
         if len(shape) == 1:
-            return payload.view(dtype)
+            tt = self.ctx.torch
+            return d_pay.view({1: tt.uint8, 2: tt.int16, 4: tt.int32, 8: tt.int64}[np.dtype(dtype).itemsize])
         k = int(pattern[0])
         rows, cols = (shape if k % 2 == 0 else shape[::-1])
         # numpy flags 1-wide arrays as C order whatever the pattern asked for: the byte stream is the same
-        d_pay = self.ctx.to_device(payload)
         t = self.ops.unpattern(self.ctx, d_pay, rows, cols, pattern)
         return (t, rows, cols)
 
@@ -486,40 +534,44 @@ class Session:
         out = out or sys.stdout
         if not tarfile.is_tarfile(args.input):
             error('ERROR: Sorry, the path you have provided as input is a file, but not a tar file, and therefore cannot be a .uq file!')
+        self.tar_path = args.input
         with tarfile.open(args.input) as t:
-            members = {m.name: t.extractfile(m).read() for m in t.getmembers()}
-        if 'config.json' not in members: error('ERROR: No config.json file was found in your input path! I cannot decode data without it!')
-        config = json.loads(members['config.json'].decode())
+            members = {m.name: (m.offset_data, m.size) for m in t.getmembers()}
+            if 'config.json' not in members: error('ERROR: No config.json file was found in your input path! I cannot decode data without it!')
+            config = json.loads(t.extractfile('config.json').read().decode())
         pat = config['pattern'] or ['0.1', '0.1']
 
         def table(name, pattern):
             if name + '.raw' in members: return self.load_from_tar(members, name + '.raw', pattern)
             if name in members and name + '.key' in members:
                 t, rows, cols = self.load_from_tar(members, name, pattern)
-                key = self.load_from_tar(members, name + '.key')
-                d_key = ctx.to_device(key)
-                return (ops.gather_rows(ctx, t, rows, cols, d_key), len(key), cols)               # uq.py:953, 957
+                d_key = self.load_from_tar(members, name + '.key')
+                return (ops.gather_rows(ctx, t, rows, cols, d_key), d_key.numel(), cols)          # uq.py:953, 957
             error('ERROR: No ' + name + ' data was found in this uQ file?!')
 
         DNA = table('DNA', pat[0])
         QUAL = table('QUAL', pat[1])
         ncols = len(config['QNAME_columns'])
+        u8 = ctx.torch.uint8
         if 'QNAME.key' in members:
-            key = self.load_from_tar(members, 'QNAME.key')
-            cols = [self.load_from_tar(members, 'QNAME_%d' % (i + 1))[key] for i in range(ncols)]  # uq.py:973, numeric order (Q6)
+            d_key = self.load_from_tar(members, 'QNAME.key')
+            d_cols = []
+            for i in range(ncols):                                                                # uq.py:973, numeric order (Q6)
+                c = self.load_from_tar(members, 'QNAME_%d' % (i + 1))
+                d_cols.append(ops.gather_rows(ctx, c.view(u8), c.numel(), c.element_size(), d_key).view(c.dtype))
         else:
-            cols = [self.load_from_tar(members, 'QNAME_%d.raw' % (i + 1)) for i in range(ncols)]
+            d_cols = [self.load_from_tar(members, 'QNAME_%d.raw' % (i + 1)) for i in range(ncols)]
         seq, qt, ln = self.split_bits(DNA, QUAL, config)
         n = DNA[1]
         w = out.buffer if hasattr(out, 'buffer') else out
         if len(config['QNAME_columns']) <= 32 and len(config['QNAME_prefix']) <= 256 and len(config['QNAME_suffix']) <= 256:
-            # the text is assembled on the device (uq_emit_fastq) and leaves as one buffer
-            d_cols = [ctx.to_device(np.ascontiguousarray(c)) for c in cols]
+            # the text is assembled on the device (uq_emit_fastq) and streams out through the pinned buffers
             text = ops.emit_fastq(ctx, config, d_cols, seq, qt, ln, n)
-            w.write(ctx.to_numpy(text).tobytes())
+            self.io.device_to_stream(text, w)
         else:
             dmax = config['dna_max']
             S = ctx.to_numpy(seq).reshape(n, dmax); Q = ctx.to_numpy(qt).reshape(n, dmax); L = ctx.to_numpy(ln, np.uint32)
+            cols = [ctx.to_numpy(c, np.dtype(cc['dtype'])) for c, cc in zip(d_cols, config['QNAME_columns'])]
             names = qname.decode_names(config, cols)
             for r in range(n):
                 l = int(L[r])
