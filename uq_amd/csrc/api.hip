@@ -45,6 +45,7 @@ extern "C" int uq_ctx_destroy(uq_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->idx_partials) (void)hipFree(c->idx_partials);
+    if (c->idx_bitmap) (void)hipFree(c->idx_bitmap);
     if (c->scan_ws) (void)hipFree(c->scan_ws);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     (void)hipEventDestroy(c->ev0);

@@ -20,6 +20,7 @@ struct uq_ctx {
     // cache of the newline counts of the last uq_count_lines call (reused by uq_index_lines)
     const uint8_t* idx_buf; uint64_t idx_nbytes; uint64_t idx_nlines;
     uint32_t* idx_partials; size_t idx_partials_cap;
+    uint16_t* idx_bitmap;   // newline bitmap of that buffer: one u16 per 16-byte vector (index.hip)
     uint64_t* h_pinned;     // small pinned host staging (64 KiB)
     void* scan_ws; size_t scan_ws_bytes;   // partial sums of the hierarchical scans
 };

@@ -27,26 +27,6 @@ constexpr uint32_t FZ_BBASE = 64, FZ_NB = 64, FZ_NQ = 64;
 constexpr uint32_t FZ_P = 5;                           // lanes per record
 constexpr uint32_t FZ_RPB = FZ_THREADS / FZ_P;         // records per batch
 
-__device__ __forceinline__ uint32_t nl_bits(uint32_t v) {
-    v ^= 0x0A0A0A0Au;
-    uint32_t t = (v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
-    return ~(t | v | 0x7F7F7F7Fu);
-}
-__device__ __forceinline__ uint32_t nl_mask16(uint4 q) {
-    auto nib = [](uint32_t w) { return (((nl_bits(w) >> 7) & 0x01010101u) * 0x01020408u >> 24) & 0xFu; };
-    return nib(q.x) | (nib(q.y) << 4) | (nib(q.z) << 8) | (nib(q.w) << 12);
-}
-__device__ __forceinline__ uint32_t valid_mask16(int64_t p, uint64_t nbytes) {
-    if (p >= 0 && (uint64_t)p + 16 <= nbytes) return 0xFFFFu;
-    uint32_t m = 0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        int64_t q = p + i;
-        if (q >= 0 && (uint64_t)q < nbytes) m |= 1u << i;
-    }
-    return m;
-}
-
 __device__ __forceinline__ void fz_count_pair(uint32_t b, uint32_t c, uint32_t qbase, uint32_t* hist, uq_stats* st) {
     const uint32_t sb = b - FZ_BBASE, sq = c - qbase;
     if (sb < FZ_NB && sq < FZ_NQ) atomicAdd(&hist[sb * FZ_NQ + sq], 1u);

@@ -2,6 +2,29 @@
 #pragma once
 #include "common.h"
 
+// High bit of each byte of the result is set iff that byte of v equals '\n' (exact, no carries between bytes).
+__device__ __forceinline__ uint32_t nl_bits(uint32_t v) {
+    v ^= 0x0A0A0A0Au;
+    uint32_t t = (v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+    return ~(t | v | 0x7F7F7F7Fu);
+}
+// 16-bit mask (bit i = byte i of the 16-byte vector is '\n').
+__device__ __forceinline__ uint32_t nl_mask16(uint4 q) {
+    auto nib = [](uint32_t w) { return (((nl_bits(w) >> 7) & 0x01010101u) * 0x01020408u >> 24) & 0xFu; };
+    return nib(q.x) | (nib(q.y) << 4) | (nib(q.z) << 8) | (nib(q.w) << 12);
+}
+// Bytes of the vector at stream position p .. p+15 that fall inside [0, nbytes) (p may be negative).
+__device__ __forceinline__ uint32_t valid_mask16(int64_t p, uint64_t nbytes) {
+    if (p >= 0 && (uint64_t)p + 16 <= nbytes) return 0xFFFFu;
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        int64_t q = p + i;
+        if (q >= 0 && (uint64_t)q < nbytes) m |= 1u << i;
+    }
+    return m;
+}
+
 // 8 consecutive bytes at LDS byte offset `o` (any alignment, may be slightly negative) as two dwords:
 // three aligned ds_read_b32 + two v_alignbyte.
 __device__ __forceinline__ void lds_window8(const uint8_t* base, int32_t o, uint32_t& lo, uint32_t& hi) {
