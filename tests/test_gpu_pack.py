@@ -111,6 +111,27 @@ def test_stats_unusual_bytes_and_bad_records(ctx):
     assert np.array_equal(hs2.counts, ref['counts']) and hs2.bad_plus == 1 and hs2.bad_len == 2
 
 
+@pytest.mark.parametrize('case', ['lower', 'mixed', 'phred64', 'iupac'])
+def test_stats_window_hints(ctx, case):
+    """The LDS count tables are windows placed from the first record; every byte must still be counted exactly."""
+    rng = np.random.default_rng(11)
+    alpha = {'lower': b'acgtn', 'mixed': b'ACGTacgtN', 'phred64': b'ACGT', 'iupac': b'ACGTNRYKMSWBDHV'}[case]
+    qlo, qhi = (64, 105) if case == 'phred64' else (33, 74)
+    recs = []
+    for i in range(3000):
+        L = int(rng.integers(1, 120))
+        recs.append(b'@r:%d\n' % i + bytes(rng.choice(np.frombuffer(alpha, np.uint8), L)) + b'\n+\n' + bytes(rng.integers(qlo, qhi, L, dtype=np.uint8)) + b'\n')
+    host = np.frombuffer(b''.join(recs), dtype=np.uint8).copy()
+    d_buf = ctx.to_device(host)
+    nlines, ls = _index(ctx, d_buf)
+    st = ops.stats_new(ctx)
+    ops.stats_accumulate(ctx, st, d_buf, ls, 0, 3000)
+    hs = ops.stats_fetch(ctx, st)
+    ref = oracle_c.stats(host, oracle_c.index_lines(host), 0, 3000)
+    assert np.array_equal(hs.counts, ref['counts'])
+    assert (hs.len_min, hs.len_max) == (ref['len_min'], ref['len_max'])
+
+
 def _check_fused(ctx, host, misalign=0):
     t = ctx.torch
     backing = ctx.empty(host.size + 64)

@@ -6,12 +6,14 @@
 // over tiles of R consecutive records.  A tile is one contiguous byte span: it is copied to LDS with
 // 16-byte coalesced loads (the next tile's span bounds are requested one iteration ahead), then each
 // half-wave (32 lanes) owns one record at a time and a lane takes 4 consecutive (base, quality) pairs
-// per step (a 150-base read is one step of 38 lanes).  Counts go to the LDS table
-// [64 base bytes 64..127][64 quality bytes qbase..qbase+63] of u32 with fire-and-forget ds_add_u32
-// (slot = byte - window base: no lookup, no wait between the four adds); any pair outside the two
-// windows uses a global atomic on the full 256 x 256 table, so every byte value is counted exactly.
-// `qbase` is a speed hint the host takes from the first record.  Tables are flushed to the u64 global
-// table once per workgroup.  A tile whose span exceeds the staging buffer (very long reads) is counted
+// per step (a 150-base read is one step of 38 lanes).  Counts go to LDS with fire-and-forget ds_add_u32,
+// in three tiers per group of 8 positions:
+//   1. all eight bases exactly A/C/G/T and qualities inside the window: an 8-fold replicated table
+//      [4 bases][64 qualities][8 copies] (scattered LDS adds are bank-conflict bound: -0.14 ms on 10M x 150);
+//   2. bases in [bbase, bbase+32), qualities in [qbase, qbase+64): one general table, slot = byte - corner;
+//   3. anything else: a global atomic on the full 256 x 256 table -- every byte value is counted exactly.
+// `bbase` / `qbase` are speed hints the host takes from the first record.  Tables are flushed to the u64
+// global table once per workgroup.  A tile whose span exceeds the staging buffer (very long reads) is counted
 // straight from HBM.
 // Algorithmic HBM bytes: the record bytes once + 32 B of line offsets per record.
 #include "common.h"
@@ -19,8 +21,9 @@
 
 namespace {
 constexpr int ST_THREADS = 256;
-constexpr uint32_t ST_BBASE = 64;          // base bytes with an LDS counter: [64, 128)
-constexpr uint32_t ST_NB = 64, ST_NQ = 64;
+constexpr uint32_t ST_NB = 32, ST_NQ = 64;  // general LDS table: 32 base bytes from bbase (64: upper case, 96: lower case) x 64 qualities from qbase
+constexpr int ST_COPIES = 8;               // replication of the A/C/G/T table (bank-conflict control)
+static_assert(4 * ST_NQ == 256, "one lane per A/C/G/T bin in the flush");
 constexpr int ST_NV = 5;                  // 16-byte loads per lane per tile
 constexpr uint32_t ST_CAP = ST_NV * 256 * 16;   // staging bytes per tile (20 KiB)
 constexpr uint32_t ST_RMAX = 64;           // records per tile, upper bound (4 * ST_RMAX + 1 <= 2 * ST_THREADS)
@@ -42,16 +45,17 @@ __device__ __forceinline__ uint32_t lds_load4(const uint8_t* base, uint32_t o) {
     return __builtin_amdgcn_alignbyte(p[1], p[0], o & 3u);
 }
 
-__device__ __forceinline__ void count_pair(uint32_t b, uint32_t c, uint32_t qbase, uint32_t* hist, uq_stats* st) {
-    const uint32_t sb = b - ST_BBASE, sq = c - qbase;
+// `win` = bbase << 8 | qbase: the corners of the LDS table's base / quality windows
+__device__ __forceinline__ void count_pair(uint32_t b, uint32_t c, uint32_t win, uint32_t* hist, uq_stats* st) {
+    const uint32_t sb = b - (win >> 8), sq = c - (win & 255u);
     if (sb < ST_NB && sq < ST_NQ) atomicAdd(&hist[sb * ST_NQ + sq], 1u);
     else atomicAdd((unsigned long long*)&st->counts[b * 256 + c], 1ull);
 }
-__device__ __forceinline__ void count_quad(uint32_t vb, uint32_t vq, uint32_t cnt, uint32_t qbase, uint32_t* hist, uq_stats* st) {
-    count_pair(vb & 255u, vq & 255u, qbase, hist, st);
-    if (cnt > 1) count_pair((vb >> 8) & 255u, (vq >> 8) & 255u, qbase, hist, st);
-    if (cnt > 2) count_pair((vb >> 16) & 255u, (vq >> 16) & 255u, qbase, hist, st);
-    if (cnt > 3) count_pair(vb >> 24, vq >> 24, qbase, hist, st);
+__device__ __forceinline__ void count_quad(uint32_t vb, uint32_t vq, uint32_t cnt, uint32_t win, uint32_t* hist, uq_stats* st) {
+    count_pair(vb & 255u, vq & 255u, win, hist, st);
+    if (cnt > 1) count_pair((vb >> 8) & 255u, (vq >> 8) & 255u, win, hist, st);
+    if (cnt > 2) count_pair((vb >> 16) & 255u, (vq >> 16) & 255u, win, hist, st);
+    if (cnt > 3) count_pair(vb >> 24, vq >> 24, win, hist, st);
 }
 
 struct Acc {
@@ -68,11 +72,14 @@ struct Acc {
 
 __global__ __launch_bounds__(ST_THREADS) void stats_kernel(const uint8_t* __restrict__ buf, uint64_t nbytes,
                                                            const uint64_t* __restrict__ ls, uint64_t first,
-                                                           uint64_t n, uint32_t R, uint32_t qbase, uint32_t P, uint32_t magicP, uq_stats* __restrict__ st) {
+                                                           uint64_t n, uint32_t R, uint32_t win, uint32_t P, uint32_t magicP, uq_stats* __restrict__ st) {
+    const uint32_t qbase = win & 255u, bbase = win >> 8;       // bbase is 64 or 96 (the XOR test below needs a multiple of 32)
     __shared__ uint32_t hist[ST_NB * ST_NQ];
+    __shared__ uint32_t fast[4 * ST_NQ * ST_COPIES];          // [A C T G][quality slot][copy]
     __shared__ __align__(16) uint8_t stage[ST_CAP + 32];
     __shared__ uint32_t meta[4 * ST_RMAX + 4];
     for (int i = threadIdx.x; i < (int)(ST_NB * ST_NQ); i += ST_THREADS) hist[i] = 0;
+    for (int i = threadIdx.x; i < (int)(4 * ST_NQ * ST_COPIES); i += ST_THREADS) fast[i] = 0;
     __syncthreads();
 
     const uint32_t tid = threadIdx.x, lane = lane_id();
@@ -84,6 +91,7 @@ __global__ __launch_bounds__(ST_THREADS) void stats_kernel(const uint8_t* __rest
     uint32_t rr, pp;                                  // this lane counts groups pp, pp + P, ... of read rr of every tile
     fast_divmod(tid, P, magicP, rr, pp);
     const uint32_t q_addlo = 0x01010101u * (0x80u - qbase), q_addhi = 0x01010101u * (0x80u - qbase - ST_NQ);
+    const uint32_t b_xor = 0x01010101u * bbase;
 
     // Software pipeline over this workgroup's tiles t, t + S, t + 2S, ... (S = gridDim.x):
     //   span bounds are requested two tiles ahead, the tile's bytes + line offsets one tile ahead (they
@@ -150,12 +158,26 @@ __global__ __launch_bounds__(ST_THREADS) void stats_kernel(const uint8_t* __rest
                     lds_window8(stage, (int32_t)(s + j), b_lo, b_hi);
                     lds_window8(stage, (int32_t)(q + j), q_lo, q_hi);
                     const uint32_t cnt = Lc - j;
-                    // byte - window base, valid when the top bits vanish: bases 64..127, qualities qbase..qbase+63
-                    const uint32_t sb0 = b_lo ^ 0x40404040u, sb1 = b_hi ^ 0x40404040u;
+                    // byte - window base, valid when the top bits vanish: bases bbase..bbase+31, qualities qbase..qbase+63
+                    const uint32_t sb0 = b_lo ^ b_xor, sb1 = b_hi ^ b_xor;
                     const uint32_t u0 = q_lo + q_addlo, u1 = q_hi + q_addlo;
-                    const uint32_t bad = ((sb0 | sb1) & 0xC0C0C0C0u) |
+                    const uint32_t bad = ((sb0 | sb1) & 0xE0E0E0E0u) |
                                          ((q_lo | (q_lo + q_addhi) | ~u0 | q_hi | (q_hi + q_addhi) | ~u1) & 0x80808080u);
-                    if (cnt >= 8 && bad == 0) {
+                    // tier 1: all eight bases are exactly A/C/G/T -> bin byte = code << 6 | quality slot, counted in the
+                    // ST_COPIES-fold replicated table (copy = lane % 8: the bank is (quality & 3) * 8 + lane % 8, so the
+                    // four lanes of a half-wave that share a copy collide only on equal low quality bits -- mostly
+                    // <= 2-way, which ds_add_u32 absorbs at no cost; the single-copy table is ~3.5-way on random data)
+                    const uint32_t c0 = (b_lo >> 1) & 0x03030303u, c1 = (b_hi >> 1) & 0x03030303u;
+                    const bool acgt = __builtin_amdgcn_perm(0u, 0x47544341u, c0) == b_lo && __builtin_amdgcn_perm(0u, 0x47544341u, c1) == b_hi;
+                    if (cnt >= 8 && bad == 0 && acgt) {
+                        const uint32_t bin0 = (c0 << 6) | (u0 & 0x7F7F7F7Fu), bin1 = (c1 << 6) | (u1 & 0x7F7F7F7Fu);
+                        uint8_t* hb = (uint8_t*)fast + ((lane & (ST_COPIES - 1)) << 2);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            atomicAdd((uint32_t*)(hb + (((bin0 >> (8 * k)) & 0xFFu) << 5)), 1u);
+                            atomicAdd((uint32_t*)(hb + (((bin1 >> (8 * k)) & 0xFFu) << 5)), 1u);
+                        }
+                    } else if (cnt >= 8 && bad == 0) {
                         const uint32_t sq0 = (u0 & 0x7F7F7F7Fu) << 2, sq1 = (u1 & 0x7F7F7F7Fu) << 2;   // quality slot * 4 per byte
                         uint8_t* hb = (uint8_t*)hist;
 #pragma unroll
@@ -164,8 +186,8 @@ __global__ __launch_bounds__(ST_THREADS) void stats_kernel(const uint8_t* __rest
                             atomicAdd((uint32_t*)(hb + ((((sb1 >> (8 * k)) & 0xFFu) << 8) | ((sq1 >> (8 * k)) & 0xFFu))), 1u);
                         }
                     } else {
-                        count_quad(b_lo, q_lo, cnt, qbase, hist, st);
-                        if (cnt > 4) count_quad(b_hi, q_hi, cnt - 4, qbase, hist, st);
+                        count_quad(b_lo, q_lo, cnt, win, hist, st);
+                        if (cnt > 4) count_quad(b_hi, q_hi, cnt - 4, win, hist, st);
                     }
                 }
             }
@@ -181,7 +203,7 @@ __global__ __launch_bounds__(ST_THREADS) void stats_kernel(const uint8_t* __rest
                 for (uint32_t j = hl * 4; j < Lc; j += 128) {
                     const uint32_t vb = load_u32_unaligned(buf + s + j);   // s + j + 3 <= e1 + 1 < nbytes always
                     const uint32_t vq = (q + j + 4 <= nbytes) ? load_u32_unaligned(buf + q + j) : load_tail(buf, q + j, nbytes);
-                    count_quad(vb, vq, Lc - j, qbase, hist, st);
+                    count_quad(vb, vq, Lc - j, win, hist, st);
                 }
             }
         }
@@ -190,7 +212,16 @@ __global__ __launch_bounds__(ST_THREADS) void stats_kernel(const uint8_t* __rest
     __syncthreads();
     for (int i = threadIdx.x; i < (int)(ST_NB * ST_NQ); i += ST_THREADS) {
         const uint32_t v = hist[i];
-        if (v) atomicAdd((unsigned long long*)&st->counts[(ST_BBASE + i / ST_NQ) * 256 + qbase + (i % ST_NQ)], (unsigned long long)v);
+        if (v) atomicAdd((unsigned long long*)&st->counts[(bbase + i / ST_NQ) * 256 + qbase + (i % ST_NQ)], (unsigned long long)v);
+    }
+    {
+        // the replicated A/C/T/G table: one lane per bin sums its copies
+        const uint32_t bin = threadIdx.x;                   // 4 * ST_NQ == ST_THREADS
+        uint32_t v = 0;
+#pragma unroll
+        for (int c = 0; c < ST_COPIES; ++c) v += fast[bin * ST_COPIES + ((c + bin) & (ST_COPIES - 1))];
+        const uint32_t base = (0x47544341u >> (8 * (bin >> 6))) & 0xFFu;
+        if (v) atomicAdd((unsigned long long*)&st->counts[base * 256 + qbase + (bin & 63u)], (unsigned long long)v);
     }
     const uint32_t lmin = wave_min(acc.lmin), lmax = wave_max(acc.lmax), rmax = wave_max(acc.rmax);
     const uint64_t bad_plus = wave_min(acc.bad_plus), bad_len = wave_min(acc.bad_len);
@@ -256,18 +287,20 @@ extern "C" int uq_stats_accumulate(uq_ctx* ctx, const uint8_t* d_buf, const uint
     UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     const uint64_t nbytes = tmp[0];
     const uint64_t q = tmp[4], e = tmp[5];
-    uint32_t qbase = 33;
+    uint32_t qbase = 33, bbase = 64;
     uint64_t len = e > q + 1 ? e - q - 1 : 0;
     if (len > 4096) len = 4096;
     if (len) {
         uint8_t* qh = (uint8_t*)(tmp + 8);
         UQ_CHECK_HIP(hipMemcpyAsync(qh, d_buf + q, len, hipMemcpyDeviceToHost, ctx->stream));
+        UQ_CHECK_HIP(hipMemcpyAsync(qh + 4096, d_buf + tmp[2], 1, hipMemcpyDeviceToHost, ctx->stream));   // first base
         UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
         uint32_t mn = 255;
         for (uint64_t i = 0; i < len; ++i)
             if (qh[i] < mn) mn = qh[i];
         if (mn >= 64) qbase = 59;          // Phred+64 era files: window [59, 123)
         else if (mn < 33) qbase = 0;
+        if (qh[4096] >= 96) bbase = 96;    // lower-case reads
     }
     // tile = R records sized from the average record length so that a typical span fits the staging buffer
     const uint64_t avg = (nbytes - tmp[1]) / nreads + 1;
@@ -279,7 +312,7 @@ extern "C" int uq_stats_accumulate(uq_ctx* ctx, const uint8_t* d_buf, const uint
     uint32_t P = ST_THREADS / (uint32_t)R;
     if (P > 16) P = 16;
     if (P < 1) P = 1;
-    stats_kernel<<<blocks, ST_THREADS, 0, ctx->stream>>>(d_buf, nbytes, d_line_start, first_read, nreads, (uint32_t)R, qbase, P, magic_u32(P), d_stats);
+    stats_kernel<<<blocks, ST_THREADS, 0, ctx->stream>>>(d_buf, nbytes, d_line_start, first_read, nreads, (uint32_t)R, (bbase << 8) | qbase, P, magic_u32(P), d_stats);
     UQ_LAUNCH_CHECK();
     return 0;
 }
