@@ -27,16 +27,18 @@ def decide_from_counts(counts, len_min, len_max, notricks=False, pad=False, firs
     """
     counts = np.asarray(counts).reshape(256, 256)
     base_tot = counts.sum(axis=1)
-    qual_tot = counts.sum(axis=0)
-    dna_bases = [b for b in range(256) if base_tot[b]]            # uq.py:456 sorted(keys)
-    quals = [q for q in range(256) if qual_tot[q]]                # uq.py:457
+    dna_bases = np.flatnonzero(base_tot).tolist()                 # uq.py:456 sorted(keys)
     if not dna_bases:
         raise ValueError('no bases counted')
+    live = counts[dna_bases]                                      # the few rows that hold anything
+    qual_tot = live.sum(axis=0)
+    quals = np.flatnonzero(qual_tot).tolist()                     # uq.py:457
+    all_bases = list(dna_bases)
     N_qual = {}
     total_quals = len(quals)
     if not notricks:                                              # uq.py:479-494
-        nq = (counts != 0).sum(axis=1)
-        cand = [b for b in dna_bases if nq[b] == 1]
+        nq = (live != 0).sum(axis=1)
+        cand = [b for b, k in zip(dna_bases, nq.tolist()) if k == 1]
         if len(cand) > 1:
             fs = first_seen() if callable(first_seen) else first_seen
             if fs is not None:
@@ -60,6 +62,6 @@ def decide_from_counts(counts, len_min, len_max, notricks=False, pad=False, firs
         'bits_per_base': bits_per_base, 'bits_per_quality': bits_per_quality,
         'variable_read_lengths': variable, 'dna_max': int(len_max), 'dna_min': int(len_min),
         'dna_bytes_per_row': -(-bits_per_base * lv // 8), 'quality_bytes_per_row': -(-bits_per_quality * lv // 8),
-        'base_distribution': {chr(b): int(base_tot[b]) for b in range(256) if base_tot[b]},
-        'qual_distribution': {chr(q): int(qual_tot[q]) for q in range(256) if qual_tot[q]},
+        'base_distribution': {chr(b): int(base_tot[b]) for b in all_bases},
+        'qual_distribution': {chr(q): int(qual_tot[q]) for q in quals},
     }

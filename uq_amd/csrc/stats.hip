@@ -70,26 +70,50 @@ struct Acc {
     }
 };
 
-__global__ __launch_bounds__(ST_THREADS) void stats_kernel(const uint8_t* __restrict__ buf, uint64_t nbytes,
-                                                           const uint64_t* __restrict__ ls, uint64_t first,
-                                                           uint64_t n, uint32_t R, uint32_t win, uint32_t P, uint32_t magicP, uq_stats* __restrict__ st) {
-    const uint32_t qbase = win & 255u, bbase = win >> 8;       // bbase is 64 or 96 (the XOR test below needs a multiple of 32)
+__global__ __launch_bounds__(ST_THREADS) void stats_kernel(const uint8_t* __restrict__ buf, const uint64_t* __restrict__ ls, uint64_t first,
+                                                           uint64_t n, uq_stats* __restrict__ st) {
     __shared__ uint32_t hist[ST_NB * ST_NQ];
     __shared__ uint32_t fast[4 * ST_NQ * ST_COPIES];          // [A C T G][quality slot][copy]
     __shared__ __align__(16) uint8_t stage[ST_CAP + 32];
     __shared__ uint32_t meta[4 * ST_RMAX + 4];
+    __shared__ uint32_t cfg[3];
+    const uint32_t tid = threadIdx.x, lane = lane_id();
     for (int i = threadIdx.x; i < (int)(ST_NB * ST_NQ); i += ST_THREADS) hist[i] = 0;
     for (int i = threadIdx.x; i < (int)(4 * ST_NQ * ST_COPIES); i += ST_THREADS) fast[i] = 0;
+    // Launch geometry is decided here, not on the host (no device -> host round trip before the launch):
+    // wave 0 places the table windows from the first record (speed hints: any byte is still counted exactly)
+    // and sizes the tile from the shard's average record length so that a typical span fits the staging buffer.
+    const uint64_t nbytes = ls[4 * (first + n)];              // end of the shard: bound of the unaligned tail loads
+    if (tid < 64) {
+        const uint64_t* l0 = ls + 4 * first;
+        const uint64_t s = l0[1], e1 = l0[2], q = l0[3], e = l0[4];
+        uint64_t len = e > q + 1 ? e - q - 1 : 0;
+        if (len > 4096) len = 4096;
+        uint32_t mn = 255;
+        for (uint64_t j = lane; j < len; j += 64) { const uint32_t c = buf[q + j]; mn = c < mn ? c : mn; }
+        mn = wave_min(mn);
+        if (lane == 0) {
+            uint32_t qb = 33, bb = 64;
+            if (len) { if (mn >= 64) qb = 59; else if (mn < 33) qb = 0; }   // Phred+64 era files: window [59, 123)
+            if (e1 > s + 1 && buf[s] >= 96) bb = 96;                           // lower-case reads
+            const uint64_t avg = (nbytes - l0[0]) / n + 1;
+            uint64_t R = (ST_CAP - 64) / (avg + avg / 8 + 1);
+            R = R > ST_RMAX ? ST_RMAX : (R < 1 ? 1 : R);
+            uint32_t P = ST_THREADS / (uint32_t)R;
+            P = P > 16 ? 16 : (P < 1 ? 1 : P);
+            cfg[0] = (bb << 8) | qb; cfg[1] = (uint32_t)R; cfg[2] = P;
+        }
+    }
     __syncthreads();
+    const uint32_t win = cfg[0], R = cfg[1], P = cfg[2];
+    const uint32_t qbase = win & 255u, bbase = win >> 8;       // bbase is 64 or 96 (the XOR test below needs a multiple of 32)
 
-    const uint32_t tid = threadIdx.x, lane = lane_id();
     const uint32_t hl = lane & 31;
     const uint32_t hw = (tid >> 6) * 2 + (lane >> 5);       // half-wave index inside the workgroup, 0..7
     constexpr uint32_t NHW = 2 * (ST_THREADS / 64);
     Acc acc;
     const uint64_t ntiles = (n + R - 1) / R;
-    uint32_t rr, pp;                                  // this lane counts groups pp, pp + P, ... of read rr of every tile
-    fast_divmod(tid, P, magicP, rr, pp);
+    const uint32_t rr = tid / P, pp = tid - rr * P;   // this lane counts groups pp, pp + P, ... of read rr of every tile
     const uint32_t q_addlo = 0x01010101u * (0x80u - qbase), q_addhi = 0x01010101u * (0x80u - qbase - ST_NQ);
     const uint32_t b_xor = 0x01010101u * bbase;
 
@@ -279,40 +303,10 @@ extern "C" int uq_stats_accumulate(uq_ctx* ctx, const uint8_t* d_buf, const uint
                                    uint64_t first_read, uint64_t nreads, uq_stats* d_stats) {
     UQ_REQUIRE(ctx && d_buf && d_line_start && d_stats, "uq_stats_accumulate: null argument");
     if (nreads == 0) return 0;
-    // Two host peeks (one sync): the shard's byte range from the index (tile sizing, tail guard) and
-    // the first record's offsets (to place the quality window of the LDS table).
-    uint64_t* tmp = ctx->h_pinned;
-    UQ_CHECK_HIP(hipMemcpyAsync(tmp, d_line_start + 4 * (first_read + nreads), 8, hipMemcpyDeviceToHost, ctx->stream));
-    UQ_CHECK_HIP(hipMemcpyAsync(tmp + 1, d_line_start + 4 * first_read, 40, hipMemcpyDeviceToHost, ctx->stream));
-    UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-    const uint64_t nbytes = tmp[0];
-    const uint64_t q = tmp[4], e = tmp[5];
-    uint32_t qbase = 33, bbase = 64;
-    uint64_t len = e > q + 1 ? e - q - 1 : 0;
-    if (len > 4096) len = 4096;
-    if (len) {
-        uint8_t* qh = (uint8_t*)(tmp + 8);
-        UQ_CHECK_HIP(hipMemcpyAsync(qh, d_buf + q, len, hipMemcpyDeviceToHost, ctx->stream));
-        UQ_CHECK_HIP(hipMemcpyAsync(qh + 4096, d_buf + tmp[2], 1, hipMemcpyDeviceToHost, ctx->stream));   // first base
-        UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-        uint32_t mn = 255;
-        for (uint64_t i = 0; i < len; ++i)
-            if (qh[i] < mn) mn = qh[i];
-        if (mn >= 64) qbase = 59;          // Phred+64 era files: window [59, 123)
-        else if (mn < 33) qbase = 0;
-        if (qh[4096] >= 96) bbase = 96;    // lower-case reads
-    }
-    // tile = R records sized from the average record length so that a typical span fits the staging buffer
-    const uint64_t avg = (nbytes - tmp[1]) / nreads + 1;
-    uint64_t R = (ST_CAP - 64) / (avg + avg / 8 + 1);
-    if (R > ST_RMAX) R = ST_RMAX;
-    if (R < 1) R = 1;
-    const uint64_t ntiles = (nreads + R - 1) / R;
-    uint32_t blocks = (uint32_t)(ntiles < UQ_NUM_CU * 4 ? ntiles : UQ_NUM_CU * 4);
-    uint32_t P = ST_THREADS / (uint32_t)R;
-    if (P > 16) P = 16;
-    if (P < 1) P = 1;
-    stats_kernel<<<blocks, ST_THREADS, 0, ctx->stream>>>(d_buf, nbytes, d_line_start, first_read, nreads, (uint32_t)R, (bbase << 8) | qbase, P, magic_u32(P), d_stats);
+    // No host round trip: tile size and table windows are derived on the device (kernel prologue).  The grid
+    // only needs an upper bound of the tile count (tiles hold >= 1 record); surplus workgroups exit at once.
+    const uint32_t blocks = (uint32_t)(nreads < UQ_NUM_CU * 4 ? nreads : UQ_NUM_CU * 4);
+    stats_kernel<<<blocks, ST_THREADS, 0, ctx->stream>>>(d_buf, d_line_start, first_read, nreads, d_stats);
     UQ_LAUNCH_CHECK();
     return 0;
 }

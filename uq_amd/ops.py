@@ -29,15 +29,24 @@ def index_lines(ctx, buf, nlines):
 
 
 # ------------------------------------------------------------------ pass-1 statistics
+STATS_DTYPE = np.dtype([('counts', np.uint64, (65536,)), ('bad_plus', np.uint64), ('bad_len', np.uint64), ('len_min', np.uint32),
+                        ('len_max', np.uint32), ('max_record_bytes', np.uint32), ('reserved', np.uint32)])    # struct uq_stats
+assert STATS_DTYPE.itemsize == C.sizeof(Stats)
+
+
 class HostStats:
     """Host copy of uq_stats: counts[256][256] + ranges + first bad records."""
 
     def __init__(self, s):
-        self.counts = np.ctypeslib.as_array(s.counts).reshape(256, 256).copy()
-        self.bad_plus = None if s.bad_plus == UQ_NONE else int(s.bad_plus)
-        self.bad_len = None if s.bad_len == UQ_NONE else int(s.bad_len)
-        self.len_min, self.len_max = int(s.len_min), int(s.len_max)
-        self.max_record_bytes = int(s.max_record_bytes)
+        """`s`: a ctypes `Stats` or a numpy record of STATS_DTYPE (same layout)."""
+        if isinstance(s, Stats):
+            s = np.frombuffer(s, dtype=STATS_DTYPE, count=1)[0]
+        self.counts = s['counts'].reshape(256, 256).copy()
+        bad_plus, bad_len = int(s['bad_plus']), int(s['bad_len'])
+        self.bad_plus = None if bad_plus == UQ_NONE else bad_plus
+        self.bad_len = None if bad_len == UQ_NONE else bad_len
+        self.len_min, self.len_max = int(s['len_min']), int(s['len_max'])
+        self.max_record_bytes = int(s['max_record_bytes'])
 
 
 def stats_new(ctx):
@@ -71,9 +80,9 @@ def index_and_stats(ctx, buf, nlines, fused=False):
 
 
 def stats_fetch(ctx, d_stats):
-    s = Stats()
-    call('uq_d2h', ctx.h, C.byref(s), _p(d_stats), C.sizeof(Stats))
-    return HostStats(s)
+    raw = np.empty(1, dtype=STATS_DTYPE)
+    call('uq_d2h', ctx.h, C.c_void_p(raw.ctypes.data), _p(d_stats), raw.nbytes)
+    return HostStats(raw[0])
 
 
 def first_occurrence(ctx, buf, line_start, first_read, nreads, index_base=0):
@@ -87,11 +96,12 @@ def first_occurrence(ctx, buf, line_start, first_read, nreads, index_base=0):
 def make_pack_params(bases, qualities, N_qual, bits_per_base, bits_per_quality, variable,
                      dna_bytes_per_row, quality_bytes_per_row, dna_max, max_record_bytes):
     p = PackParams()
-    for i in range(256):
-        p.dna_code[i] = -1; p.qual_code[i] = -1; p.n_qual[i] = -1
-    for i, ch in enumerate(bases): p.dna_code[ord(ch)] = i
-    for i, ch in enumerate(qualities): p.qual_code[ord(ch)] = i
-    for ch, code in N_qual.items(): p.n_qual[ord(ch)] = int(code)
+    dna_code = np.full(256, -1, dtype=np.int16); qual_code = np.full(256, -1, dtype=np.int16); n_qual = np.full(256, -1, dtype=np.int32)
+    dna_code[np.frombuffer(bases.encode('latin-1'), dtype=np.uint8)] = np.arange(len(bases), dtype=np.int16)
+    qual_code[np.frombuffer(qualities.encode('latin-1'), dtype=np.uint8)] = np.arange(len(qualities), dtype=np.int16)
+    for ch, code in N_qual.items(): n_qual[ord(ch)] = int(code)
+    C.memmove(p.dna_code, dna_code.ctypes.data, 512); C.memmove(p.qual_code, qual_code.ctypes.data, 512)
+    C.memmove(p.n_qual, n_qual.ctypes.data, 1024)
     p.bits_per_base = bits_per_base; p.bits_per_quality = bits_per_quality
     p.variable = 1 if variable else 0
     p.dna_bytes_per_row = dna_bytes_per_row; p.quality_bytes_per_row = quality_bytes_per_row
