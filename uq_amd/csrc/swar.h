@@ -26,7 +26,8 @@ __device__ __forceinline__ uint32_t valid_mask16(int64_t p, uint64_t nbytes) {
 }
 
 // 8 consecutive bytes at LDS byte offset `o` (any alignment, may be slightly negative) as two dwords:
-// three aligned ds_read_b32 + two v_alignbyte.
+// three aligned ds_read_b32 + two v_alignbyte.  (gfx950 accepts an unaligned ds_read_b64 here, but it is
+// much slower: pack 1.11 -> 1.62 ms, stats 0.93 -> 1.24 ms on 10M x 150 bp -- measured, reverted.)
 __device__ __forceinline__ void lds_window8(const uint8_t* base, int32_t o, uint32_t& lo, uint32_t& hi) {
     const uint32_t* p = (const uint32_t*)(base + (o & ~3));
     const uint32_t a = p[0], b = p[1], c = p[2];
