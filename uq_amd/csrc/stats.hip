@@ -105,7 +105,9 @@ __global__ __launch_bounds__(ST_THREADS) void stats_kernel(const uint8_t* __rest
         }
     }
     __syncthreads();
-    const uint32_t win = cfg[0], R = cfg[1], P = cfg[2];
+    // wave-uniform values: keep them in SGPRs (an LDS read lands in a VGPR and would drag all tile arithmetic onto the VALU)
+    const uint32_t win = __builtin_amdgcn_readfirstlane(cfg[0]), R = __builtin_amdgcn_readfirstlane(cfg[1]),
+                   P = __builtin_amdgcn_readfirstlane(cfg[2]);
     const uint32_t qbase = win & 255u, bbase = win >> 8;       // bbase is 64 or 96 (the XOR test below needs a multiple of 32)
 
     const uint32_t hl = lane & 31;
