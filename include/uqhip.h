@@ -188,7 +188,9 @@ int uq_qname_free(uq_qname* q);
  *   c survives the reference's loop  <=>  entry[k] != UQ_NONE and lastviol[k] < entry[k].
  *   min_lcp / min_lcs = lengths of the common prefix / suffix.  flags bit0: some QNAME is a proper prefix or
  *   suffix of line 1 (the reference may raise IndexError there), bit1: a QNAME longer than 255 bytes -- in
- *   both cases use uq_qname_analyse.
+ *   both cases use uq_qname_analyse.  Sharded input: h_line1 is the first QNAME of the WHOLE file,
+ *   read_index_base the file-wide number of this shard's first read (0: the shard starts with line 1 itself, which
+ *   is skipped); entry / lastviol are file-wide read numbers, so ranks combine results with MIN / MAX.
  * uq_qname_tokenise (uq.py:555-565, 717-736): splits QNAME[prefix_len : len - suffix_len] of every read at the
  *   ordered separators and writes, per column c, h_d_vals[c][read] = int(field) (0 if not an integer) and
  *   h_d_strs[c][read] = the field as 8 bytes in text order, zero padded (fields longer than 8 bytes that are
@@ -199,7 +201,8 @@ int uq_qname_free(uq_qname* q);
  *   strips it), bit2 more than 18 digits, bit3 QNAME shorter than prefix + suffix -- any flag: use uq_qname_analyse.
  * uq_prefix_distinct (uq.py:609-625, the `len(map) > entries_read / 10` checkpoints): from a STABLE argsort
  *   (d_perm) and the group ids in sorted order (d_sorted_key; both from uq_unique_rows), the number of distinct
- *   rows among rows [0, T] for each threshold T.
+ *   rows among rows [0, T] for each threshold T.  d_perm holds, per sorted position, the file-order index of that
+ *   row as uint32 (perm_itemsize 4: the local argsort) or uint64 (8: file-wide indices after a distributed sort).
  * uq_encode_int (uq.py:724-733): d_out[i] = (unsigned itemsize)(d_val[i] - sub). */
 typedef struct uq_qname_layout_result {
     uint32_t min_lcp, min_lcs;
@@ -216,12 +219,12 @@ typedef struct uq_qname_cols_result {
     uint32_t flags;
     uint32_t reserved;
 } uq_qname_cols_result;
-int uq_qname_layout(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start, uint64_t nreads,
+int uq_qname_layout(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start, uint64_t nreads, uint64_t read_index_base,
                     const uint8_t* h_line1, uint32_t line1_len, uq_qname_layout_result* h_out);
 int uq_qname_tokenise(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start, uint64_t nreads, uint32_t prefix_len,
                       uint32_t suffix_len, const uint8_t* h_separators, uint32_t nsep, int64_t* const* h_d_vals,
                       uint64_t* const* h_d_strs, uq_qname_cols_result* h_out);
-int uq_prefix_distinct(uq_ctx* ctx, const uint32_t* d_perm, const uint32_t* d_sorted_key, uint64_t n,
+int uq_prefix_distinct(uq_ctx* ctx, const void* d_perm, int perm_itemsize, const uint32_t* d_sorted_key, uint64_t n,
                        const uint64_t* h_thresholds, int nthresholds, uint64_t* h_counts);
 int uq_encode_int(uq_ctx* ctx, const int64_t* d_val, uint64_t n, int64_t sub, int itemsize, void* d_out);
 

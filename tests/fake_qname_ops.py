@@ -13,12 +13,29 @@ NONE = (1 << 64) - 1
 
 class FakeCtx:
     torch = torch
+    device = torch.device('cpu')
 
     @staticmethod
     def to_numpy(t, dtype=None, shape=None):
         a = t.detach().cpu().numpy()
         if dtype is not None: a = a.view(dtype)
         return a
+
+    @staticmethod
+    def empty(n, dtype=None):
+        return torch.empty(int(n), dtype=dtype or torch.uint8)
+
+
+def gather_rows(ctx, table, table_rows, cols, index, n_out=None, out=None):
+    t = table.numpy().view(np.uint8).reshape(table_rows, cols)
+    idx = index.numpy().astype(np.int64) & 0xFFFFFFFF if index.dtype == torch.int32 else index.numpy().astype(np.int64)
+    return torch.from_numpy(np.ascontiguousarray(t[idx]).reshape(-1))
+
+
+def lower_bound_rows(ctx, sorted_table, rows, cols, probes, nprobes):
+    import bisect
+    keys = [bytes(r) for r in sorted_table.numpy().view(np.uint8).reshape(rows, cols)]
+    return torch.tensor([bisect.bisect_left(keys, bytes(p)) for p in probes.numpy().view(np.uint8).reshape(nprobes, cols)], dtype=torch.int64)
 
 
 def _names(buf, ls, n):
@@ -27,7 +44,7 @@ def _names(buf, ls, n):
     return [b[int(o[4 * i]):int(o[4 * i + 1]) - 1] for i in range(n)]
 
 
-def qname_layout(ctx, buf, ls, n, line1):
+def qname_layout(ctx, buf, ls, n, line1, read_index_base=0):
     names = _names(buf, ls, n)
     chars = []
     for c in line1:
@@ -39,8 +56,9 @@ def qname_layout(ctx, buf, ls, n, line1):
                               entry=[NONE] * 64, lastviol=[0] * 64)
     lastpos = [line1.rindex(bytes([c])) for c in chars]
     cnt1 = [line1.count(bytes([c])) for c in chars]
-    for i in range(1, n):
-        q = names[i]
+    for li in range(1 if read_index_base == 0 else 0, n):
+        q = names[li]
+        i = read_index_base + li
         if len(q) > 255:
             r.flags |= 2; continue
         m = min(len(q), len(line1))

@@ -134,6 +134,69 @@ def test_allreduce_stats_struct():
         assert o == dict(c=30, c2=2, bp=1007, bl=(1 << 64) - 1, lmin=36, lmax=101, rmax=500)
 
 
+def _qname_cases():
+    from uq_amd import synth
+    cases = {'illumina': synth.fastq(6, 25000, 8)}
+    # checkpoint demotions at 10 000 / 20 000 reads land in different shards; a mapping column of strings
+    names = []
+    for i in range(23000):
+        b = i % 1000 if i <= 10000 else i % 2001
+        names.append(b'@q:%d:%d:%s/%d' % ((i % 1001) * 3, b * 1000, [b'x', b'yy', b'zzz'][i % 3], 1 + i % 2))
+    cases['checkpoints'] = b''.join(n + b'\nACGT\n+\nIIII\n' for n in names)
+    cases['strings'] = b''.join(b'@q:%d:%s\nA\n+\nI\n' % (i % 7, b'abc' if i == 11000 else b'%d' % i) for i in range(12000))   # refused
+    cases['nosep'] = b''.join(b'@r%d\nA\n+\nI\n' % (i % 10) for i in range(50))                                               # refused (Q13)
+    return cases
+
+
+def _qname_job(rank, world):
+    import fake_qname_ops as F
+    import oracle_c
+    from uq_amd import qname, qname_device
+    qname_device.ops = F
+    out = {}
+    for name, fq in _qname_cases().items():
+        host = np.frombuffer(fq, dtype=np.uint8)
+        ls = oracle_c.index_lines(host)
+        n = (len(ls) - 1) // 4
+        lo, hi = uqdist.shard_range(n, rank, world)
+        b0, b1 = int(ls[4 * lo]), int(ls[4 * hi])
+        buf = torch.from_numpy(host[b0:b1].copy())
+        lls = torch.from_numpy((ls[4 * lo:4 * hi + 1] - b0).astype(np.uint64).view(np.int64).copy())
+        shard = uqdist.Shard(NumpyRows(), lo, n)
+        try:
+            res = qname_device.analyse_device(F.FakeCtx(), buf, lls, hi - lo, shard)
+        except qname.QnameError as e:
+            out[name] = ('error', str(e)); continue
+        if res is None:
+            out[name] = ('declined',); continue
+        pre, suf, sep, cols, arrs = res
+        out[name] = ('ok', pre, suf, sep, cols, [a.numpy().view(np.dtype(c['dtype'])).copy() for a, c in zip(arrs, cols)])
+    return out
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_qname_passes_match_oracle(world):
+    """The device QNAME path over shards (MIN/MAX/SUM of its reductions + a distributed sort of the field keys for
+    the distinct counts) reaches the single-process oracle's answer -- or its refusal -- on every rank."""
+    import uq_oracle as O
+    outs = _run(world, _qname_job)
+    for name, fq in _qname_cases().items():
+        lines = O.read_lines(fq)
+        try:
+            p1 = O.pass1(lines)
+            ocols = O.qname_columns(lines, p1['prefix'], p1['suffix'], p1['separators'])
+            oarr = O.qname_encode(lines, p1['prefix'], p1['suffix'], p1['separators'], ocols)
+        except O.UqError:
+            assert all(o[name][0] == 'error' for o in outs), name
+            continue
+        assert all(o[name][0] == 'ok' for o in outs), (name, [o[name][:1] for o in outs])
+        for o in outs:
+            assert o[name][1:4] == (p1['prefix'], p1['suffix'], p1['separators']) and o[name][4] == ocols
+        for c in range(len(ocols)):
+            got = np.concatenate([o[name][5][c] for o in outs])
+            assert got.dtype == oarr[c].dtype and np.array_equal(got, oarr[c]), (name, c)
+
+
 def test_shard_ranges_cover():
     for total in (0, 1, 7, 1000):
         for world in (1, 2, 3, 8):

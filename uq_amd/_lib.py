@@ -96,9 +96,9 @@ SIGNATURES = {
     'uq_qname_json': [_vp, _P(C.c_char_p)],
     'uq_qname_column': [_vp, _int, _vp, _u64],
     'uq_qname_free': [_vp],
-    'uq_qname_layout': [_vp, _vp, _vp, _u64, _vp, _u32, _P(QnameLayoutResult)],
+    'uq_qname_layout': [_vp, _vp, _vp, _u64, _u64, _vp, _u32, _P(QnameLayoutResult)],
     'uq_qname_tokenise': [_vp, _vp, _vp, _u64, _u32, _u32, _vp, _u32, _P(_vp), _P(_vp), _P(QnameColsResult)],
-    'uq_prefix_distinct': [_vp, _vp, _vp, _u64, _P(_u64), _int, _P(_u64)],
+    'uq_prefix_distinct': [_vp, _vp, _int, _vp, _u64, _P(_u64), _int, _P(_u64)],
     'uq_encode_int': [_vp, _vp, _u64, C.c_int64, _int, _vp],
     'uq_emit_fastq': [_vp, _P(EmitParams), _P(_vp), _P(_vp), _P(_vp), _vp, _vp, _vp, _u64, _vp, _vp, _u64, _P(_u64)],
     'uq_synth_size': [_vp, _P(SynthSpec), _u64, _u64, _P(_u64)],

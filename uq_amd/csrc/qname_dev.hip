@@ -39,10 +39,9 @@ struct LayoutOut {                  // device + host mirror
     uint8_t ch[QN_MAXCH];
 };
 
-__device__ __forceinline__ uint32_t ld_u32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
-
 __global__ __launch_bounds__(QN_THREADS) void qname_layout_kernel(const uint8_t* __restrict__ buf, const uint64_t* __restrict__ ls,
-                                                                   uint64_t n, Line1 l1, LayoutOut* __restrict__ out) {
+                                                                   uint64_t n, uint64_t index_base, uint32_t start, Line1 l1,
+                                                                   LayoutOut* __restrict__ out) {
     __shared__ uint8_t cnt[QN_MAXCH * QN_THREADS];      // per-lane character counters, slot-major (no bank conflicts)
     __shared__ uint8_t s_slot[256];
     __shared__ uint8_t s_text[256];
@@ -55,9 +54,10 @@ __global__ __launch_bounds__(QN_THREADS) void qname_layout_kernel(const uint8_t*
     for (uint32_t k = 0; k < l1.nch; ++k) cnt[k * QN_THREADS + tid] = 0;
     __syncthreads();
     const uint64_t stride = (uint64_t)gridDim.x * QN_THREADS;
-    for (uint64_t i = (uint64_t)blockIdx.x * QN_THREADS + tid + 1; i < n; i += stride) {
-        const uint8_t* q = buf + ls[4 * i];
-        const uint32_t ql = (uint32_t)(ls[4 * i + 1] - ls[4 * i] - 1);
+    for (uint64_t li = (uint64_t)blockIdx.x * QN_THREADS + tid + start; li < n; li += stride) {
+        const uint64_t i = index_base + li;           // record number in the whole file (shards: SURVEY.md 8e)
+        const uint8_t* q = buf + ls[4 * li];
+        const uint32_t ql = (uint32_t)(ls[4 * li + 1] - ls[4 * li] - 1);
         if (ql > 255) { atomicOr(&s_flags, 2u); continue; }
         const uint32_t m = ql < l1.len ? ql : l1.len;
         uint32_t lcp = 0;
@@ -180,7 +180,8 @@ __global__ __launch_bounds__(QN_THREADS) void qname_tokenise_kernel(const uint8_
 }
 
 // number of groups (runs of equal sorted keys) whose FIRST member in file order has index <= T_k
-__global__ __launch_bounds__(QN_THREADS) void prefix_distinct_kernel(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ skey, uint64_t n,
+template <typename IDX>
+__global__ __launch_bounds__(QN_THREADS) void prefix_distinct_kernel(const IDX* __restrict__ perm, const uint32_t* __restrict__ skey, uint64_t n,
                                                                      const unsigned long long* __restrict__ th, int nth,
                                                                      unsigned long long* __restrict__ counts) {
     __shared__ uint32_t s_cnt[64];
@@ -210,9 +211,9 @@ uint32_t grid_for(uint64_t n) {
 }
 }  // namespace
 
-extern "C" int uq_qname_layout(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start, uint64_t nreads,
+extern "C" int uq_qname_layout(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start, uint64_t nreads, uint64_t read_index_base,
                                const uint8_t* h_line1, uint32_t line1_len, uq_qname_layout_result* h_out) {
-    UQ_REQUIRE(ctx && d_buf && d_line_start && h_line1 && h_out, "uq_qname_layout: null argument");
+    UQ_REQUIRE(ctx && h_line1 && h_out && (nreads == 0 || (d_buf && d_line_start)), "uq_qname_layout: null argument");
     UQ_REQUIRE(line1_len >= 1 && line1_len <= 255, "uq_qname_layout: first QNAME line must be 1..255 bytes");
     static_assert(sizeof(uq_qname_layout_result) == sizeof(LayoutOut), "layout result mirrors differ");
     Line1 l1;
@@ -235,8 +236,10 @@ extern "C" int uq_qname_layout(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t
     init.min_lcp = line1_len; init.min_lcs = line1_len;
     for (int k = 0; k < QN_MAXCH; ++k) init.entry[k] = UQ_NONE;
     UQ_CHECK_HIP(hipMemcpyAsync(scr, &init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
-    if (nreads > 1) {
-        qname_layout_kernel<<<grid_for(nreads - 1), QN_THREADS, 0, ctx->stream>>>(d_buf, d_line_start, nreads, l1, (LayoutOut*)scr);
+    const uint32_t start = read_index_base == 0 ? 1u : 0u;      // read 0 of the file is line 1 itself
+    if (nreads > start) {
+        qname_layout_kernel<<<grid_for(nreads - start), QN_THREADS, 0, ctx->stream>>>(d_buf, d_line_start, nreads, read_index_base, start, l1,
+                                                                                     (LayoutOut*)scr);
         UQ_LAUNCH_CHECK();
     }
     UQ_CHECK_HIP(hipMemcpyAsync(h_out, scr, sizeof(LayoutOut), hipMemcpyDeviceToHost, ctx->stream));
@@ -249,7 +252,7 @@ extern "C" int uq_qname_layout(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t
 extern "C" int uq_qname_tokenise(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start, uint64_t nreads, uint32_t prefix_len,
                                  uint32_t suffix_len, const uint8_t* h_separators, uint32_t nsep, int64_t* const* h_d_vals,
                                  uint64_t* const* h_d_strs, uq_qname_cols_result* h_out) {
-    UQ_REQUIRE(ctx && d_buf && d_line_start && h_separators && h_d_vals && h_d_strs && h_out, "uq_qname_tokenise: null argument");
+    UQ_REQUIRE(ctx && h_separators && h_d_vals && h_d_strs && h_out && (nreads == 0 || (d_buf && d_line_start)), "uq_qname_tokenise: null argument");
     UQ_REQUIRE(nsep >= 1 && nsep < QN_MAXCOLS, "uq_qname_tokenise: 1..31 separators supported");
     static_assert(sizeof(uq_qname_cols_result) == sizeof(ColsOut), "column result mirrors differ");
     Split sp;
@@ -280,9 +283,10 @@ extern "C" int uq_qname_tokenise(uq_ctx* ctx, const uint8_t* d_buf, const uint64
     return 0;
 }
 
-extern "C" int uq_prefix_distinct(uq_ctx* ctx, const uint32_t* d_perm, const uint32_t* d_sorted_key, uint64_t n,
+extern "C" int uq_prefix_distinct(uq_ctx* ctx, const void* d_perm, int perm_itemsize, const uint32_t* d_sorted_key, uint64_t n,
                                   const uint64_t* h_thresholds, int nthresholds, uint64_t* h_counts) {
     UQ_REQUIRE(ctx && h_thresholds && h_counts && nthresholds >= 1 && nthresholds <= 64, "uq_prefix_distinct: bad argument");
+    UQ_REQUIRE(perm_itemsize == 4 || perm_itemsize == 8, "uq_prefix_distinct: perm_itemsize must be 4 or 8");
     for (int k = 0; k < nthresholds; ++k) h_counts[k] = 0;
     if (n == 0) return 0;
     UQ_REQUIRE(d_perm && d_sorted_key, "uq_prefix_distinct: null buffer");
@@ -293,7 +297,11 @@ extern "C" int uq_prefix_distinct(uq_ctx* ctx, const uint32_t* d_perm, const uin
     UQ_CHECK_HIP(hipMemcpyAsync(d_th, h_thresholds, nthresholds * 8, hipMemcpyHostToDevice, ctx->stream));
     UQ_CHECK_HIP(hipMemsetAsync(d_cnt, 0, 64 * 8, ctx->stream));
     UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));       // h_thresholds may be a temporary of the caller
-    prefix_distinct_kernel<<<grid_for(n), QN_THREADS, 0, ctx->stream>>>(d_perm, d_sorted_key, n, d_th, nthresholds, d_cnt);
+    if (perm_itemsize == 4)
+        prefix_distinct_kernel<uint32_t><<<grid_for(n), QN_THREADS, 0, ctx->stream>>>((const uint32_t*)d_perm, d_sorted_key, n, d_th, nthresholds, d_cnt);
+    else
+        prefix_distinct_kernel<unsigned long long><<<grid_for(n), QN_THREADS, 0, ctx->stream>>>((const unsigned long long*)d_perm, d_sorted_key, n, d_th,
+                                                                                               nthresholds, d_cnt);
     UQ_LAUNCH_CHECK();
     UQ_CHECK_HIP(hipMemcpyAsync(h_counts, d_cnt, nthresholds * 8, hipMemcpyDeviceToHost, ctx->stream));
     UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));

@@ -51,6 +51,12 @@ def allreduce_stats_inplace(t, stats_bytes, read_offset=0):
     """All-reduce the bytes of a `uq_stats` struct (a uint8 tensor on any device) over the process group,
     in place.  `read_offset` = global index of this rank's first read (bad-record indices become global)."""
     nbytes = C.sizeof(Stats)
+    dist, _, world = _world()
+    if dist is not None and stats_bytes.is_cuda and dist.get_backend() == 'gloo':
+        host = stats_bytes.cpu()                      # gloo rehearsal: reduce on the host, copy back
+        allreduce_stats_inplace(t, host, read_offset)
+        stats_bytes.copy_(host)
+        return
     i64 = stats_bytes[:nbytes - nbytes % 8].view(t.int64)
     counts = i64[:65536]
     mins = i64[65536:65538]
@@ -69,6 +75,59 @@ def allreduce_stats(ctx, d_stats, read_offset=0):
     from . import ops
     allreduce_stats_inplace(ctx.torch, d_stats, read_offset)
     return ops.stats_fetch(ctx, d_stats)
+
+
+class Shard:
+    """Where this rank's reads sit in the whole file, and small-control-data collectives over the group
+    (python ints / bytes in, python ints / bytes out: a few hundred bytes per call)."""
+
+    def __init__(self, be, read_offset, total, group=None):
+        self.be, self.read_offset, self.total, self.group = be, int(read_offset), int(total), group
+        self.dist, self.rank, self.world = _world()
+
+    def reduce(self, values, op):
+        """Element-wise all-reduce of signed 64-bit python ints; op in 'min' | 'max' | 'sum'."""
+        values = [int(v) for v in values]
+        if self.world == 1 or not values:
+            return values
+        torch, dist = self.be.torch, self.dist
+        dev = self.be.device if dist.get_backend(self.group) != 'gloo' else 'cpu'
+        t = torch.tensor(values, dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op={'min': dist.ReduceOp.MIN, 'max': dist.ReduceOp.MAX, 'sum': dist.ReduceOp.SUM}[op], group=self.group)
+        return [int(v) for v in t.cpu().tolist()]
+
+    def gather_ints(self, value):
+        """One python int per rank -> list over ranks."""
+        if self.world == 1:
+            return [int(value)]
+        out = [0] * self.world
+        out[self.rank] = int(value)
+        return self.reduce(out, 'sum')
+
+    def gather_bytes(self, data):
+        """One bytes object per rank -> list over ranks."""
+        if self.world == 1:
+            return [bytes(data)]
+        torch, dist = self.be.torch, self.dist
+        lens = self.gather_ints(len(data))
+        cap = max(lens) if lens else 0
+        if cap == 0:
+            return [b''] * self.world
+        dev = self.be.device if dist.get_backend(self.group) != 'gloo' else 'cpu'
+        mine = torch.zeros(cap, dtype=torch.uint8, device=dev)
+        if len(data):
+            mine[:len(data)] = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(dev)
+        allb = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(allb, mine, group=self.group)
+        return [bytes(allb[r][:lens[r]].cpu().numpy().tobytes()) for r in range(self.world)]
+
+    def gather_rows(self, rows_u8):
+        """All-gather of variable-length uint8 device tensors, concatenated in rank order (stays on the device)."""
+        if self.world == 1:
+            return rows_u8
+        torch = self.be.torch
+        parts = exchange_v([rows_u8 for _ in range(self.world)], self.dist, torch, self.be.device, torch.uint8, self.group)
+        return torch.cat(parts)
 
 
 # --------------------------------------------------------------------------- global --sort (SURVEY.md 8e)
@@ -99,6 +158,11 @@ def exchange_v(parts, dist, torch, device, dtype, group=None):
     runs on gloo), after an all-gather of the counts."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    out_device = device
+    if dist.get_backend(group) == 'gloo' and torch.device(device).type != 'cpu':
+        # gloo rehearsal on a GPU box (several ranks sharing one card): stage through the host
+        parts = [p.cpu() for p in parts]
+        device = 'cpu'
     counts = torch.tensor([int(p.numel()) for p in parts], dtype=torch.int64, device=device)
     allc = [torch.empty_like(counts) for _ in range(world)]
     dist.all_gather(allc, counts, group=group)
@@ -112,6 +176,8 @@ def exchange_v(parts, dist, torch, device, dtype, group=None):
         if recv[peer].numel(): ops_.append(dist.P2POp(dist.irecv, recv[peer], peer, group))
     if ops_:
         for req in dist.batch_isend_irecv(ops_): req.wait()
+    if out_device != device:
+        recv = [r.to(out_device) for r in recv]
     return recv
 
 
@@ -134,10 +200,13 @@ def global_sort_rows(be, table, rows, cols, read_offset, group=None, samples_per
     rank, arrive grouped by source rank, and the final local sort is stable)."""
     dist, rank, world = _world()
     torch = be.torch
-    perm = be.argsort_rows(table, rows, cols)
-    local_sorted = be.gather_rows(table, rows, cols, perm)
-    gidx = perm.to(torch.int64) & 0xFFFFFFFF
-    gidx += int(read_offset)
+    if rows:
+        perm = be.argsort_rows(table, rows, cols)
+        local_sorted = be.gather_rows(table, rows, cols, perm)
+        gidx = perm.to(torch.int64) & 0xFFFFFFFF
+        gidx += int(read_offset)
+    else:                                   # an empty shard still takes part in the exchange
+        local_sorted, gidx = table, torch.empty(0, dtype=torch.int64, device=be.device)
     if world == 1:
         return dict(table=local_sorted, rows=rows, gidx=gidx, offset=0)
     # 1. samples -> splitters (identical on every rank)
@@ -166,11 +235,48 @@ def global_sort_rows(be, table, rows, cols, read_offset, group=None, samples_per
         oidx = be.gather_rows(midx.view(torch.uint8), m, 8, perm2).view(torch.int64)
     else:
         out, oidx = merged, midx
-    counts = torch.tensor([m], dtype=torch.int64, device=be.device)
+    counts = torch.tensor([m], dtype=torch.int64, device='cpu' if dist.get_backend(group) == 'gloo' else be.device)
     allm = [torch.empty_like(counts) for _ in range(world)]
     dist.all_gather(allm, counts, group=group)
     offset = sum(int(allm[r].item()) for r in range(rank))
     return dict(table=out, rows=m, gidx=oidx, offset=offset)
+
+
+def _route_by_owner(be, shard_starts, gidx, world):
+    """Sort file-wide row numbers by owning rank: (order, sorted gidx, bounds per destination rank)."""
+    torch = be.torch
+    n = int(gidx.numel())
+    starts = torch.tensor(list(shard_starts), dtype=torch.int64, device=be.device)
+    owner = (torch.bucketize(gidx, starts[1:-1], right=True)).to(torch.uint8)          # plumbing on indices only
+    order = be.argsort_rows(owner, n, 1) if n else torch.empty(0, dtype=torch.int32, device=be.device)
+    sorted_idx = be.gather_rows(gidx.view(torch.uint8), n, 8, order).view(torch.int64) if n else gidx
+    sorted_owner = be.gather_rows(owner, n, 1, order) if n else owner
+    probes = torch.arange(1, world, dtype=torch.uint8, device=be.device)
+    cuts = be.lower_bound_rows(sorted_owner, n, 1, probes, world - 1).cpu().tolist() if n else [0] * (world - 1)
+    return order, sorted_idx, [0] + [int(c) for c in cuts] + [n]
+
+
+def dist_scatter_rows(be, values, cols, shard_starts, gidx, group=None):
+    """The inverse of dist_gather_rows: `values` (len(gidx) rows of `cols` bytes) are rows of a file-ordered
+    global table at row numbers `gidx`; every rank receives the rows it owns and returns them in file order
+    (uint8 tensor, rows = its shard size).  Every global row must be sent exactly once over all ranks."""
+    dist, rank, world = _world()
+    torch = be.torch
+    n = int(gidx.numel())
+    mine = int(shard_starts[rank + 1]) - int(shard_starts[rank])
+    if world == 1:
+        inv = torch.empty(n, dtype=torch.int32, device=be.device)
+        inv[gidx - int(shard_starts[0])] = torch.arange(n, dtype=torch.int32, device=be.device)
+        return be.gather_rows(values, n, cols, inv) if n else values
+    order, sorted_idx, bounds = _route_by_owner(be, shard_starts, gidx, world)
+    sorted_vals = be.gather_rows(values, n, cols, order) if n else values
+    ridx = torch.cat(exchange_v([sorted_idx[bounds[d]:bounds[d + 1]] for d in range(world)], dist, torch, be.device, torch.int64, group))
+    rval = torch.cat(exchange_v([sorted_vals[bounds[d] * cols:bounds[d + 1] * cols] for d in range(world)], dist, torch, be.device, torch.uint8, group))
+    if int(ridx.numel()) != mine:
+        raise RuntimeError('dist_scatter_rows: received %d rows for a shard of %d' % (int(ridx.numel()), mine))
+    inv = torch.empty(mine, dtype=torch.int32, device=be.device)
+    inv[ridx - int(shard_starts[rank])] = torch.arange(mine, dtype=torch.int32, device=be.device)
+    return be.gather_rows(rval, mine, cols, inv) if mine else rval
 
 
 def dist_gather_rows(be, table, rows, cols, shard_starts, gidx, group=None):

@@ -1,0 +1,326 @@
+"""Sharded encode: one process per GPU, every rank encodes a contiguous range of reads and all ranks write
+one `.uQ` file together (BASELINE configs[3] is this with `--sort QUAL --raw DNA QUAL QNAME`).
+
+    python -m torch.distributed.run --nproc-per-node N -m uq_amd.dist_encode -i reads.fastq [uq flags]
+
+The result is byte-for-byte the file the single-GPU CLI writes (members and config; tar mtimes aside):
+  load      each rank streams its byte range of the file (+ slack) to HBM; an all-gather of the number of line
+            starts per range tells every rank where its first record begins
+  pass 1    local `uq_stats`, all-reduced (two collectives) -> identical decisions everywhere
+  QNAME     the device QNAME passes over shards (uq_amd.qname_device with a `Shard`)
+  pass 3    local pack
+  tables    `--sort`: sample sort over the ranks (dist.global_sort_rows: all-to-all(v) of rows by key range, equal
+            rows never straddle ranks); the other tables follow with dist.dist_gather_rows; unique + key:
+            head flags of the sorted shard, exclusive offset of the group counts, keys returned to file order
+            with dist.dist_scatter_rows
+  write     every member's global size is known after an all-gather of the shard sizes; ranks `pwrite` their
+            pieces into place (pinned staging), rank 0 writes the tar / .npy headers and config.json
+
+Only the exchange steps use the process group (RCCL over xGMI: rows move once, by key range; everything else is
+a few integers).  With the gloo backend device tensors are staged through the host, which is how the CPU box
+rehearses this path with several ranks sharing one GPU (tests/test_gpu_dist.py).
+"""
+import json
+import os
+import sys
+import tarfile
+import time
+
+import numpy as np
+
+from . import dist as uqdist
+from .uq import Session, UqError, build_parser, error, npy_header, pattern_header, validate_args
+
+# pattern id -> (column-major?, rows flipped?, columns flipped?)   (csrc/pattern.hip)
+PATTERN_FLAGS = {'0.1': (0, 0, 0), '0.2': (1, 0, 0), '1.1': (1, 0, 1), '1.2': (0, 0, 1),
+                 '2.1': (0, 1, 1), '2.2': (1, 1, 1), '3.1': (1, 1, 0), '3.2': (0, 1, 0)}
+SLACK = 4 << 20          # bytes read past a rank's range so that its last record is complete
+
+
+class ShardedSession(Session):
+    """`Session` whose tables are shards; members are (header, total payload bytes, [(offset, device bytes)])."""
+
+    def __init__(self, args, ctx=None, out=sys.stdout, group=None):
+        super().__init__(args, ctx=ctx, out=out)
+        self.be = uqdist.HipRows(self.ctx)
+        self.group = group
+        self.dist, self.rank, self.world = uqdist._world()
+        if self.rank != 0: args.quiet = True
+
+    # ------------------------------------------------------------------ load
+    def load(self, path):
+        ops, ctx, t = self.ops, self.ctx, self.ctx.torch
+        size = os.path.getsize(path)
+        if size == 0: error('ERROR: empty input')
+        self.path, self._host = path, None
+        lo, hi = size * self.rank // self.world, size * (self.rank + 1) // self.world
+        a = max(lo - 1, 0)                         # a newline at lo - 1 makes `lo` a line start
+        b = min(size, hi + SLACK)
+        chunk = self.io.file_to_device(path, a, b - a)
+        # line starts inside [lo, hi): one per newline in [lo - 1, hi - 1), plus the start of the file
+        span = max(0, (hi - 1) - a)
+        mine = (ops.count_lines(ctx, chunk[:span]) if span else 0) + (1 if self.rank == 0 else 0)
+        sh = uqdist.Shard(self.be, 0, 0, self.group)
+        per_rank = sh.gather_ints(mine)
+        total_lines = sum(per_rank)
+        if total_lines % 4 != 0:
+            error('ERROR: The FASTQ file provided contains' + str(total_lines) + 'rows, which is not divisible by 4!')
+        if total_lines == 0: error('ERROR: empty input')
+        first_line = sum(per_rank[:self.rank])                     # file-wide number of my first line start
+        j0 = (-first_line) % 4                                     # my first record starts at my j0-th line start
+        n = max(0, -(-(mine - j0) // 4))
+        counts = sh.gather_ints(n)
+        self.total = n
+        self.total_reads = sum(counts)
+        self.read_offset = sum(counts[:self.rank])
+        self.shard_starts = [sum(counts[:r]) for r in range(self.world + 1)]
+        self.shard = uqdist.Shard(self.be, self.read_offset, self.total_reads, self.group)
+        nl = ops.count_lines(ctx, chunk)
+        ls = ops.index_lines(ctx, chunk, nl)                       # ls[k] = chunk offset after the k-th newline, ls[0] = 0
+        k0 = j0 + (0 if self.rank == 0 else 1)
+        if n and k0 + 4 * n > nl:
+            error('ERROR: a record of more than %d bytes straddles a shard boundary' % SLACK)
+        if n:
+            ends = ctx.to_numpy(ls[k0:k0 + 4 * n + 1:4 * n], np.uint64)
+            start, end = int(ends[0]), int(ends[1])
+            self.d_buf = chunk[start:end]
+            self.d_ls = ls[k0:k0 + 4 * n + 1] - start              # index arithmetic only
+        else:
+            self.d_buf, self.d_ls = chunk[:0], t.zeros(1, dtype=t.int64, device=ctx.device)
+        self.d_stats = ops.stats_new(ctx)
+        if n: ops.stats_accumulate(ctx, self.d_stats, self.d_buf, self.d_ls, 0, n)
+
+    # ------------------------------------------------------------------ analysis seams
+    def fetch_stats(self):
+        return uqdist.allreduce_stats(self.ctx, self.d_stats, self.read_offset)
+
+    def starts_with_at(self):
+        flag = 1 if (self.rank != 0 or (self.total and int(self.d_buf[0]) == ord('@'))) else 0
+        return min(self.shard.reduce([flag], 'min')) == 1
+
+    def first_seen(self):
+        fs = self.ops.first_occurrence(self.ctx, self.d_buf, self.d_ls, 0, self.total, index_base=self.read_offset) if self.total \
+            else np.full(256, np.iinfo(np.uint64).max, dtype=np.uint64)
+        big = (1 << 63) - 1
+        red = self.shard.reduce([min(int(v), big) for v in fs], 'min')
+        return np.array([np.iinfo(np.uint64).max if v == big else v for v in red], dtype=np.uint64)
+
+    def reads_in_file(self):
+        return self.total_reads
+
+    def analyse_qname(self):
+        from . import qname, qname_device
+        self.qname_path = 'device'
+        res = qname_device.analyse_device(self.ctx, self.d_buf, self.d_ls, self.total, self.shard)
+        if res is None:
+            raise qname.QnameError('ERROR: these QNAMEs need the sequential host passes (see DESIGN.md 2), which the sharded '
+                                   'encoder does not run; encode this file on one GPU')
+        return res
+
+    # ------------------------------------------------------------------ members as pieces
+    def _put(self, name, header, total_bytes, pieces):
+        self.members[name] = (header, int(total_bytes), [(int(o), p) for o, p in pieces if p.numel()])
+
+    def write_pattern_shard(self, table, first_row, rows_total, filename):
+        """write_pattern (uq.py:257-270) for rows [first_row, first_row + n) of a `rows_total`-row table."""
+        args = self.args
+        if args.pattern is None: pattern = '0.1'; args.pattern = ['0.1', '0.1']
+        elif filename.startswith('DNA'): pattern = args.pattern[0]
+        elif filename.startswith('QUAL'): pattern = args.pattern[1]
+        else: error('ERROR: This should never happen!')
+        t, n, cols = table
+        colmajor, fr, _ = PATTERN_FLAGS[pattern]
+        header = pattern_header(rows_total, cols, pattern)
+        if n == 0:
+            return self._put(filename, header, rows_total * cols, [])
+        payload = self.ops.pattern(self.ctx, t, n, cols, pattern)          # the shard's block, same flips applied locally
+        at = (rows_total - first_row - n) if fr else first_row             # where the block's rows sit in the (flipped) row order
+        if not colmajor:
+            pieces = [(at * cols, payload)]
+        else:                                                              # column k of the payload = rows_total bytes; mine are n of them
+            pieces = [(k * rows_total + at, payload[k * n:(k + 1) * n]) for k in range(cols)]
+        self._put(filename, header, rows_total * cols, pieces)
+
+    def write_out_shard(self, tensor, first, total, filename, dtype):
+        """write_out (uq.py:272-274) for entries [first, first + len) of a 1-D member of `total` entries."""
+        isz = np.dtype(dtype).itemsize
+        self._put(filename, npy_header((total,), False, dtype), total * isz,
+                  [(first * isz, tensor.contiguous().view(self.ctx.torch.uint8).reshape(-1))])
+
+    # ------------------------------------------------------------------ table builds over shards
+    def _sorted(self, t, n, cols):
+        gs = uqdist.global_sort_rows(self.be, t, n, cols, self.read_offset, self.group)
+        return gs, {'gidx': gs['gidx'], 'offset': gs['offset'], 'rows': gs['rows']}
+
+    def _unique(self, gs, cols):
+        """Head flags of a sorted shard -> (unique rows, count, first global group id, total groups, group id per sorted row)."""
+        ops, ctx, t = self.ops, self.ctx, self.ctx.torch
+        m = gs['rows']
+        if m:
+            _, _, skey, uniq, nu = ops.unique_rows(ctx, gs['table'], m, cols, want_key=False)
+        else:
+            skey, uniq, nu = t.empty(0, dtype=t.int32, device=ctx.device), ctx.empty(0), 0
+        per_rank = self.shard.gather_ints(nu)
+        g0, nu_total = sum(per_rank[:self.rank]), sum(per_rank)
+        g0_bits = g0 - (1 << 32) if g0 >= (1 << 31) else g0      # group ids are u32 bit patterns in an int32 tensor
+        return uniq, nu, g0, nu_total, skey + g0_bits              # index arithmetic only
+
+    def _key_member(self, gs, order, gids, sort_order, isz, name):
+        """The key member: group ids in sorted order (this table is sorted on), in file order, or in another table's order."""
+        ops, ctx, t = self.ops, self.ctx, self.ctx.torch
+        N = self.total_reads
+        if sort_order is False:
+            k, first = gids, order['offset']
+        else:
+            in_file_order = uqdist.dist_scatter_rows(self.be, gids.view(t.uint8), 4, self.shard_starts, gs['gidx'], self.group).view(t.int32)
+            if sort_order is None:
+                k, first = in_file_order, self.read_offset
+            else:
+                k = uqdist.dist_gather_rows(self.be, in_file_order.view(t.uint8), self.total, 4, self.shard_starts, sort_order['gidx'], self.group).view(t.int32)
+                first = sort_order['offset']
+        self.write_out_shard(ops.narrow(ctx, k, isz), first, N, name, self._npdtype(isz))
+
+    def encode_dna_qual(self, sort_order, table_name, raw, test):
+        """uq.py:765-805 over shards.  sort_order: None = no sort, False = compute and return, dict = apply."""
+        if test: error('ERROR: --test is not available in the sharded encoder')
+        ops = self.ops
+        t, n, cols = self.tables[table_name]
+        N = self.total_reads
+        if raw:
+            if sort_order is None:
+                table, first = (t, n, cols), self.read_offset
+            elif sort_order is False:
+                gs, sort_order = self._sorted(t, n, cols)                                        # uq.py:773-777
+                table, first = (gs['table'], gs['rows'], cols), gs['offset']
+            else:
+                g = uqdist.dist_gather_rows(self.be, t, n, cols, self.shard_starts, sort_order['gidx'], self.group)
+                table, first = (g, sort_order['rows'], cols), sort_order['offset']
+            self.write_pattern_shard(table, first, N, table_name + '.raw')
+        else:
+            gs, order = self._sorted(t, n, cols)                                                 # uq.py:784-789
+            uniq, nu, g0, nu_total, gids = self._unique(gs, cols)
+            isz = ops.key_itemsize(nu_total - 1)                                                 # uq.py:790
+            self._key_member(gs, order, gids, sort_order, isz, table_name + '.key')
+            if sort_order is False: sort_order = order                                           # stable order == argsort(key), uq.py:796
+            self.write_pattern_shard((uniq, nu, cols), g0, nu_total, table_name)
+        return sort_order
+
+    def encode_qname(self, sort_order, raw, test):
+        """uq.py:808-851 over shards."""
+        if test: error('ERROR: --test is not available in the sharded encoder')
+        ops, ctx, columns, t = self.ops, self.ctx, self.columns, self.ctx.torch
+        cols_d = self.tables['QNAME']
+        n, N = self.total, self.total_reads
+        common = max(c.element_size() for c in cols_d)
+        ncols = len(cols_d)
+        width = ncols * common
+        if raw:
+            if sort_order is False:
+                rows = ops.stack_columns(ctx, cols_d, common)                                    # uq.py:814-816
+                gs, sort_order = self._sorted(rows, n, width)
+                for idx, column in enumerate(columns):
+                    isz = np.dtype(column['dtype']).itemsize
+                    c = ops.unstack_column(ctx, gs['table'], gs['rows'], ncols, common, idx, isz)
+                    self.write_out_shard(c, gs['offset'], N, column['name'] + '.raw', np.dtype(column['dtype']))
+                return sort_order
+            for idx, column in enumerate(columns):
+                c, first = cols_d[idx], self.read_offset
+                if sort_order is not None:
+                    c = uqdist.dist_gather_rows(self.be, c.view(t.uint8), n, c.element_size(), self.shard_starts, sort_order['gidx'],
+                                                self.group).view(c.dtype)
+                    first = sort_order['offset']
+                self.write_out_shard(c, first, N, column['name'] + '.raw', np.dtype(column['dtype']))
+        else:
+            rows = ops.stack_columns(ctx, cols_d, common)                                        # uq.py:828-830
+            gs, order = self._sorted(rows, n, width)
+            uniq, nu, g0, nu_total, gids = self._unique(gs, width)
+            isz = ops.key_itemsize(nu_total - 1)                                                 # uq.py:832
+            self._key_member(gs, order, gids, sort_order, isz, 'QNAME.key')
+            if sort_order is False: sort_order = order
+            for idx, column in enumerate(columns):                                               # uq.py:845-847
+                col = ops.unstack_column(ctx, uniq, nu, ncols, common, idx, np.dtype(column['dtype']).itemsize)
+                self.write_out_shard(col, g0, nu_total, column['name'], np.dtype(column['dtype']))
+        return sort_order
+
+    def _encode(self, variable):
+        if self.total == 0:                                        # a rank without reads still owns (empty) tables
+            e = self.ctx.empty(0)
+            return ((e, 0, self.d['dna_bytes_per_row']), (e, 0, self.d['quality_bytes_per_row']))
+        return super()._encode(variable)
+
+    # ------------------------------------------------------------------ container
+    def write_container(self, path):
+        """uq.py:897-913 with every rank writing its pieces: the tar layout follows from the member sizes alone."""
+        args = self.args
+        cfg = dict(self.config)
+        cfg['sort'] = args.sort if isinstance(args.sort, str) else [None]
+        cfg['raw'] = sorted(args.raw, key=str) if args.raw else [None]
+        cfg['pattern'] = list(args.pattern) if args.pattern else None
+        self.config = cfg
+        blob = json.dumps(cfg, indent=4, sort_keys=True).encode()
+
+        def order(name):
+            base = name.split('.')[0]
+            if base.startswith('QNAME_'): return (3, int(base[6:]), name)
+            return ({'DNA': 0, 'QUAL': 1, 'QNAME': 2}.get(base, 4), 0, name)
+
+        names = sorted(self.members, key=order)
+        layout, pos = [], 0                         # (name, header bytes, tar header offset, payload offset, size)
+        for name, header, size in [('config.json', blob, 0)] + [(k, self.members[k][0], self.members[k][1]) for k in names]:
+            layout.append((name, header, pos, pos + tarfile.BLOCKSIZE + len(header), len(header) + size))
+            pos += tarfile.BLOCKSIZE + len(header) + size
+            pos += -pos % tarfile.BLOCKSIZE
+        end = pos + 2 * tarfile.BLOCKSIZE
+        end += -end % tarfile.RECORDSIZE
+        tmp = path + '.part'
+        mtime = self.shard.reduce([int(time.time())], 'min')[0]
+        if self.rank == 0:
+            fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+            os.ftruncate(fd, end)                                  # sparse zeros: tar padding and end blocks are already there
+            for name, header, hpos, _, size in layout:
+                ti = tarfile.TarInfo(name); ti.size = size; ti.mtime = mtime
+                os.pwrite(fd, ti.tobuf(tarfile.DEFAULT_FORMAT, tarfile.ENCODING, 'surrogateescape') + header, hpos)
+        self.shard.reduce([0], 'sum')                              # barrier: the file exists at its final size
+        if self.rank != 0:
+            fd = os.open(tmp, os.O_WRONLY)
+        try:
+            for name, _, _, ppos, _ in layout[1:]:
+                for off, piece in self.members[name][2]:
+                    self.io.device_to_fd(piece, fd, ppos + off)
+        finally:
+            os.close(fd)
+        self.shard.reduce([0], 'sum')                              # barrier: all pieces are in place
+        if self.rank == 0:
+            os.replace(tmp, path)
+
+
+def main(argv=None):
+    import torch
+    import torch.distributed as dist
+    args = build_parser().parse_args(argv)
+    rank, world = int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    backend = os.environ.get('UQ_DIST_BACKEND', 'nccl')
+    ngpu = torch.cuda.device_count()
+    device = local_rank % max(ngpu, 1)                             # gloo rehearsal: ranks may share a card
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29541')
+    if backend == 'nccl':
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', device))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    code = 0
+    try:
+        args.device = device
+        validate_args(args)
+        if args.decode: error('ERROR: decode runs on one GPU (python -m uq_amd.uq --decode)')
+        ShardedSession(args).encode()
+    except UqError as e:
+        if rank == 0: print(e)
+        code = 1
+    finally:
+        dist.destroy_process_group()
+    return code
+
+
+if __name__ == '__main__':
+    sys.exit(main())

@@ -210,12 +210,13 @@ def unstack_column(ctx, rows, n, ncols, common_itemsize, col, out_itemsize):
 
 
 # ------------------------------------------------------------------ QNAME passes on the device
-def qname_layout(ctx, buf, line_start, nreads, line1):
-    """`line1`: bytes of the first QNAME line.  Returns the QnameLayoutResult structure."""
+def qname_layout(ctx, buf, line_start, nreads, line1, read_index_base=0):
+    """`line1`: bytes of the first QNAME line of the whole file; `read_index_base`: file-wide number of this
+    shard's first read.  Returns the QnameLayoutResult structure."""
     from ._lib import QnameLayoutResult
     res = QnameLayoutResult()
     l1 = (C.c_uint8 * len(line1)).from_buffer_copy(line1)
-    call('uq_qname_layout', ctx.h, _p(buf), _p(line_start), nreads, l1, len(line1), C.byref(res))
+    call('uq_qname_layout', ctx.h, _p(buf), _p(line_start), nreads, int(read_index_base), l1, len(line1), C.byref(res))
     return res
 
 
@@ -235,9 +236,10 @@ def qname_tokenise(ctx, buf, line_start, nreads, prefix_len, suffix_len, separat
 
 
 def prefix_distinct(ctx, perm, sorted_key, n, thresholds):
+    """`perm`: int32 (local argsort) or int64 (file-wide indices) tensor, one entry per sorted position."""
     th = (C.c_uint64 * len(thresholds))(*thresholds)
     out = (C.c_uint64 * len(thresholds))()
-    call('uq_prefix_distinct', ctx.h, _p(perm), _p(sorted_key), n, th, len(thresholds), out)
+    call('uq_prefix_distinct', ctx.h, _p(perm), perm.element_size(), _p(sorted_key), n, th, len(thresholds), out)
     return list(out)
 
 

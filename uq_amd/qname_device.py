@@ -7,6 +7,10 @@ host, on a handful of numbers per column.  It reproduces the reference only for 
 exactly-characterised subset (ASCII fields, plain decimal integers, separators that are not regex
 metacharacters, ...); outside it `analyse_device` returns None and the caller uses the sequential
 host implementation (`qname.analyse_native` / `qname.analyse`).  The column arrays stay in HBM.
+
+Sharded input (one rank per GPU, `shard` = uq_amd.dist.Shard): every reduction is combined over the
+ranks with MIN / MAX / SUM of a few integers, the distinct counts come from a distributed sort of the
+8-byte field keys, and all ranks reach the same decisions (or the same refusal) from the same numbers.
 """
 import numpy as np
 
@@ -17,6 +21,7 @@ from .qname import QnameError, _LADDER
 # '[' + seps + ']+' and '(.*)'.join(seps) are regexes in the reference: leave their metacharacters to `re`
 REGEX_SPECIAL = frozenset('.^$*+?{}[]\\|()-')
 _STRINGS = 'Encoding QNAMEs as strings has not been implimented yet.'
+_I64_MAX = (1 << 63) - 1
 
 
 def _ladder(x):
@@ -30,9 +35,20 @@ def _fetch_bytes(ctx, d_buf, lo, hi):
     return ctx.to_numpy(d_buf[lo:hi]).tobytes()
 
 
-def infer_layout_device(ctx, d_buf, d_ls, nreads):
+def _min_u64(shard, values):
+    """MIN over ranks of unsigned values where UQ_NONE means 'none' (read numbers stay below 2^63)."""
+    if shard is None or shard.world == 1:
+        return list(values)
+    red = shard.reduce([_I64_MAX if v == UQ_NONE else v for v in values], 'min')
+    return [UQ_NONE if v == _I64_MAX else v for v in red]
+
+
+def infer_layout_device(ctx, d_buf, d_ls, nreads, shard=None):
     """uq.py:348-352, 394-413, 428-444 -> (prefix, suffix, separators) as latin-1 strings, or None."""
-    head = _fetch_bytes(ctx, d_buf, 0, min(257, d_buf.numel()))
+    base = shard.read_offset if shard else 0
+    head = _fetch_bytes(ctx, d_buf, 0, min(257, d_buf.numel())) if nreads else b''
+    if shard is not None:
+        head = shard.gather_bytes(head if shard.rank == 0 else b'')[0]        # line 1 of the whole file
     nl = head.find(b'\n')
     if nl < 0:
         return None
@@ -42,18 +58,25 @@ def infer_layout_device(ctx, d_buf, d_ls, nreads):
     if len(line1) > 255:
         return None
     try:
-        res = ops.qname_layout(ctx, d_buf, d_ls, nreads, line1)
+        res = ops.qname_layout(ctx, d_buf, d_ls, nreads, line1, base)
     except UqHipError:
         return None                      # more than 64 distinct characters in line 1
-    if res.flags:
+    nch = res.nch
+    flags, plen, slen = res.flags, res.min_lcp, res.min_lcs
+    entry, lastviol = list(res.entry[:nch]), list(res.lastviol[:nch])
+    if shard is not None and shard.world > 1:
+        plen, slen = shard.reduce([plen, slen], 'min')
+        red = shard.reduce([flags] + lastviol, 'max')
+        flags, lastviol = red[0], red[1:]
+        entry = _min_u64(shard, entry)
+    if flags:
         return None
-    plen, slen = res.min_lcp, res.min_lcs
     l1 = line1.decode('latin-1')
     prefix = l1[:plen]
     suffix = l1[len(l1) - slen:] if slen else ''
     seps = set()
-    for k in range(res.nch):
-        if res.entry[k] != UQ_NONE and res.lastviol[k] < res.entry[k]:
+    for k in range(nch):
+        if entry[k] != UQ_NONE and lastviol[k] < entry[k]:
             c = chr(res.ch[k])
             if l1[plen:].count(c) - suffix.count(c) != 0:
                 seps.add(c)
@@ -62,8 +85,13 @@ def infer_layout_device(ctx, d_buf, d_ls, nreads):
                          'files either (SURVEY.md Q13)')
     if seps & REGEX_SPECIAL or plen + slen > len(l1):
         return None
-    o = ctx.to_numpy(d_ls[4 * (nreads - 1):4 * (nreads - 1) + 2], np.uint64)
-    last = _fetch_bytes(ctx, d_buf, int(o[0]), int(o[1]) - 1).decode('latin-1')
+    last = b''
+    if nreads:
+        o = ctx.to_numpy(d_ls[4 * (nreads - 1):4 * (nreads - 1) + 2], np.uint64)
+        last = _fetch_bytes(ctx, d_buf, int(o[0]), int(o[1]) - 1)
+    if shard is not None:
+        last = [b for b in shard.gather_bytes(last + b'\n') if b][-1][:-1]   # the last QNAME of the whole file
+    last = last.decode('latin-1')
 
     def order_seps(q):
         return ''.join(ch for ch in q[plen:-1 - slen] if ch in seps)
@@ -77,13 +105,44 @@ def infer_layout_device(ctx, d_buf, d_ls, nreads):
     return prefix, suffix, separators
 
 
-def type_and_encode_device(ctx, d_buf, d_ls, nreads, prefix, suffix, separators):
+def _distinct_counts(ctx, keys, n, thresholds, shard):
+    """-> (distinct-count among reads [0, T] for each T, number of distinct keys, key codes tensor or None,
+    sorted unique rows tensor [nu * 8]).  Codes (rank of each read's key) are only produced on one GPU;
+    sharded callers look them up in the gathered unique table."""
+    if shard is None or shard.world == 1:
+        perm, key, skey, uniq, nu = ops.unique_rows(ctx, keys, n, 8)
+        return ops.prefix_distinct(ctx, perm, skey, n, thresholds), nu, key, uniq
+    from .dist import global_sort_rows
+    gs = global_sort_rows(shard.be, keys.view(ctx.torch.uint8), n, 8, shard.read_offset, shard.group)
+    m = gs['rows']
+    counts, nu, uniq = [0] * len(thresholds), 0, ctx.empty(0)
+    if m:
+        perm, _, skey, uniq, nu = ops.unique_rows(ctx, gs['table'], m, 8, want_key=False)
+        first = ops.gather_rows(ctx, gs['gidx'].view(ctx.torch.uint8), m, 8, perm).view(ctx.torch.int64)   # file-wide read numbers
+        counts = ops.prefix_distinct(ctx, first, skey, m, thresholds)
+    red = shard.reduce(counts + [nu], 'sum')       # equal keys all live on one rank: counts simply add up
+    return red[:-1], red[-1], None, shard.gather_rows(uniq)
+
+
+def type_and_encode_device(ctx, d_buf, d_ls, nreads, prefix, suffix, separators, shard=None):
     """uq.py:555-678 + 717-736 -> (columns, device column tensors) or None."""
-    n = nreads
-    vals, strs, res = ops.qname_tokenise(ctx, d_buf, d_ls, n, len(prefix), len(suffix), separators.encode('latin-1'))
-    if res.flags:
-        return None
+    n_local = nreads
+    n = shard.total if shard else nreads                     # reads in the whole file
+    base = shard.read_offset if shard else 0
+    vals, strs, res = ops.qname_tokenise(ctx, d_buf, d_ls, n_local, len(prefix), len(suffix), separators.encode('latin-1'))
     ncols = len(separators) + 1
+    flags = res.flags
+    first_nonint = [UQ_NONE if res.first_nonint[c] == UQ_NONE else res.first_nonint[c] + base for c in range(ncols)]
+    vmins, vmaxs = list(res.vmin[:ncols]), list(res.vmax[:ncols])
+    long_bad = [res.any_long[c] & 1 for c in range(ncols)]
+    long_int = [(res.any_long[c] >> 1) & 1 for c in range(ncols)]
+    if shard is not None and shard.world > 1:
+        red = shard.reduce([flags] + vmaxs + long_bad + long_int, 'max')
+        flags, vmaxs, long_bad, long_int = red[0], red[1:1 + ncols], red[1 + ncols:1 + 2 * ncols], red[1 + 2 * ncols:]
+        vmins = shard.reduce(vmins, 'min')
+        first_nonint = _min_u64(shard, first_nonint)
+    if flags:
+        return None
     thresholds = []
     t = 10000
     while t <= n - 1:
@@ -92,17 +151,15 @@ def type_and_encode_device(ctx, d_buf, d_ls, nreads, prefix, suffix, separators)
         thresholds.append(n - 1)
     columns, arrays = [], []
     for c in range(ncols):
-        if res.any_long[c] & 1:
+        if long_bad[c]:
             return None
         col = {'name': 'QNAME_%d' % (c + 1), 'format': 'mapping'}
-        first_nonint = res.first_nonint[c]
-        all_int = first_nonint == UQ_NONE
-        vmin, vmax = res.vmin[c], res.vmax[c]
-        perm, key, skey, uniq, nu = ops.unique_rows(ctx, strs[c], n, 8)
-        counts = ops.prefix_distinct(ctx, perm, skey, n, thresholds)
+        all_int = first_nonint[c] == UQ_NONE
+        vmin, vmax = vmins[c], vmaxs[c]
+        counts, nu, key, uniq = _distinct_counts(ctx, strs[c], n_local, thresholds, shard)
         for T, cnt in zip(thresholds, counts):
             if cnt > T // 10:                               # check_format(): mapping -> integers
-                if first_nonint <= T or not all_int:
+                if not all_int:
                     raise QnameError(_STRINGS)
                 col['format'] = 'integers'
                 break
@@ -113,7 +170,7 @@ def type_and_encode_device(ctx, d_buf, d_ls, nreads, prefix, suffix, separators)
                 col['format'] = 'integers'; col['max'] = vmax; col['min'] = vmin
                 col['offset'] = bool(vmin < 0 or vmax > lim)
             else:
-                if res.any_long[c] & 2:
+                if long_int[c]:
                     return None                             # sorted map of strings longer than the 8-byte key
                 rows = ctx.to_numpy(uniq).reshape(nu, 8)
                 col['map'] = [s.decode('latin-1') for s in np.ascontiguousarray(rows).view('S8').ravel().tolist()]
@@ -124,6 +181,8 @@ def type_and_encode_device(ctx, d_buf, d_ls, nreads, prefix, suffix, separators)
             col['offset'] = bool(vmin < 0 or vmax > lim)
         isz = np.dtype(col['dtype']).itemsize
         if col['format'] == 'mapping':
+            if key is None:                                 # sharded: rank of each key in the gathered sorted map
+                key = ops.lower_bound_rows(ctx, uniq, nu, 8, strs[c], n_local).to(ctx.torch.int32)
             arrays.append(ops.narrow(ctx, key, isz))
         else:
             arrays.append(ops.encode_int(ctx, vals[c], col['min'] if col['offset'] else 0, isz))
@@ -132,13 +191,13 @@ def type_and_encode_device(ctx, d_buf, d_ls, nreads, prefix, suffix, separators)
     return columns, arrays
 
 
-def analyse_device(ctx, d_buf, d_ls, nreads):
+def analyse_device(ctx, d_buf, d_ls, nreads, shard=None):
     """(prefix, suffix, separators, columns, device column tensors), or None -> use the host path."""
-    lay = infer_layout_device(ctx, d_buf, d_ls, nreads)
+    lay = infer_layout_device(ctx, d_buf, d_ls, nreads, shard)
     if lay is None:
         return None
     prefix, suffix, separators = lay
-    out = type_and_encode_device(ctx, d_buf, d_ls, nreads, prefix, suffix, separators)
+    out = type_and_encode_device(ctx, d_buf, d_ls, nreads, prefix, suffix, separators, shard)
     if out is None:
         return None
     return prefix, suffix, separators, out[0], out[1]

@@ -142,6 +142,19 @@ class Session:
             self._host = np.fromfile(self.path, dtype=np.uint8)
         return self._host
 
+    # small seams the sharded session (uq_amd/dist_encode.py) overrides
+    def fetch_stats(self):
+        return self.ops.stats_fetch(self.ctx, self.d_stats)
+
+    def starts_with_at(self):
+        return int(self.d_buf[0]) == ord('@')
+
+    def first_seen(self):
+        return self.ops.first_occurrence(self.ctx, self.d_buf, self.d_ls, 0, self.total)
+
+    def reads_in_file(self):
+        return self.total
+
     def analyse_qname(self):
         """QNAME passes 1 / 2 / 4: per-read work on the device (qname_device), or -- for QNAMEs outside the
         subset that path reproduces exactly, and with --host-qname -- sequentially on the host."""
@@ -160,16 +173,15 @@ class Session:
     def analyse(self):
         """Pass 1 (histogram, lengths, QNAME layout), the N-trick / width decisions, pass 2 (QNAME typing)."""
         from . import analysis, qname
-        ops, ctx, args = self.ops, self.ctx, self.args
-        hs = ops.stats_fetch(ctx, self.d_stats)
-        if int(self.d_buf[0]) != ord('@'): error('ERROR: This does not look like a FASTA/FASTQ file! (first line does not start with @)')
+        args = self.args
+        hs = self.fetch_stats()
+        if not self.starts_with_at(): error('ERROR: This does not look like a FASTA/FASTQ file! (first line does not start with @)')
         if hs.bad_plus is not None:
             error('ERROR: For entry' + str(hs.bad_plus) + 'the third line does not start with +')
         if hs.bad_len is not None:
             error('ERROR: Length of DNA does not match the length of the quality scores for entry ' + str(hs.bad_len))
         self.hs = hs
-        first_seen = lambda: ops.first_occurrence(ctx, self.d_buf, self.d_ls, 0, self.total)
-        d = analysis.decide_from_counts(hs.counts, hs.len_min, hs.len_max, notricks=args.notricks, pad=args.pad, first_seen=first_seen)
+        d = analysis.decide_from_counts(hs.counts, hs.len_min, hs.len_max, notricks=args.notricks, pad=args.pad, first_seen=self.first_seen)
         self.d = d
         try:
             prefix, suffix, separators, columns, arrays = self.analyse_qname()
@@ -180,7 +192,7 @@ class Session:
         self.report(prefix, suffix, separators)
         self.config = {
             'base_distribution': d['base_distribution'], 'qual_distribution': d['qual_distribution'],
-            'reads': self.total, 'bases': d['bases'], 'qualities': d['qualities'],
+            'reads': self.reads_in_file(), 'bases': d['bases'], 'qualities': d['qualities'],
             'variable_read_lengths': d['variable_read_lengths'], 'bits_per_base': d['bits_per_base'],
             'bits_per_quality': d['bits_per_quality'], 'N_qual': d['N_qual'], 'dna_max': d['dna_max'],
             'QNAME_prefix': prefix, 'QNAME_suffix': suffix, 'QNAME_separators': separators, 'QNAME_columns': columns,
@@ -191,7 +203,7 @@ class Session:
         d, say = self.d, self.say
         total_bases = float(sum(d['base_distribution'].values()))
         say('Finished analysing file!', self.split_time())
-        say('    - total reads:', self.total)
+        say('    - total reads:', self.reads_in_file())
         say('    - total bases:', int(total_bases))
         say('\nQNAME Analysis:')
         if prefix: say('    - all QNAMEs prefixed with:', prefix)
