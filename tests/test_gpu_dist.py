@@ -23,12 +23,12 @@ def _free_port():
     s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _run_sharded(world, inp, out, flags):
+def _run_sharded(world, inp, out, flags, backend='gloo'):
     port = _free_port()
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1',
-                   MASTER_PORT=str(port), UQ_DIST_BACKEND='gloo', PYTHONPATH=REPO)
+                   MASTER_PORT=str(port), UQ_DIST_BACKEND=backend, PYTHONPATH=REPO)
         procs.append(subprocess.Popen([sys.executable, '-m', 'uq_amd.dist_encode', '-i', str(inp), '-o', str(out), '--quiet'] + flags,
                                       env=env, cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = []
@@ -52,12 +52,21 @@ CASES = [
 ]
 
 
+def test_sharded_encoder_on_rccl_single_rank(tmp_path):
+    """The same program over the nccl (= RCCL) backend; one rank is all a one-GPU box can host."""
+    _check(tmp_path, 1, ['--sort', 'QUAL', '--raw', 'DNA'], backend='nccl')
+
+
 @pytest.mark.parametrize('world,flags', CASES, ids=lambda v: str(v).replace(' ', ''))
 def test_sharded_encode_equals_oracle(tmp_path, world, flags):
+    _check(tmp_path, world, flags)
+
+
+def _check(tmp_path, world, flags, backend='gloo'):
     fq = synth.fastq(20261003 + 40, 3000, (30, 61), n_rate=2, dup='both', dup_templates=40)
     inp = tmp_path / 'in.fastq'; inp.write_bytes(fq)
     out = tmp_path / 'out.uQ'
-    _run_sharded(world, inp, out, flags)
+    _run_sharded(world, inp, out, flags, backend)
     cfg, members = O.read_tar(str(out))
 
     def opt(k, n):
