@@ -30,9 +30,13 @@ def main():
     ap.add_argument('--flags', default='--sort None --raw DNA QUAL QNAME --pattern 0.1 0.1')
     ap.add_argument('--decode', action='store_true')
     ap.add_argument('--dir', default='/dev/shm')
+    ap.add_argument('--config', type=int, default=2, choices=[2, 3, 5],
+                    help='BASELINE configs[n-1] shape: 2 = fixed length; 3 = 10 %% of reads copy one of N/16 DNA templates; 5 = 36-301 bp, 1 %% N')
     args = ap.parse_args()
     ctx = Context(0)
-    spec = synth.Spec(20261003 + 2, args.length)
+    if args.config == 3: spec = synth.Spec(20261003 + 3, args.length, dup='dna', dup_templates=max(1, args.reads // 16))
+    elif args.config == 5: spec = synth.Spec(20261003 + 5, (36, 301), n_rate=1)
+    else: spec = synth.Spec(20261003 + 2, args.length)
     d = ops.synth_fastq(ctx, spec, 0, args.reads)
     path = os.path.join(args.dir, 'uq_e2e_%d.fastq' % os.getpid())
     out = path + '.uQ'

@@ -133,7 +133,7 @@ class ShardedSession(Session):
         header = pattern_header(rows_total, cols, pattern)
         if n == 0:
             return self._put(filename, header, rows_total * cols, [])
-        payload = self.ops.pattern(self.ctx, t, n, cols, pattern)          # the shard's block, same flips applied locally
+        payload = t[:n * cols] if pattern == '0.1' else self.ops.pattern(self.ctx, t, n, cols, pattern)   # the shard's block, same flips applied locally
         at = (rows_total - first_row - n) if fr else first_row             # where the block's rows sit in the (flipped) row order
         if not colmajor:
             pieces = [(at * cols, payload)]

@@ -265,7 +265,7 @@ class Session:
         elif filename.startswith('QUAL'): pattern = args.pattern[1]
         else: error('ERROR: This should never happen!')
         t, rows, cols = table
-        payload = self.ops.pattern(self.ctx, t, rows, cols, pattern)
+        payload = t[:rows * cols] if pattern == '0.1' else self.ops.pattern(self.ctx, t, rows, cols, pattern)   # 0.1 is the table itself
         self.members[filename] = (pattern_header(rows, cols, pattern), payload)      # stays in HBM until write_container streams it
 
     def write_out(self, array, filename, dtype=None):
