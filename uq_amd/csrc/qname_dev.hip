@@ -39,10 +39,30 @@ struct LayoutOut {                  // device + host mirror
     uint8_t ch[QN_MAXCH];
 };
 
+// A lane's QNAME line is fetched ONCE, with 16-byte (unaligned) global loads, into the lane's private LDS row; all
+// the byte-wise work then runs out of LDS.  (Byte loads straight from HBM made both kernels ~8 ms per 10 M reads:
+// 64 lanes x 64 different cache lines per load thrash the 32 KiB L1, so every byte came from L2 again.)
+constexpr uint32_t QN_ROW = 64;                        // staged bytes per lane; longer lines are read from HBM directly
+constexpr uint32_t QN_STRIDE = QN_ROW + 4;             // 17 dwords: consecutive lanes hit different banks
+
+__device__ __forceinline__ void stage_line(uint8_t* row, const uint8_t* q, uint32_t ql, const uint8_t* buf_end) {
+    for (uint32_t c = 0; c < ql; c += 16) {
+        if (q + c + 16 <= buf_end) {
+            uint4 v;
+            __builtin_memcpy(&v, q + c, 16);
+            uint32_t* d = (uint32_t*)(row + c);
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        } else {
+            for (uint32_t b = c; b < ql; ++b) row[b] = q[b];
+        }
+    }
+}
+
 __global__ __launch_bounds__(QN_THREADS) void qname_layout_kernel(const uint8_t* __restrict__ buf, const uint64_t* __restrict__ ls,
                                                                    uint64_t n, uint64_t index_base, uint32_t start, Line1 l1,
                                                                    LayoutOut* __restrict__ out) {
     __shared__ uint8_t cnt[QN_MAXCH * QN_THREADS];      // per-lane character counters, slot-major (no bank conflicts)
+    __shared__ __align__(16) uint8_t stage[QN_THREADS * QN_STRIDE];
     __shared__ uint8_t s_slot[256];
     __shared__ uint8_t s_text[256];
     __shared__ unsigned long long s_entry[QN_MAXCH], s_viol[QN_MAXCH];
@@ -53,30 +73,43 @@ __global__ __launch_bounds__(QN_THREADS) void qname_layout_kernel(const uint8_t*
     if (tid == 0) { s_lcp = 0xFFFFFFFFu; s_lcs = 0xFFFFFFFFu; s_flags = 0; }
     for (uint32_t k = 0; k < l1.nch; ++k) cnt[k * QN_THREADS + tid] = 0;
     __syncthreads();
+    const uint8_t* buf_end = buf + ls[4 * n];
+    uint32_t my_lcp = 0xFFFFFFFFu, my_lcs = 0xFFFFFFFFu;
     const uint64_t stride = (uint64_t)gridDim.x * QN_THREADS;
     for (uint64_t li = (uint64_t)blockIdx.x * QN_THREADS + tid + start; li < n; li += stride) {
         const uint64_t i = index_base + li;           // record number in the whole file (shards: SURVEY.md 8e)
         const uint8_t* q = buf + ls[4 * li];
         const uint32_t ql = (uint32_t)(ls[4 * li + 1] - ls[4 * li] - 1);
         if (ql > 255) { atomicOr(&s_flags, 2u); continue; }
+        const uint8_t* row = stage + tid * QN_STRIDE;
+        const bool staged = ql <= QN_ROW;
+        if (staged) stage_line(stage + tid * QN_STRIDE, q, ql, buf_end);
+        auto at = [&](uint32_t j) -> uint32_t { return staged ? row[j] : q[j]; };
         const uint32_t m = ql < l1.len ? ql : l1.len;
         uint32_t lcp = 0;
-        while (lcp < m && q[lcp] == s_text[lcp]) ++lcp;
+        while (lcp < m && at(lcp) == s_text[lcp]) ++lcp;
         uint32_t lcs = 0;
-        while (lcs < m && q[ql - 1 - lcs] == s_text[l1.len - 1 - lcs]) ++lcs;
+        while (lcs < m && at(ql - 1 - lcs) == s_text[l1.len - 1 - lcs]) ++lcs;
         if ((lcp == ql && ql < l1.len) || (lcs == ql && ql < l1.len)) atomicOr(&s_flags, 1u);
-        atomicMin(&s_lcp, lcp); atomicMin(&s_lcs, lcs);
+        if (lcp < my_lcp) my_lcp = lcp;
+        if (lcs < my_lcs) my_lcs = lcs;
         for (uint32_t j = 0; j < ql; ++j) {
-            const uint32_t sl = s_slot[q[j]];
+            const uint32_t sl = s_slot[at(j)];
             if (sl != 0xFFu) cnt[sl * QN_THREADS + tid] += 1;      // saturation impossible: QNAME lines are < 256 bytes here (checked by the host)
         }
         for (uint32_t k = 0; k < l1.nch; ++k) {
             const uint32_t c = cnt[k * QN_THREADS + tid];
             cnt[k * QN_THREADS + tid] = 0;
-            if (lcp <= l1.lastpos[k]) atomicMin(&s_entry[k], (unsigned long long)i);
-            if (c != l1.cnt[k]) atomicMax(&s_viol[k], (unsigned long long)i);
+            // the lanes of a wave hold increasing record numbers: one lane per wave (the first / last that qualifies)
+            // speaks for all, and only if it can still change the table -- same-address LDS atomics from 64 lanes serialise
+            const unsigned long long em = __ballot(lcp <= l1.lastpos[k]), vm = __ballot(c != l1.cnt[k]);
+            const uint32_t lane = lane_id();
+            if (em && lane == (uint32_t)__builtin_ctzll(em) && (unsigned long long)i < s_entry[k]) atomicMin(&s_entry[k], (unsigned long long)i);
+            if (vm && lane == 63u - (uint32_t)__builtin_clzll(vm) && (unsigned long long)i > s_viol[k]) atomicMax(&s_viol[k], (unsigned long long)i);
         }
     }
+    my_lcp = wave_min(my_lcp); my_lcs = wave_min(my_lcs);
+    if (lane_id() == 0) { atomicMin(&s_lcp, my_lcp); atomicMin(&s_lcs, my_lcs); }
     __syncthreads();
     if (tid < l1.nch) {
         if (s_entry[tid] != UQ_NONE) atomicMin(&out->entry[tid], s_entry[tid]);
@@ -110,46 +143,53 @@ __global__ __launch_bounds__(QN_THREADS) void qname_tokenise_kernel(const uint8_
     __shared__ uint32_t s_long[QN_MAXCOLS];
     __shared__ uint32_t s_flags;
     __shared__ uint8_t s_inset[256];
-    const uint32_t tid = threadIdx.x;
+    __shared__ __align__(16) uint8_t stage[QN_THREADS * QN_STRIDE];
+    const uint32_t tid = threadIdx.x, lane = lane_id();
     const uint32_t ncols = sp.nsep + 1;
     s_inset[tid] = sp.inset[tid];
     if (tid < QN_MAXCOLS) { s_first[tid] = UQ_NONE; s_min[tid] = 0x7FFFFFFFFFFFFFFFll; s_max[tid] = -0x7FFFFFFFFFFFFFFFll - 1; s_long[tid] = 0; }
     if (tid == 0) s_flags = 0;
     __syncthreads();
+    const uint8_t* buf_end = buf + ls[4 * n];
     const uint64_t stride = (uint64_t)gridDim.x * QN_THREADS;
     for (uint64_t i = (uint64_t)blockIdx.x * QN_THREADS + tid; i < n; i += stride) {
         const uint8_t* q = buf + ls[4 * i];
         const uint32_t ql = (uint32_t)(ls[4 * i + 1] - ls[4 * i] - 1);
         uint32_t flags = 0;
         if (ql < sp.plen + sp.slen) { atomicOr(&s_flags, 8u); continue; }
+        const uint8_t* row = stage + tid * QN_STRIDE;
+        const bool staged = ql <= QN_ROW;
+        if (staged) stage_line(stage + tid * QN_STRIDE, q, ql, buf_end);
+        auto at = [&](uint32_t j) -> uint32_t { return staged ? row[j] : q[j]; };
         uint32_t pos = sp.plen;
         const uint32_t end = ql - sp.slen;
         for (uint32_t c = 0; c < ncols; ++c) {
             // field c runs to the next separator-set character (which must be separators[c]) or to `end`
             uint32_t e = pos;
-            while (e < end && !s_inset[q[e]]) ++e;
-            if (c < sp.nsep) { if (e >= end || q[e] != sp.seps[c]) flags |= 1u; }
+            while (e < end && !s_inset[at(e)]) ++e;
+            if (c < sp.nsep) { if (e >= end || at(e) != sp.seps[c]) flags |= 1u; }
             else if (e != end) flags |= 1u;
             const uint32_t fl = e - pos;
             // parse: [+-]digits, nothing else (Python would also accept surrounding whitespace: flagged instead)
             unsigned long long key = 0;
             bool odd = false, ws = false;            // odd: NUL or non-ASCII byte (the 8-byte key cannot carry it)
             for (uint32_t k = 0; k < fl; ++k) {
-                const uint32_t b = q[pos + k];
+                const uint32_t b = at(pos + k);
                 if (k < 8) key |= (unsigned long long)b << (56 - 8 * k);
                 odd |= (b == 0 || b >= 0x80);
                 ws |= (b == ' ' || (b >= 9 && b <= 13));
             }
             uint32_t k = 0;
             bool neg = false;
-            if (fl && (q[pos] == '+' || q[pos] == '-')) { neg = q[pos] == '-'; k = 1; }
+            const uint32_t b0 = fl ? at(pos) : 0u;
+            if (b0 == '+' || b0 == '-') { neg = b0 == '-'; k = 1; }
             const bool sign = k != 0;
             bool isint = fl > k;
             unsigned long long mag = 0;
             const uint32_t nd = fl - k;
-            const bool lead0 = nd > 1 && q[pos + k] == '0';
+            const bool lead0 = nd > 1 && at(pos + k) == '0';
             for (; k < fl; ++k) {
-                const uint32_t b = q[pos + k];
+                const uint32_t b = at(pos + k);
                 if (b < '0' || b > '9') { isint = false; break; }
                 mag = mag * 10 + (b - '0');
             }
@@ -163,9 +203,10 @@ __global__ __launch_bounds__(QN_THREADS) void qname_tokenise_kernel(const uint8_
             }
             vals[c][i] = isint ? v : 0;
             strs[c][i] = __builtin_bswap64(key);     // memory order = text order (rows for uq_unique_rows)
-            if (lng) atomicOr(&s_long[c], lng);
-            if (isint) { atomicMin(&s_min[c], v); atomicMax(&s_max[c], v); }
-            else atomicMin(&s_first[c], (unsigned long long)i);
+            if (lng && (s_long[c] & lng) != lng) atomicOr(&s_long[c], lng);
+            // same-address LDS atomics from 64 lanes serialise: lanes that cannot change the table stay out
+            if (isint) { if (v < s_min[c]) atomicMin(&s_min[c], v); if (v > s_max[c]) atomicMax(&s_max[c], v); }
+            else if ((unsigned long long)i < s_first[c]) atomicMin(&s_first[c], (unsigned long long)i);
             pos = e + 1;
         }
         if (flags) atomicOr(&s_flags, flags);
