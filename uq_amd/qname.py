@@ -1,4 +1,5 @@
-"""QNAME passes on the host ("next" for a device tokenizer).
+"""QNAME passes, sequential form, on the host (the device form is uq_amd/qname_device.py and
+falls back to this module for QNAMEs outside the subset it reproduces exactly).
 
 The reference infers a common prefix / suffix and constant-count separator characters while it scans
 the file (uq.py:348-352, 394-444), types each delimited column as mapping / integers (uq.py:555-678)
