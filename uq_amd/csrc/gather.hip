@@ -70,15 +70,46 @@ __global__ __launch_bounds__(GT) void gather_rows_kernel(const uint8_t* __restri
     const uint32_t n = (uint32_t)((g.n_out - j0) < g.TR ? (g.n_out - j0) : g.TR);
     const uint32_t gl = threadIdx.x & (g.G - 1);          // lane inside the row group
     const uint32_t groups = GT / g.G;
-    for (uint32_t i = threadIdx.x / g.G; i < n; i += groups) {
-        uint64_t r = load_index(idx, itemsize, j0 + i);
-        if (r >= g.table_rows) r = 0;
-        const uint8_t* s = table + r * g.C;
-        const uint32_t sk = (uint32_t)((uintptr_t)s & 3);
-        const uint32_t* s32 = (const uint32_t*)(s - sk);
-        const uint32_t nd = (sk + g.C + 3) >> 2;
-        for (uint32_t d = gl; d < nd; d += g.G) lds32[i * g.P + d] = s32[d];
-        if (gl == 0) skew[i] = (uint8_t)sk;
+    if (((g.C + 6) >> 2) <= g.G) {
+        // a row is at most one dword per lane of its group: four rows per group in flight (index -> row -> LDS is a
+        // chain of dependent latencies; one row at a time left the kernel latency-bound)
+        constexpr int U = 4;
+        for (uint32_t i0 = threadIdx.x / g.G; i0 < n; i0 += U * groups) {
+            uint64_t r[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t i = i0 + u * groups;
+                r[u] = i < n ? load_index(idx, itemsize, j0 + i) : 0;
+                if (r[u] >= g.table_rows) r[u] = 0;
+            }
+            uint32_t v[U], sk[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint8_t* s = table + r[u] * g.C;
+                sk[u] = (uint32_t)((uintptr_t)s & 3);
+                const uint32_t nd = (sk[u] + g.C + 3) >> 2;
+                v[u] = (i0 + u * groups < n && gl < nd) ? ((const uint32_t*)(s - sk[u]))[gl] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t i = i0 + u * groups;
+                if (i < n) {
+                    if (gl < ((sk[u] + g.C + 3) >> 2)) lds32[i * g.P + gl] = v[u];
+                    if (gl == 0) skew[i] = (uint8_t)sk[u];
+                }
+            }
+        }
+    } else {
+        for (uint32_t i = threadIdx.x / g.G; i < n; i += groups) {
+            uint64_t r = load_index(idx, itemsize, j0 + i);
+            if (r >= g.table_rows) r = 0;
+            const uint8_t* s = table + r * g.C;
+            const uint32_t sk = (uint32_t)((uintptr_t)s & 3);
+            const uint32_t* s32 = (const uint32_t*)(s - sk);
+            const uint32_t nd = (sk + g.C + 3) >> 2;
+            for (uint32_t d = gl; d < nd; d += g.G) lds32[i * g.P + d] = s32[d];
+            if (gl == 0) skew[i] = (uint8_t)sk;
+        }
     }
     __syncthreads();
     GatherFn fn{smem, skew, g};
