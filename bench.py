@@ -106,7 +106,12 @@ def main():
     from uq_amd import ops, synth
     from uq_amd.device import Context
 
+    json_out = sys.stdout
     if use_dist:
+        # RCCL prints its version banner / warnings with printf on fd 1: keep stdout for the one JSON line
+        sys.stdout.flush()
+        json_out = os.fdopen(os.dup(1), 'w')
+        os.dup2(2, 1)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
@@ -160,10 +165,14 @@ def main():
         step(True)
     fence()
     dt = time.perf_counter() - t0
+    total_bytes, total_reads = fastq_bytes, None
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=ctx.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        tot = torch.tensor([fastq_bytes, state['nreads']], dtype=torch.int64, device=ctx.device)   # shards differ by a few bytes
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        total_bytes, total_reads = int(tot[0].item()), int(tot[1].item())
 
     if ops.bad_index(state['bad']) is not None:
         raise RuntimeError('pack reported an uncoded symbol at read %d' % ops.bad_index(state['bad']))
@@ -185,11 +194,11 @@ def main():
 
     result = {
         'metric': 'FASTQ encode MB/s (150bp synthetic; bit-exact tables vs reference)',
-        'value': round(world * fastq_bytes / 1e6 / (dt / args.steps), 1), 'unit': 'MB/s',
+        'value': round(total_bytes / 1e6 / (dt / args.steps), 1), 'unit': 'MB/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic',
-        'reads_per_s': round(world * nreads / (dt / args.steps), 1),
+        'reads_per_s': round((total_reads if total_reads is not None else nreads) / (dt / args.steps), 1),
         'config': {'workload': ('BASELINE configs[1]: %d x %dbp synth-v1 FASTQ per GPU (%.3f GB), --sort None --raw DNA QUAL QNAME '
                                 '--pattern 0.1 0.1; step = census + index + stats + decisions + %d-bit DNA / %d-bit QUAL pack'
                                 % (nreads, args.length, fastq_bytes / 1e9, d['bits_per_base'], d['bits_per_quality'])) if args.workload == 'cfg2' else
@@ -215,7 +224,7 @@ def main():
             raise RuntimeError('parity failure: GPU rows differ from the oracle on the CPU sample')
         result['cpu_baseline'] = cb
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), file=json_out, flush=True)
     if use_dist:
         dist.destroy_process_group()
 

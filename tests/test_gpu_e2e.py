@@ -154,13 +154,11 @@ def test_cli_edge_inputs(ctx, tmp_path):
     p.write_bytes(b'@q:1:5\nA\n+\nI\n@q:2:6\nC\n+\nI')
     with pytest.raises(uq.UqError):
         uq.Session(uq.validate_args(uq.build_parser().parse_args(['-i', str(p), '--quiet'])), ctx=ctx).encode()
-    # a read longer than one LDS tile is refused with a clear message, not a fault
+    # reads longer than one LDS tile take the HBM-direct kernels (see test_cli_long_reads)
     L = 30000
-    p.write_bytes(b'@q:1:5\n' + b'A' * L + b'\n+\n' + b'I' * L + b'\n@q:2:6\n' + b'C' * L + b'\n+\n' + b'H' * L + b'\n')
-    from uq_amd._lib import UqHipError
-    with pytest.raises((uq.UqError, UqHipError)) as e:
-        uq.Session(uq.validate_args(uq.build_parser().parse_args(['-i', str(p), '--quiet'])), ctx=ctx).encode()
-    assert 'tile' in str(e.value)
+    fq = b'@q:1:5\n' + b'A' * L + b'\n+\n' + b'I' * L + b'\n@q:2:6\n' + b'C' * L + b'\n+\n' + b'H' * L + b'\n'
+    cfg, members, names, path = _run_encode(ctx, tmp_path, fq, [])
+    assert _run_decode(ctx, path) == fq
 
 
 def test_device_text_emit_matches_oracle_decode(ctx, tmp_path):
@@ -198,3 +196,26 @@ def test_cli_errors(ctx, tmp_path):
         uq.validate_args(uq.build_parser().parse_args(['-i', str(p), '--pattern', '0.1']))
     with pytest.raises(uq.UqError):
         uq.validate_args(uq.build_parser().parse_args(['-i', str(p), '--sort', 'bogus']))
+
+
+@pytest.mark.parametrize('flags', [[], ['--sort', 'QUAL', '--raw', 'DNA', 'QUAL', 'QNAME'], ['--notricks', '--pattern', '2.2', '1.1']],
+                         ids=lambda v: '_'.join(v) or 'default')
+def test_cli_long_reads(ctx, tmp_path, flags):
+    """Reads far beyond one LDS tile (long-read platforms): pack / unpack / emit take their HBM-direct paths."""
+    rng = np.random.default_rng(31)
+    recs = []
+    for i, L in enumerate([12000, 30000, 70000, 100, 25000, 60001, 7]):
+        seq = rng.choice(np.frombuffer(b'ACGT', np.uint8), L)
+        qual = rng.integers(35, 75, L, dtype=np.uint8)
+        n_at = rng.random(L) < 0.01
+        seq[n_at] = ord('N'); qual[n_at] = ord('!')
+        recs.append(b'@ont:%d:%d\n' % (i, 1000 + 7 * i) + bytes(seq) + b'\n+\n' + bytes(qual) + b'\n')
+    fq = b''.join(recs)
+    cfg, members, names, path = _run_encode(ctx, tmp_path, fq, flags)
+    ocfg, omembers, _ = O.encode(fq, **_oracle_flags(flags))
+    assert set(members) == set(omembers)
+    for k in omembers:
+        assert members[k] == omembers[k], k
+    text = _run_decode(ctx, path)
+    assert text.decode('latin-1') == O.decode(ocfg, omembers)
+    if '--sort' not in flags: assert text == fq

@@ -364,8 +364,13 @@ extern "C" int uq_pack(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line
     UQ_REQUIRE(fill_d >= 0 && fill_q >= 0, "uq_pack: the alphabets need a symbol with code 0");
     UQ_REQUIRE(max_d < (1 << bd), "uq_pack: a DNA code does not fit %u bits", bd);
     const bool carry = max_q >= (1 << bq);   // Q9: N quality code == 2^b (or beyond)
+    // A tile is at most PK_NV * 256 * 16 B = 20 KiB of FASTQ (what one workgroup keeps in flight in registers).  Records
+    // that do not fit (reads beyond ~10 kbp: long-read platforms) take the exact thread-per-read kernel too: slow, never wrong.
+    const uint32_t stage_cap = PK_NV * PK_THREADS * 16;
+    const uint32_t rec = (uint32_t)hp->max_record_bytes;
+    UQ_REQUIRE(rec >= 4, "uq_pack: max_record_bytes not set (take it from uq_stats)");
 
-    if (carry) {
+    if (carry || rec + 64 > stage_cap) {
         uint32_t blocks = (uint32_t)((nreads + 255) / 256);
         pack_carry_kernel<<<blocks, 256, 0, ctx->stream>>>(d_buf, d_line_start, first_read, nreads, lut, bd, bq, Cd, Cq,
                                                            hp->variable ? 1u : 0u, d_dna, d_qual, (unsigned long long*)d_bad);
@@ -380,11 +385,6 @@ extern "C" int uq_pack(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line
     g.magicG = magic_u32(g.G);
     g.fill_d = 0x01010101u * (uint32_t)fill_d;
     g.fill_q = 0x01010101u * (uint32_t)fill_q;
-    const uint32_t rec = (uint32_t)hp->max_record_bytes;
-    UQ_REQUIRE(rec >= 4, "uq_pack: max_record_bytes not set (take it from uq_stats)");
-    // A tile is at most PK_NV * 256 * 16 B = 20 KiB of FASTQ (what one workgroup keeps in flight in registers).
-    const uint32_t stage_cap = PK_NV * PK_THREADS * 16;
-    UQ_REQUIRE(rec + 64 <= stage_cap, "uq_pack: a %u-byte record does not fit one %u-byte tile", rec, stage_cap);
     uint32_t R = (stage_cap - 64) / rec;
     if (R > (PK_THREADS - 1) / 4) R = (PK_THREADS - 1) / 4;     // 4R + 1 line offsets, one per lane
     // R a multiple of 16 keeps every tile's output offset 16-byte aligned (uint4 stores); when that would waste

@@ -172,6 +172,21 @@ __global__ __launch_bounds__(PT_THREADS) void unpattern_cm_kernel(const uint8_t*
     emit_span(T + r0 * g.C, n * g.C, fn);
 }
 
+// Rows too wide for an LDS tile (long-read tables): one byte per lane, indexed directly.  Lanes walk the
+// TABLE in row-major order, so the table side is coalesced and the payload side is not.
+__global__ __launch_bounds__(PT_THREADS) void pattern_wide_kernel(const uint8_t* __restrict__ in, uint64_t R, uint32_t C, uint32_t colmajor,
+                                                                  uint32_t fr, uint32_t fc, uint32_t inverse, uint8_t* __restrict__ out) {
+    const uint64_t total = R * C;
+    for (uint64_t k = (uint64_t)blockIdx.x * PT_THREADS + threadIdx.x; k < total; k += (uint64_t)gridDim.x * PT_THREADS) {
+        const uint64_t r = k / C;
+        const uint32_t c = (uint32_t)(k - r * C);
+        const uint64_t ro = fr ? R - 1 - r : r;
+        const uint64_t co = fc ? C - 1 - c : c;
+        const uint64_t p = colmajor ? co * R + ro : ro * C + co;       // payload position of T[r][c]
+        if (inverse) out[k] = in[p]; else out[p] = in[k];
+    }
+}
+
 int launch(uq_ctx* ctx, const uint8_t* in, uint64_t rows, uint32_t cols, int pattern_id, uint8_t* out, bool inverse) {
     UQ_REQUIRE(ctx, "null context");
     UQ_REQUIRE(pattern_id >= 0 && pattern_id < 8, "pattern id %d out of range", pattern_id);
@@ -198,7 +213,14 @@ int launch(uq_ctx* ctx, const uint8_t* in, uint64_t rows, uint32_t cols, int pat
     PatGeom g;
     g.R = rows; g.C = cols; g.fr = fr; g.fc = fc;
     g.magicC = magic_u32(cols);
-    UQ_REQUIRE(cols <= 32768, "pattern: %u columns do not fit one LDS tile", cols);
+    if (cols > 8192) {                          // fewer than ~8 rows would fit a tile: take the direct kernel
+        const uint64_t total = rows * cols;
+        const uint64_t nb = (total + PT_THREADS - 1) / PT_THREADS;
+        const uint32_t blocks = (uint32_t)(nb < (uint64_t)UQ_NUM_CU * 16 ? nb : (uint64_t)UQ_NUM_CU * 16);
+        pattern_wide_kernel<<<blocks, PT_THREADS, 0, ctx->stream>>>(in, rows, cols, colmajor ? 1u : 0u, fr, fc, inverse ? 1u : 0u, out);
+        UQ_LAUNCH_CHECK();
+        return 0;
+    }
     const uint32_t budget = 60 * 1024;
     size_t lds;
     if (!colmajor) {

@@ -107,6 +107,53 @@ __global__ __launch_bounds__(UT) void unpack_kernel(const uint8_t* __restrict__ 
     emit_span(seq + r0 * g.dmax, Rt * g.dmax, fs);
     emit_span(qtxt + r0 * g.dmax, Rt * g.dmax, fq);
 }
+
+// Rows too long for one LDS tile (reads beyond ~50 kbp): one wave per read, symbols straight from / to HBM.
+__global__ __launch_bounds__(UT) void unpack_long_kernel(const uint8_t* __restrict__ dna, const uint8_t* __restrict__ qual, uint64_t n,
+                                                         UnpackLut lut, UnpackGeom g, uint8_t* __restrict__ seq, uint8_t* __restrict__ qtxt,
+                                                         uint32_t* __restrict__ len, unsigned long long* __restrict__ bad) {
+    __shared__ uint8_t l_base[256], l_qual[256], l_qn[256];
+    const uint32_t tid = threadIdx.x, lane = lane_id();
+    l_base[tid] = lut.base_char[tid]; l_qual[tid] = lut.qual_char[tid]; l_qn[tid] = lut.qual_n_base[tid];
+    __syncthreads();
+    const uint32_t md = (1u << g.bd) - 1, mq = (1u << g.bq) - 1;
+    for (uint64_t r = (uint64_t)blockIdx.x * (UT / 64) + (tid >> 6); r < n; r += (uint64_t)gridDim.x * (UT / 64)) {
+        const uint8_t* drow = dna + r * g.Cd;
+        const uint8_t* qrow = qual + r * g.Cq;
+        uint32_t L = g.dmax;
+        if (g.variable) {
+            // first non-zero byte of the row: lanes scan strided, the lowest hit wins
+            uint32_t first = 0xFFFFFFFFu;
+            for (uint32_t k = lane; k < g.Cd && first == 0xFFFFFFFFu; k += 64) if (drow[k]) first = k;
+            first = wave_min(first);
+            bool ok = first != 0xFFFFFFFFu;
+            if (ok) {
+                const uint32_t hb = 8 * (g.Cd - 1 - first) + (31 - __clz((uint32_t)drow[first]));
+                L = hb / g.bd;
+                if (L * g.bd != hb || L > g.dmax) { ok = false; L = L > g.dmax ? g.dmax : L; }
+            } else L = 0;
+            if (!ok && lane == 0) atomicMin(bad, (unsigned long long)r);
+        }
+        if (lane == 0) len[r] = L;
+        uint8_t* so = seq + r * g.dmax;
+        uint8_t* qo = qtxt + r * g.dmax;
+        for (uint32_t j = lane; j < g.dmax; j += 64) {
+            uint8_t cb = 0, cc = 0;
+            if (j < L) {
+                const uint32_t t = L - 1 - j;                        // symbol index from the end of the read
+                const uint32_t bitd = t * g.bd, bitq = t * g.bq;
+                const uint32_t bd0 = g.Cd - 1 - (bitd >> 3), bq0 = g.Cq - 1 - (bitq >> 3);
+                const uint32_t vd = drow[bd0] | (bd0 ? (uint32_t)drow[bd0 - 1] << 8 : 0u);
+                const uint32_t vq = qrow[bq0] | (bq0 ? (uint32_t)qrow[bq0 - 1] << 8 : 0u);
+                const uint32_t cd = (vd >> (bitd & 7)) & md, cq = (vq >> (bitq & 7)) & mq;
+                const uint8_t nb = l_qn[cq];
+                cb = nb ? nb : l_base[cd];
+                cc = l_qual[cq];
+            }
+            so[j] = cb; qo[j] = cc;
+        }
+    }
+}
 }  // namespace
 
 extern "C" int uq_unpack(uq_ctx* ctx, const uint8_t* d_dna, const uint8_t* d_qual, uint64_t nreads, const uq_unpack_params* hp,
@@ -126,7 +173,16 @@ extern "C" int uq_unpack(uq_ctx* ctx, const uint8_t* d_dna, const uint8_t* d_qua
     g.G = (g.dmax + 7) / 8;
     g.magicG = magic_u32(g.G);
     const uint32_t per_read = g.Cd + g.Cq + 2 * g.dmax + 4;
-    UQ_REQUIRE(per_read + 256 <= 150 * 1024, "uq_unpack: a read of %u bases does not fit one LDS tile", g.dmax);
+    UnpackLut lut;
+    memcpy(lut.base_char, hp->base_char, 256); memcpy(lut.qual_char, hp->qual_char, 256); memcpy(lut.qual_n_base, hp->qual_n_base, 256);
+    if (per_read + 256 > 150 * 1024) {            // rows beyond one LDS tile: wave per read
+        g.R = 0; g.in_d = g.in_q = g.out_s = g.out_q = g.lens = 0;
+        const uint64_t waves = (nreads + 3) / 4;
+        const uint32_t blocks = (uint32_t)(waves < (uint64_t)UQ_NUM_CU * 8 ? waves : (uint64_t)UQ_NUM_CU * 8);
+        unpack_long_kernel<<<blocks, UT, 0, ctx->stream>>>(d_dna, d_qual, nreads, lut, g, d_seq, d_qualtxt, d_len, (unsigned long long*)d_bad);
+        UQ_LAUNCH_CHECK();
+        return 0;
+    }
     uint32_t R = (48 * 1024 - 256) / per_read;
     if (R >= 16) R &= ~15u;
     if (R == 0) R = 1;
@@ -138,8 +194,6 @@ extern "C" int uq_unpack(uq_ctx* ctx, const uint8_t* d_dna, const uint8_t* d_qua
     g.out_s = carve(R * g.dmax + 16); g.out_q = carve(R * g.dmax + 16);
     g.lens = carve(R * 4);
     const size_t lds = off;
-    UnpackLut lut;
-    memcpy(lut.base_char, hp->base_char, 256); memcpy(lut.qual_char, hp->qual_char, 256); memcpy(lut.qual_n_base, hp->qual_n_base, 256);
     const uint64_t tiles = (nreads + R - 1) / R;
     UQ_REQUIRE(tiles <= 0x7fffffffu, "uq_unpack: too many tiles");
     if (lds > 48 * 1024) UQ_CHECK_HIP(hipFuncSetAttribute((const void*)unpack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
