@@ -89,6 +89,9 @@ def main():
     ap.add_argument('--length', type=int, default=150)
     ap.add_argument('--cpu-sample', type=int, default=100_000, help='reads timed on the host for cpu_baseline (0 = skip)')
     ap.add_argument('--force-dist', action='store_true', help='initialise the process group and run the collectives even with one rank')
+    ap.add_argument('--one-pass', action='store_true',
+                    help='pack speculatively (previous step\'s decisions) during the statistics pass and verify afterwards: one pass over the '
+                         'stream less, +5 %% on configs[1], but the fused kernel is latency-bound (DESIGN.md 4); not the default')
     ap.add_argument('--workload', default='cfg2', choices=['cfg2', 'cfg5-notricks', 'cfg5-ntrick'],
                     help='cfg2 = BASELINE configs[1] (the bench line the driver reads); cfg5-* = configs[4]: variable length 36-301 bp '
                          'with 1%% N, 3-bit ACGNT path (--notricks) or 2-bit N-trick path -- parity/measurement extras')
@@ -130,27 +133,52 @@ def main():
     pack_events = []
     state = {}
 
+    def fetch(st):
+        if use_dist:
+            from uq_amd import dist as uqdist
+            return uqdist.allreduce_stats(ctx, st)
+        return ops.stats_fetch(ctx, st)
+
     def step(timed):
         nlines = ops.count_lines(ctx, d_buf)
         nreads = nlines // 4
-        ls, st = ops.index_and_stats(ctx, d_buf, nlines)      # record index, then pass-1 statistics
-        if use_dist:
-            from uq_amd import dist as uqdist
-            hs = uqdist.allreduce_stats(ctx, st)
+        ls = ops.index_lines(ctx, d_buf, nlines)              # record index
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        # One-pass form: pack with the previous step's decisions WHILE counting the pass-1 statistics (uq_pack_stats);
+        # the real decisions are then derived from those statistics and the tables kept only if they agree.
+        guess = state.get('params') if args.one_pass else None
+        spec = None
+        if guess is not None:
+            e0.record()
+            spec = ops.pack_stats(ctx, d_buf, ls, 0, nreads, guess)
+            e1.record()
+        if spec is not None:
+            st = spec[3]
         else:
-            hs = ops.stats_fetch(ctx, st)
+            st = ops.stats_new(ctx)
+            ops.stats_accumulate(ctx, st, d_buf, ls, 0, nreads)
+        hs = fetch(st)
+        if hs.incomplete:                                     # the speculative pass could not count everything
+            spec = None
+            st = ops.stats_new(ctx)
+            ops.stats_accumulate(ctx, st, d_buf, ls, 0, nreads)
+            hs = fetch(st)
         if hs.bad_plus is not None or hs.bad_len is not None:
             raise RuntimeError('malformed FASTQ record')
         d = host_decide(hs, notricks=notricks)
         p = ops.make_pack_params(d['bases'], d['qualities'], d['N_qual'], d['bits_per_base'], d['bits_per_quality'],
                                  d['variable_read_lengths'], d['dna_bytes_per_row'], d['quality_bytes_per_row'],
                                  d['dna_max'], hs.max_record_bytes)
-        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        dna, qual, bad = ops.pack(ctx, d_buf, ls, 0, nreads, p)
-        e1.record()
-        if timed: pack_events.append((e0, e1))
-        state.update(dna=dna, qual=qual, bad=bad, d=d, nreads=nreads, ls=ls)
+        if spec is not None and ops.same_pack_params(p, guess):
+            dna, qual, bad = spec[:3]
+            kernel = 'pack_tile_kernel<STATS> (pack + pass-1 statistics in one pass)'
+        else:
+            e0.record()
+            dna, qual, bad = ops.pack(ctx, d_buf, ls, 0, nreads, p)
+            e1.record()
+            kernel = 'pack_tile_kernel'
+        if timed: pack_events.append((e0, e1, kernel))
+        state.update(dna=dna, qual=qual, bad=bad, d=d, nreads=nreads, ls=ls, params=p)
 
     for _ in range(args.warmup):
         step(False)
@@ -178,12 +206,14 @@ def main():
         raise RuntimeError('pack reported an uncoded symbol at read %d' % ops.bad_index(state['bad']))
     d = state['d']
     nreads = state['nreads']
-    pack_ms = float(np.mean([a.elapsed_time(b) for a, b in pack_events]))
+    kernel = pack_events[-1][2]
+    one_pass = 'STATS' in kernel
+    pack_ms = float(np.mean([a.elapsed_time(b) for a, b, k in pack_events if k == kernel]))
     algo_bytes = fastq_bytes + nreads * (d['dna_bytes_per_row'] + d['quality_bytes_per_row'])
     achieved = algo_bytes / 1e9 / (pack_ms / 1e3)
 
     traffic = None
-    tpath = os.path.join(HERE, 'profiles', 'pack_traffic.json')
+    tpath = os.path.join(HERE, 'profiles', 'pack_stats_traffic.json' if one_pass else 'pack_traffic.json')
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
@@ -192,6 +222,8 @@ def main():
         except Exception:
             traffic = None
 
+    mode = (' [one-pass: stats and pack share one pass over the stream, packed with the previous step\'s decisions and kept only '
+            'because this step\'s statistics gave the same decisions]' if one_pass else ' [two passes]')
     result = {
         'metric': 'FASTQ encode MB/s (150bp synthetic; bit-exact tables vs reference)',
         'value': round(total_bytes / 1e6 / (dt / args.steps), 1), 'unit': 'MB/s',
@@ -200,14 +232,14 @@ def main():
         'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic',
         'reads_per_s': round((total_reads if total_reads is not None else nreads) / (dt / args.steps), 1),
         'config': {'workload': ('BASELINE configs[1]: %d x %dbp synth-v1 FASTQ per GPU (%.3f GB), --sort None --raw DNA QUAL QNAME '
-                                '--pattern 0.1 0.1; step = census + index + stats + decisions + %d-bit DNA / %d-bit QUAL pack'
-                                % (nreads, args.length, fastq_bytes / 1e9, d['bits_per_base'], d['bits_per_quality'])) if args.workload == 'cfg2' else
+                                '--pattern 0.1 0.1; step = census + index + stats + decisions + %d-bit DNA / %d-bit QUAL pack%s'
+                                % (nreads, args.length, fastq_bytes / 1e9, d['bits_per_base'], d['bits_per_quality'], mode)) if args.workload == 'cfg2' else
                                ('BASELINE configs[4] (%s): %d x 36-301bp synth-v1 FASTQ with 1%% N per GPU (%.3f GB); step = census + index + '
-                                'stats + decisions + %d-bit DNA / %d-bit QUAL variable-length pack'
-                                % (args.workload, nreads, fastq_bytes / 1e9, d['bits_per_base'], d['bits_per_quality'])),
+                                'stats + decisions + %d-bit DNA / %d-bit QUAL variable-length pack%s'
+                                % (args.workload, nreads, fastq_bytes / 1e9, d['bits_per_base'], d['bits_per_quality'], mode)),
                    'reads_per_gpu': nreads, 'read_length': args.length, 'fastq_bytes_per_gpu': fastq_bytes,
                    'sharding': 'record-parallel, %d shard(s)' % world},
-        'roofline': {'bound': 'hbm', 'kernel': 'pack_tile_kernel', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
+        'roofline': {'bound': 'hbm', 'kernel': kernel, 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
                      'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
                      'algorithmic_bytes_per_launch': int(algo_bytes), 'avg_launch_ms': round(pack_ms, 4)},
     }

@@ -65,7 +65,7 @@ typedef struct uq_stats {
     uint64_t bad_len;           /* smallest read index with len(SEQ) != len(QUAL)        (uq.py:388) */
     uint32_t len_min, len_max;  /* uq.py:416-417 */
     uint32_t max_record_bytes;  /* longest record (4 lines), sizing hint for the pack tiles */
-    uint32_t reserved;
+    uint32_t reserved;          /* uq_pack_stats only: non-zero = the counts above are incomplete, run uq_stats_accumulate */
 } uq_stats;
 int uq_stats_init(uq_ctx* ctx, uq_stats* d_stats);
 int uq_stats_accumulate(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start,
@@ -102,6 +102,18 @@ typedef struct uq_pack_params {
  * symbol with no code, else UQ_NONE. */
 int uq_pack(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start, uint64_t first_read,
             uint64_t nreads, const uq_pack_params* h_params, uint8_t* d_dna, uint8_t* d_qual, uint64_t* d_bad);
+/* a1 + a3/a4 in ONE pass over the stream: packs with GUESSED parameters (h_guess: e.g. the decisions of the previous
+ * file / shard, or of a sample of this one) and accumulates the pass-1 statistics of the same reads into d_stats
+ * (initialised by uq_stats_init) while the characters are in registers.  The caller then derives the real decisions
+ * from d_stats (uq.py:448-545) and keeps the tables iff they equal the guess; otherwise it calls uq_pack with the
+ * real ones -- nothing is assumed, the stream is just read once instead of twice when the guess holds.
+ * *h_fused = 0: this geometry has no fused kernel (anything but 2-bit A/C/G/T with one contiguous quality range, the
+ * Q9 carry case, records beyond one tile) and NOTHING was launched: run uq_stats_accumulate + uq_pack.
+ * d_stats->reserved != 0 after the call: the counts are incomplete (a read longer than h_guess->dna_max, a record
+ * longer than h_guess->max_record_bytes, SEQ / QUAL lengths differ): re-initialise and run uq_stats_accumulate. */
+int uq_pack_stats(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start, uint64_t first_read,
+                  uint64_t nreads, const uq_pack_params* h_guess, uint8_t* d_dna, uint8_t* d_qual, uint64_t* d_bad,
+                  uq_stats* d_stats, int* h_fused);
 
 /* ---- a9 / a11: the eight --pattern byte layouts.  Replaces numpy.rot90 + ascontiguousarray /
  * asfortranarray + the payload write of numpy.save (uq.py:263-270) and, inverse, numpy.load +

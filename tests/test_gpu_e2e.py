@@ -198,6 +198,28 @@ def test_cli_errors(ctx, tmp_path):
         uq.validate_args(uq.build_parser().parse_args(['-i', str(p), '--sort', 'bogus']))
 
 
+def test_cli_one_pass_speculation(ctx, tmp_path):
+    """--one-pass: the second encode of a process packs during the statistics pass with the first one's decisions; a file
+    whose decisions differ falls back to the separate pack.  The output never depends on the path taken."""
+    uq.Session.last_params = None
+    a = synth.fastq(20261003 + 50, 3000, 60)
+    b = synth.fastq(20261003 + 51, 2500, 60)                                   # same alphabets and length: the guess holds
+    c = synth.fastq(20261003 + 52, 2000, (30, 61), n_rate=2)                   # variable length, N: the guess fails
+    paths = []
+    for i, fq in enumerate((a, b, c, b)):
+        inp = tmp_path / ('in%d.fastq' % i); inp.write_bytes(fq)
+        out = tmp_path / ('out%d.uQ' % i)
+        args = uq.validate_args(uq.build_parser().parse_args(['-i', str(inp), '-o', str(out), '--quiet', '--one-pass', '--raw', 'DNA', 'QUAL', 'QNAME']))
+        s = uq.Session(args, ctx=ctx)
+        s.encode()
+        paths.append(s.pack_path)
+        cfg, members = O.read_tar(str(out))
+        ocfg, omembers, _ = O.encode(fq, raw=['DNA', 'QUAL', 'QNAME'])
+        assert all(members[k] == omembers[k] for k in omembers)
+    assert paths == ['two-pass', 'one-pass', 'two-pass', 'two-pass']
+    uq.Session.last_params = None
+
+
 @pytest.mark.parametrize('flags', [[], ['--sort', 'QUAL', '--raw', 'DNA', 'QUAL', 'QNAME'], ['--notricks', '--pattern', '2.2', '1.1']],
                          ids=lambda v: '_'.join(v) or 'default')
 def test_cli_long_reads(ctx, tmp_path, flags):

@@ -274,3 +274,68 @@ def test_pack_matches_reference_golden(ctx, name):
     assert bad is None
     assert np.array_equal(dna, O.unpattern(members['DNA.raw']))
     assert np.array_equal(qual, O.unpattern(members['QUAL.raw']))
+
+
+FUSED_CASES = [('fixed150', 4096 + 37, 150, {}), ('fixed100', 3000, 100, {}), ('var_ntrick', 5000, (36, 301), dict(n_rate=1)),
+               ('short_var', 2000, (1, 12), {})]
+
+
+@pytest.mark.parametrize('name,n,length,kw', FUSED_CASES, ids=[c[0] for c in FUSED_CASES])
+def test_pack_stats_fused(ctx, name, n, length, kw):
+    """uq_pack_stats: with the right guess the tables AND the statistics equal those of the two separate passes."""
+    spec = synth.Spec(S + 6, length, **kw)
+    host = synth.fastq_array(spec, n)
+    d_buf = ctx.to_device(host)
+    nlines, ls = _index(ctx, d_buf)
+    st = ops.stats_new(ctx)
+    ops.stats_accumulate(ctx, st, d_buf, ls, 0, n)
+    hs = ops.stats_fetch(ctx, st)
+    d = _decide_from_stats(hs)
+    p = ops.make_pack_params(d['bases'], d['qualities'], d['N_qual'], d['bits_per_base'], d['bits_per_quality'], d['variable_read_lengths'],
+                             d['dna_bytes_per_row'], d['quality_bytes_per_row'], d['dna_max'], hs.max_record_bytes)
+    ref_d, ref_q, bad = ops.pack(ctx, d_buf, ls, 0, n, p)
+    res = ops.pack_stats(ctx, d_buf, ls, 0, n, p)
+    assert res is not None, 'this geometry (2-bit A/C/G/T, contiguous qualities) has a fused kernel'
+    dna, qual, bad2, st2 = res
+    hs2 = ops.stats_fetch(ctx, st2)
+    assert not hs2.incomplete
+    assert np.array_equal(hs2.counts, hs.counts)
+    assert (hs2.len_min, hs2.len_max, hs2.max_record_bytes, hs2.bad_plus, hs2.bad_len) == (hs.len_min, hs.len_max, hs.max_record_bytes, None, None)
+    assert ops.bad_index(bad2) is None
+    assert np.array_equal(ctx.to_numpy(dna), ctx.to_numpy(ref_d)) and np.array_equal(ctx.to_numpy(qual), ctx.to_numpy(ref_q))
+    assert ops.same_pack_params(p, p)
+
+
+def test_pack_stats_wrong_guesses(ctx):
+    """A wrong guess never goes unnoticed: the statistics stay exact (or say they are incomplete) and differ from the guess."""
+    n = 4000
+    host = synth.fastq_array(synth.Spec(S + 7, (36, 301), n_rate=1), n)
+    d_buf = ctx.to_device(host)
+    nlines, ls = _index(ctx, d_buf)
+    st = ops.stats_new(ctx)
+    ops.stats_accumulate(ctx, st, d_buf, ls, 0, n)
+    hs = ops.stats_fetch(ctx, st)
+    d = _decide_from_stats(hs)
+    mk = lambda dd, rec: ops.make_pack_params(dd['bases'], dd['qualities'], dd['N_qual'], dd['bits_per_base'], dd['bits_per_quality'],
+                                              dd['variable_read_lengths'], dd['dna_bytes_per_row'], dd['quality_bytes_per_row'], dd['dna_max'], rec)
+    truth = mk(d, hs.max_record_bytes)
+    # (a) the guess allows for shorter reads than the file holds: counts flagged incomplete
+    short = dict(d); short['dna_max'] = 200
+    lv = 201
+    short['dna_bytes_per_row'] = -(-d['bits_per_base'] * lv // 8); short['quality_bytes_per_row'] = -(-d['bits_per_quality'] * lv // 8)
+    res = ops.pack_stats(ctx, d_buf, ls, 0, n, mk(short, hs.max_record_bytes))
+    assert res is not None and ops.stats_fetch(ctx, res[3]).incomplete
+    # (b) records longer than the guess' tile hint: incomplete as well
+    res = ops.pack_stats(ctx, d_buf, ls, 0, n, mk(d, 300))
+    assert res is not None and ops.stats_fetch(ctx, res[3]).incomplete
+    # (c) a guessed quality alphabet that misses characters: statistics exact and complete -> the decisions differ from the guess
+    fewer = dict(d); fewer['qualities'] = d['qualities'][:-3]
+    g = mk(fewer, hs.max_record_bytes)
+    res = ops.pack_stats(ctx, d_buf, ls, 0, n, g)
+    assert res is not None
+    hs2 = ops.stats_fetch(ctx, res[3])
+    assert not hs2.incomplete and np.array_equal(hs2.counts, hs.counts)
+    assert not ops.same_pack_params(g, truth) and ops.same_pack_params(mk(_decide_from_stats(hs2), hs2.max_record_bytes), truth)
+    # (d) no fused kernel for 3-bit DNA: nothing launched
+    d3 = _decide_from_stats(hs, notricks=True)
+    assert ops.pack_stats(ctx, d_buf, ls, 0, n, mk(d3, hs.max_record_bytes)) is None

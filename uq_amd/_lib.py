@@ -81,6 +81,7 @@ SIGNATURES = {
     'uq_index_stats': [_vp, _vp, _u64, _u64, _vp, _vp, _P(_int)],
     'uq_first_occurrence': [_vp, _vp, _vp, _u64, _u64, _u64, _vp],
     'uq_pack': [_vp, _vp, _vp, _u64, _u64, _P(PackParams), _vp, _vp, _vp],
+    'uq_pack_stats': [_vp, _vp, _vp, _u64, _u64, _P(PackParams), _vp, _vp, _vp, _vp, _P(_int)],
     'uq_pattern': [_vp, _vp, _u64, _u32, _int, _vp],
     'uq_unpattern': [_vp, _vp, _u64, _u32, _int, _vp],
     'uq_argsort_rows': [_vp, _vp, _u64, _u32, _vp],

@@ -23,6 +23,7 @@
 // thread-per-read big-integer addition so the bytes still match.
 #include "common.h"
 #include "swar.h"
+#include "histo.h"
 
 namespace {
 constexpr int PK_THREADS = 256;
@@ -83,17 +84,24 @@ __device__ __noinline__ void store_tile(uint8_t* gdst, const uint8_t* lsrc, uint
 }
 
 constexpr int PK_NV = 5;   // 16-byte loads per lane per tile: a tile spans at most PK_NV * 256 * 16 = 20 KiB
+constexpr int PK_NV_STATS = 4;   // the fused pack + statistics kernel keeps 16 KiB of LDS for the count tables: smaller tiles, same occupancy
 
 // LDS carve (dynamic): [16 B guard][stage][out_d | out_q][meta u32 x (4R+4)][luts 3 x 512 B]
 // Workgroups are persistent: each walks tiles b, b + S, b + 2S, ... with a software pipeline -- the
 // next tile's bytes and line offsets are loaded into registers (in flight) while the current tile is
 // packed out of LDS; span bounds are requested two tiles ahead.
-template <int BD, int BQ, bool NTRICK, bool FAST>
+// STATS: the same pass also produces the pass-1 statistics (uq_stats) of the shard -- the speculative one-pass
+// encode: the caller packs with GUESSED decisions while counting, then checks the guess against the counts
+// (uq_pack_stats).  `st->reserved` is raised when the counts are incomplete (a record longer than the guess
+// allowed for, or malformed): the caller then runs the plain statistics pass.
+template <int BD, int BQ, bool NTRICK, bool FAST, bool STATS>
 __global__ __launch_bounds__(PK_THREADS, 5) void pack_tile_kernel(const uint8_t* __restrict__ buf,
                                                                const uint64_t* __restrict__ ls, uint64_t first,
                                                                uint64_t n, PackLut lut, PackGeom g,
                                                                uint8_t* __restrict__ dna, uint8_t* __restrict__ qual,
-                                                               unsigned long long* __restrict__ bad) {
+                                                               unsigned long long* __restrict__ bad,
+                                                               uq_stats* __restrict__ st, uint32_t win) {
+    constexpr int NV = STATS ? PK_NV_STATS : PK_NV;
     extern __shared__ __align__(16) uint8_t smem[];
     uint8_t* stage = smem + 16;                       // reads of up to 8 bytes below offset 0 stay in bounds
     uint8_t* out_d = stage + g.stage_bytes;
@@ -106,12 +114,16 @@ __global__ __launch_bounds__(PK_THREADS, 5) void pack_tile_kernel(const uint8_t*
     l_dna[tid] = lut.dna_code[tid];
     l_qual[tid] = lut.qual_code[tid];
     if (NTRICK) l_nq[tid] = lut.n_qual[tid];
+    Histo hz;
+    RecordAcc acc;
+    bool incomplete = false;
+    if (STATS) hz.init((uint32_t*)(l_nq + 256), st, win);        // tables zeroed; the first tile's barrier orders it
 
     const uint64_t R = g.R;
     const uint64_t ntiles = (n + R - 1) / R;
     const uint64_t S = gridDim.x;
     struct Bounds { uint64_t g0, g1; };
-    struct Regs { uint4 v[PK_NV]; uint64_t m0; uint64_t g0; uint32_t skew, nvec, Rt; bool ok; };
+    struct Regs { uint4 v[NV]; uint64_t m0; uint64_t g0; uint32_t skew, nvec, Rt; bool ok; };
     auto load_bounds = [&](uint64_t tt) {
         Bounds b{0, 0};
         if (tt < ntiles) {
@@ -124,18 +136,18 @@ __global__ __launch_bounds__(PK_THREADS, 5) void pack_tile_kernel(const uint8_t*
         Regs x;
         x.ok = false; x.m0 = 0; x.g0 = b.g0; x.skew = 0; x.nvec = 0; x.Rt = 0;
 #pragma unroll
-        for (int u = 0; u < PK_NV; ++u) x.v[u] = make_uint4(0, 0, 0, 0);
+        for (int u = 0; u < NV; ++u) x.v[u] = make_uint4(0, 0, 0, 0);
         if (tt >= ntiles) return x;
         x.Rt = (uint32_t)((n - tt * R) < R ? (n - tt * R) : R);
         const uint64_t a0 = ((uint64_t)(uintptr_t)buf + b.g0) & ~uint64_t(15);   // absolute, 16-aligned
         x.skew = (uint32_t)(((uint64_t)(uintptr_t)buf + b.g0) - a0);
         const uint64_t span = b.g1 - b.g0 + x.skew;
         x.nvec = (uint32_t)((span + 15) >> 4);
-        x.ok = span + 32 <= g.stage_bytes && x.nvec <= (uint32_t)(PK_NV * PK_THREADS);
+        x.ok = span + 32 <= g.stage_bytes && x.nvec <= (uint32_t)(NV * PK_THREADS);
         if (!x.ok) return x;                          // a record longer than the caller's max_record_bytes
         const uint4* src = (const uint4*)(uintptr_t)a0;
 #pragma unroll
-        for (int u = 0; u < PK_NV; ++u) { const uint32_t i = u * PK_THREADS + tid; if (i < x.nvec) x.v[u] = src[i]; }
+        for (int u = 0; u < NV; ++u) { const uint32_t i = u * PK_THREADS + tid; if (i < x.nvec) x.v[u] = src[i]; }
         if (tid <= 4 * x.Rt) x.m0 = ls[4 * (first + tt * R) + tid];
         return x;
     };
@@ -156,9 +168,10 @@ __global__ __launch_bounds__(PK_THREADS, 5) void pack_tile_kernel(const uint8_t*
         if (cur.ok) {
             if (tid <= 4 * Rt) meta[tid] = (uint32_t)(cur.m0 - cur.g0) + cur.skew;
 #pragma unroll
-            for (int u = 0; u < PK_NV; ++u) { const uint32_t i = u * PK_THREADS + tid; if (i < cur.nvec) ((uint4*)stage)[i] = cur.v[u]; }
-        } else if (tid == 0) {
-            bad_tile = bad_tile < r0 ? bad_tile : r0;
+            for (int u = 0; u < NV; ++u) { const uint32_t i = u * PK_THREADS + tid; if (i < cur.nvec) ((uint4*)stage)[i] = cur.v[u]; }
+        } else {
+            if (tid == 0) bad_tile = bad_tile < r0 ? bad_tile : r0;
+            incomplete = true;
         }
         __syncthreads();
         const bool ok = cur.ok;
@@ -172,6 +185,11 @@ __global__ __launch_bounds__(PK_THREADS, 5) void pack_tile_kernel(const uint8_t*
                 const uint32_t so = meta[4 * r + 1];
                 uint32_t L = meta[4 * r + 2] - so - 1;
                 const uint32_t qo = meta[4 * r + 3];
+                if (STATS) {
+                    const uint32_t Lq = meta[4 * r + 4] - qo - 1;
+                    if (pp == 0) acc.record(r0 + r, stage[meta[4 * r + 2]] == '+', L, Lq, meta[4 * r + 4] - meta[4 * r]);
+                    if (L > g.dna_max || Lq != L) incomplete = true;        // symbols this kernel does not visit
+                }
                 if (L > g.dna_max || meta[4 * r + 4] - qo - 1 != L) { badr = badr < (uint32_t)(r0 + r) ? badr : (uint32_t)(r0 + r); L = 0; }
                 uint8_t* orow_d = out_d + r * g.Cd + (g.Cd - 1);
                 uint8_t* orow_q = out_q + r * g.Cq + (g.Cq - 1);
@@ -182,6 +200,7 @@ __global__ __launch_bounds__(PK_THREADS, 5) void pack_tile_kernel(const uint8_t*
                     uint32_t b_lo, b_hi, q_lo, q_hi;
                     lds_window8(stage, (int32_t)so + j0, b_lo, b_hi);
                     lds_window8(stage, (int32_t)qo + j0, q_lo, q_hi);
+                    if (STATS && j0 > -8) hz.group8(b_lo, b_hi, q_lo, q_hi, j0 < 0 ? (uint32_t)(-j0) : 0u, lane_id());
                     if (j0 < 0) {   // window reaches above the first base: those symbols are zero (fill with code-0 characters)
                         uint32_t mlo, mhi;
                         window_masks((uint32_t)(-j0), mlo, mhi);
@@ -270,6 +289,12 @@ __global__ __launch_bounds__(PK_THREADS, 5) void pack_tile_kernel(const uint8_t*
     }
     if (badr != 0xFFFFFFFFu) atomicMin(bad, (unsigned long long)badr);
     if (bad_tile != UQ_NONE) atomicMin(bad, (unsigned long long)bad_tile);
+    if (STATS) {
+        __syncthreads();
+        hz.flush();
+        acc.flush(st, first);
+        if (incomplete) st->reserved = 1;
+    }
 }
 
 // Exact big-integer form: thread per read, byte-serial addition with carry, straight from HBM.
@@ -308,12 +333,20 @@ __global__ __launch_bounds__(256) void pack_carry_kernel(const uint8_t* __restri
     while (pq >= 0) { qrow[pq] = (uint8_t)tq; tq >>= 8; --pq; }
 }
 
-typedef void (*PackKernel)(const uint8_t*, const uint64_t*, uint64_t, uint64_t, PackLut, PackGeom, uint8_t*, uint8_t*, unsigned long long*);
+typedef void (*PackKernel)(const uint8_t*, const uint64_t*, uint64_t, uint64_t, PackLut, PackGeom, uint8_t*, uint8_t*, unsigned long long*,
+                           uq_stats*, uint32_t);
 
 template <int BD, int BQ>
 PackKernel pick_nt(bool ntrick, bool fast) {
-    if (BD == 2 && fast) return ntrick ? pack_tile_kernel<2, BQ, true, true> : pack_tile_kernel<2, BQ, false, true>;
-    return ntrick ? pack_tile_kernel<BD, BQ, true, false> : pack_tile_kernel<BD, BQ, false, false>;
+    if (BD == 2 && fast) return ntrick ? pack_tile_kernel<2, BQ, true, true, false> : pack_tile_kernel<2, BQ, false, true, false>;
+    return ntrick ? pack_tile_kernel<BD, BQ, true, false, false> : pack_tile_kernel<BD, BQ, false, false, false>;
+}
+
+// the fused pack + statistics kernels exist for the lookup-free path only (2-bit A/C/G/T, contiguous qualities)
+PackKernel pick_stats_kernel(int bq, bool ntrick) {
+#define UQ_PS(B) case B: return ntrick ? pack_tile_kernel<2, B, true, true, true> : pack_tile_kernel<2, B, false, true, true>;
+    switch (bq) { UQ_PS(1) UQ_PS(2) UQ_PS(3) UQ_PS(4) UQ_PS(5) UQ_PS(6) UQ_PS(7) default: return ntrick ? pack_tile_kernel<2, 8, true, true, true> : pack_tile_kernel<2, 8, false, true, true>; }
+#undef UQ_PS
 }
 
 template <int BD>
@@ -334,9 +367,13 @@ PackKernel pick_kernel(int bd, int bq, bool ntrick, bool fast) {
 }
 }  // namespace
 
-extern "C" int uq_pack(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start, uint64_t first_read,
-                       uint64_t nreads, const uq_pack_params* hp, uint8_t* d_dna, uint8_t* d_qual, uint64_t* d_bad) {
+// d_stats == nullptr: plain pack.  Otherwise the fused pack + statistics kernel, if this geometry has one
+// (*h_fused = 1); if not, nothing is launched and *h_fused = 0.
+static int pack_impl(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start, uint64_t first_read,
+                     uint64_t nreads, const uq_pack_params* hp, uint8_t* d_dna, uint8_t* d_qual, uint64_t* d_bad,
+                     uq_stats* d_stats, int* h_fused) {
     UQ_REQUIRE(ctx && d_buf && d_line_start && hp && d_dna && d_qual && d_bad, "uq_pack: null argument");
+    if (h_fused) *h_fused = 0;
     UQ_REQUIRE(hp->bits_per_base >= 1 && hp->bits_per_base <= 8 && hp->bits_per_quality >= 1 && hp->bits_per_quality <= 8,
                "uq_pack: bits per symbol must be 1..8");
     const uint32_t bd = hp->bits_per_base, bq = hp->bits_per_quality;
@@ -366,11 +403,12 @@ extern "C" int uq_pack(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line
     const bool carry = max_q >= (1 << bq);   // Q9: N quality code == 2^b (or beyond)
     // A tile is at most PK_NV * 256 * 16 B = 20 KiB of FASTQ (what one workgroup keeps in flight in registers).  Records
     // that do not fit (reads beyond ~10 kbp: long-read platforms) take the exact thread-per-read kernel too: slow, never wrong.
-    const uint32_t stage_cap = PK_NV * PK_THREADS * 16;
+    const uint32_t stage_cap = (d_stats ? PK_NV_STATS : PK_NV) * PK_THREADS * 16;
     const uint32_t rec = (uint32_t)hp->max_record_bytes;
     UQ_REQUIRE(rec >= 4, "uq_pack: max_record_bytes not set (take it from uq_stats)");
 
     if (carry || rec + 64 > stage_cap) {
+        if (d_stats) return 0;                   // no fused form of the exact kernel
         uint32_t blocks = (uint32_t)((nreads + 255) / 256);
         pack_carry_kernel<<<blocks, 256, 0, ctx->stream>>>(d_buf, d_line_start, first_read, nreads, lut, bd, bq, Cd, Cq,
                                                            hp->variable ? 1u : 0u, d_dna, d_qual, (unsigned long long*)d_bad);
@@ -397,13 +435,6 @@ extern "C" int uq_pack(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line
     g.R = R;
     g.stage_bytes = stage_cap + 32;
     g.out_bytes = (((R * Cd + 15) & ~15u) + R * Cq + 15) & ~15u;
-    const size_t lds = 16 + (size_t)g.stage_bytes + g.out_bytes + (4 * R + 4) * 4 + 3 * 512;
-    UQ_REQUIRE(lds <= 160 * 1024, "uq_pack: tile needs %zu bytes of LDS", lds);
-    const uint64_t tiles = (nreads + R - 1) / R;
-    uint32_t per_cu = (uint32_t)((160 * 1024) / lds);
-    if (per_cu > 6) per_cu = 6;
-    if (per_cu < 1) per_cu = 1;
-    const uint64_t blocks = tiles < (uint64_t)UQ_NUM_CU * per_cu ? tiles : (uint64_t)UQ_NUM_CU * per_cu;
     // phase B: P lanes per read
     uint32_t P = PK_THREADS / R;
     if (P > g.G) P = g.G;
@@ -427,10 +458,33 @@ extern "C" int uq_pack(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line
         g.q_addhi = 0x01010101u * (uint32_t)(0x80 - qmin - nq);
         if (ntrick_bases == 1) { g.n_char = 0x01010101u * (uint32_t)nchar; g.n_code = 0x01010101u * (uint32_t)hp->n_qual[nchar]; }
     }
-    PackKernel k = pick_kernel((int)bd, (int)bq, ntrick, fast);
+    if (d_stats && !fast) return 0;              // the fused kernels exist for the lookup-free path only
+    const size_t lds = 16 + (size_t)g.stage_bytes + g.out_bytes + (4 * R + 4) * 4 + 3 * 512 + (d_stats ? HZ_WORDS * 4 : 0);
+    UQ_REQUIRE(lds <= 160 * 1024, "uq_pack: tile needs %zu bytes of LDS", lds);
+    const uint64_t tiles = (nreads + R - 1) / R;
+    uint32_t per_cu = (uint32_t)((160 * 1024) / lds);
+    if (per_cu > 6) per_cu = 6;
+    if (per_cu < 1) per_cu = 1;
+    const uint64_t blocks = tiles < (uint64_t)UQ_NUM_CU * per_cu ? tiles : (uint64_t)UQ_NUM_CU * per_cu;
+    // statistics windows: 32 base bytes from '@', 64 quality bytes around the guessed alphabet (speed only)
+    const uint32_t qbase = qmin >= 64 ? 59u : (qmin < 33 ? 0u : 33u);
+    PackKernel k = d_stats ? pick_stats_kernel((int)bq, ntrick) : pick_kernel((int)bd, (int)bq, ntrick, fast);
     if (lds > 48 * 1024) UQ_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     k<<<(uint32_t)blocks, PK_THREADS, lds, ctx->stream>>>(d_buf, d_line_start, first_read, nreads, lut, g, d_dna, d_qual,
-                                                         (unsigned long long*)d_bad);
+                                                         (unsigned long long*)d_bad, d_stats, (64u << 8) | qbase);
     UQ_LAUNCH_CHECK();
+    if (h_fused) *h_fused = 1;
     return 0;
+}
+
+extern "C" int uq_pack(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start, uint64_t first_read,
+                       uint64_t nreads, const uq_pack_params* hp, uint8_t* d_dna, uint8_t* d_qual, uint64_t* d_bad) {
+    return pack_impl(ctx, d_buf, d_line_start, first_read, nreads, hp, d_dna, d_qual, d_bad, nullptr, nullptr);
+}
+
+extern "C" int uq_pack_stats(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start, uint64_t first_read,
+                             uint64_t nreads, const uq_pack_params* h_guess, uint8_t* d_dna, uint8_t* d_qual, uint64_t* d_bad,
+                             uq_stats* d_stats, int* h_fused) {
+    UQ_REQUIRE(d_stats && h_fused, "uq_pack_stats: null argument");
+    return pack_impl(ctx, d_buf, d_line_start, first_read, nreads, h_guess, d_dna, d_qual, d_bad, d_stats, h_fused);
 }

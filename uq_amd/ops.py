@@ -47,6 +47,7 @@ class HostStats:
         self.bad_len = None if bad_len == UQ_NONE else bad_len
         self.len_min, self.len_max = int(s['len_min']), int(s['len_max'])
         self.max_record_bytes = int(s['max_record_bytes'])
+        self.incomplete = bool(s['reserved'])         # set by uq_pack_stats only: counts not usable
 
 
 def stats_new(ctx):
@@ -117,6 +118,27 @@ def pack(ctx, buf, line_start, first_read, nreads, params, dna=None, qual=None):
     bad = t.empty(1, dtype=t.int64, device=ctx.device)
     call('uq_pack', ctx.h, _p(buf), _p(line_start), first_read, nreads, C.byref(params), _p(dna), _p(qual), _p(bad))
     return dna, qual, bad
+
+
+def pack_stats(ctx, buf, line_start, first_read, nreads, guess):
+    """One pass: pack with the GUESSED parameters and accumulate uq_stats of the same reads (uq_pack_stats).
+    Returns (dna, qual, bad, d_stats) or None when there is no fused kernel for this geometry."""
+    t = ctx.torch
+    dna = t.empty(nreads * guess.dna_bytes_per_row, dtype=t.uint8, device=ctx.device)
+    qual = t.empty(nreads * guess.quality_bytes_per_row, dtype=t.uint8, device=ctx.device)
+    bad = t.empty(1, dtype=t.int64, device=ctx.device)
+    st = stats_new(ctx)
+    fused = C.c_int(0)
+    call('uq_pack_stats', ctx.h, _p(buf), _p(line_start), first_read, nreads, C.byref(guess), _p(dna), _p(qual), _p(bad), _p(st), C.byref(fused))
+    return (dna, qual, bad, st) if fused.value else None
+
+
+def same_pack_params(a, b):
+    """Do two uq_pack_params describe the same encoding (everything but the tile-sizing hint)?"""
+    if (a.bits_per_base, a.bits_per_quality, a.variable, a.dna_bytes_per_row, a.quality_bytes_per_row, a.dna_max) != \
+       (b.bits_per_base, b.bits_per_quality, b.variable, b.dna_bytes_per_row, b.quality_bytes_per_row, b.dna_max):
+        return False
+    return bytes(a.dna_code) == bytes(b.dna_code) and bytes(a.qual_code) == bytes(b.qual_code) and bytes(a.n_qual) == bytes(b.n_qual)
 
 
 def bad_index(bad_tensor):

@@ -57,6 +57,8 @@ def build_parser():
     p.add_argument('--device', type=int, default=int(os.environ.get('LOCAL_RANK', '0')), help='GPU index (extension)')
     p.add_argument('--quiet', action='store_true', default=False, help='suppress the analysis report (extension)')
     p.add_argument('--host-qname', action='store_true', default=False, help='run the QNAME passes sequentially on the host (extension)')
+    p.add_argument('--one-pass', action='store_true', default=False,
+                   help='pack speculatively during the statistics pass with the decisions of the previous encode of this process, verify afterwards (extension)')
     return p
 
 
@@ -121,6 +123,8 @@ class Session:
         now = time.time(); d = now - self.split; self.split = now
         return '(' + str(d / 60) + ' minutes)'
 
+    last_params = None         # uq_pack_params of the previous encode in this process: the guess of the one-pass encoder
+
     # ------------------------------------------------------------------ passes 1-2 (analysis)
     def load(self, path):
         """Read the FASTQ, put it in HBM, build the record index.  Replaces `wc -l` + line iteration."""
@@ -133,7 +137,21 @@ class Session:
             error('ERROR: The FASTQ file provided contains' + str(nlines) + 'rows, which is not divisible by 4!')
         if nlines == 0: error('ERROR: empty input')
         self.total = nlines // 4
-        self.d_ls, self.d_stats = ops.index_and_stats(ctx, self.d_buf, nlines)   # record index + pass-1 statistics
+        self.d_ls = ops.index_lines(ctx, self.d_buf, nlines)                     # record index
+        # pass-1 statistics.  With --one-pass, and when this process has encoded before, pack speculatively with those
+        # decisions in the same pass over the stream (uq_pack_stats); analyse() / _encode() keep the tables only if the
+        # real decisions agree.  (One HBM pass less, but the fused kernel is latency-bound: not the default.)
+        self._spec = None
+        guess = Session.last_params
+        if guess is not None and getattr(self.args, 'one_pass', False) and \
+                self.total * (guess.dna_bytes_per_row + guess.quality_bytes_per_row) <= 2 * self.d_buf.numel():   # a guess of another scale is no guess
+            res = ops.pack_stats(ctx, self.d_buf, self.d_ls, 0, self.total, guess)
+            if res is not None:
+                self._spec = (guess,) + res[:3]
+                self.d_stats = res[3]
+        if self._spec is None:
+            self.d_stats = ops.stats_new(ctx)
+            ops.stats_accumulate(ctx, self.d_stats, self.d_buf, self.d_ls, 0, self.total)
 
     @property
     def host(self):
@@ -144,7 +162,13 @@ class Session:
 
     # small seams the sharded session (uq_amd/dist_encode.py) overrides
     def fetch_stats(self):
-        return self.ops.stats_fetch(self.ctx, self.d_stats)
+        hs = self.ops.stats_fetch(self.ctx, self.d_stats)
+        if hs.incomplete:                        # the speculative pass could not count everything: plain statistics pass
+            self._spec = None
+            self.d_stats = self.ops.stats_new(self.ctx)
+            self.ops.stats_accumulate(self.ctx, self.d_stats, self.d_buf, self.d_ls, 0, self.total)
+            hs = self.ops.stats_fetch(self.ctx, self.d_stats)
+        return hs
 
     def starts_with_at(self):
         return int(self.d_buf[0]) == ord('@')
@@ -236,7 +260,15 @@ class Session:
         ops, ctx, d = self.ops, self.ctx, self.d
         p = ops.make_pack_params(d['bases'], d['qualities'], d['N_qual'], d['bits_per_base'], d['bits_per_quality'],
                                  variable, d['dna_bytes_per_row'], d['quality_bytes_per_row'], d['dna_max'], self.hs.max_record_bytes)
-        dna, qual, bad = ops.pack(ctx, self.d_buf, self.d_ls, 0, self.total, p)
+        spec = getattr(self, '_spec', None)
+        self._spec = None
+        self.pack_path = 'one-pass' if (spec is not None and ops.same_pack_params(p, spec[0])) else 'two-pass'
+        if self.pack_path == 'one-pass':
+            dna, qual, bad = spec[1:]            # packed while the statistics were counted: the guess was right
+        else:
+            del spec
+            dna, qual, bad = ops.pack(ctx, self.d_buf, self.d_ls, 0, self.total, p)
+        Session.last_params = p
         b = ops.bad_index(bad)
         if b is not None: error('ERROR: read %d holds a symbol with no code (internal inconsistency)' % b)
         return ((dna, self.total, d['dna_bytes_per_row']), (qual, self.total, d['quality_bytes_per_row']))
