@@ -118,6 +118,12 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise UqHipError('%s not found: build it with `python -m uq_amd.build` (hipcc, gfx950). '
                          'There is no CPU fallback.' % LIB_PATH)
+    try:
+        # one HIP runtime per process: torch ships its own libamdhip64; loading it first makes libuqhip.so bind to the
+        # same one (loaded the other way round, the two runtimes disagree about the visible devices)
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     lib.uq_last_error.restype = C.c_char_p
     lib.uq_last_error.argtypes = []
