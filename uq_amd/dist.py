@@ -32,19 +32,24 @@ def shard_range(total, rank, world):
 
 
 def allreduce_stats_tensors(counts_i64, mins_u64_as_i64, len_min, len_max, rec_max, dist=None):
-    """All-reduce the pieces of uq_stats with TWO collectives: SUM over the 512 KiB count table, and one
-    MAX over five scalars.  The minima ride in the MAX as bitwise complements (MIN(x) = ~MAX(~x));
-    `mins_u64_as_i64` are unsigned, so their sign bit is flipped first (signed order == unsigned order)."""
+    """All-reduce the pieces of uq_stats with ONE collective: a SUM over the 512 KiB count table with 5 extra
+    slots per rank appended -- every rank writes its five scalars (two unsigned minima with the sign bit flipped
+    so that signed order == unsigned order, len_min, len_max, max record bytes) into its own slots and zeros
+    elsewhere, so after the SUM everybody holds everybody's scalars and takes the MIN / MAX locally."""
     import torch
     if dist is None:
         dist, _, _ = _world()
     if dist is None:
         return
-    dist.all_reduce(counts_i64, op=dist.ReduceOp.SUM)
-    pack = torch.cat([~(mins_u64_as_i64 ^ _SIGN), ~len_min.reshape(1), len_max.reshape(1), rec_max.reshape(1)])
-    dist.all_reduce(pack, op=dist.ReduceOp.MAX)
-    mins_u64_as_i64.copy_((~pack[0:2]) ^ _SIGN)
-    len_min.copy_(~pack[2:3]); len_max.copy_(pack[3:4]); rec_max.copy_(pack[4:5])
+    world, rank = dist.get_world_size(), dist.get_rank()
+    slots = torch.zeros(world * 5, dtype=torch.int64, device=counts_i64.device)
+    slots[rank * 5:rank * 5 + 5] = torch.cat([mins_u64_as_i64 ^ _SIGN, len_min.reshape(1), len_max.reshape(1), rec_max.reshape(1)])
+    buf = torch.cat([counts_i64, slots])
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    counts_i64.copy_(buf[:counts_i64.numel()])
+    s = buf[counts_i64.numel():].reshape(world, 5)
+    mins_u64_as_i64.copy_(s[:, 0:2].min(dim=0).values ^ _SIGN)
+    len_min.copy_(s[:, 2].min().reshape(1)); len_max.copy_(s[:, 3].max().reshape(1)); rec_max.copy_(s[:, 4].max().reshape(1))
 
 
 def allreduce_stats_inplace(t, stats_bytes, read_offset=0):

@@ -6,7 +6,7 @@ one `.uQ` file together (BASELINE configs[3] is this with `--sort 
 The result is byte-for-byte the file the single-GPU CLI writes (members and config; tar mtimes aside):
   load      each rank streams its byte range of the file (+ slack) to HBM; an all-gather of the number of line
             starts per range tells every rank where its first record begins
-  pass 1    local `uq_stats`, all-reduced (two collectives) -> identical decisions everywhere
+  pass 1    local `uq_stats`, all-reduced (one collective) -> identical decisions everywhere
   QNAME     the device QNAME passes over shards (uq_amd.qname_device with a `Shard`)
   pass 3    local pack
   tables    `--sort`: sample sort over the ranks (dist.global_sort_rows: all-to-all(v) of rows by key range, equal
