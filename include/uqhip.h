@@ -70,6 +70,13 @@ typedef struct uq_stats {
 int uq_stats_init(uq_ctx* ctx, uq_stats* d_stats);
 int uq_stats_accumulate(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start,
                         uint64_t first_read, uint64_t nreads, uq_stats* d_stats);
+/* Multi-GPU: a uq_stats as ONE summable buffer of 65536 + 6 * world int64 words.  uq_stats_export writes the
+ * counts and, in this rank's six slots, bad_plus / bad_len (made file-wide by adding read_offset; sign bit flipped so that
+ * signed order == unsigned order), len_min, len_max, max_record_bytes and the `reserved` flag; the other ranks' slots are 0.
+ * After an all-reduce SUM of the buffer (RCCL), uq_stats_import folds everybody's slots with MIN / MAX back into d_stats:
+ * one collective per statistics exchange. */
+int uq_stats_export(uq_ctx* ctx, const uq_stats* d_stats, uint32_t rank, uint32_t world, uint64_t read_offset, int64_t* d_words);
+int uq_stats_import(uq_ctx* ctx, const int64_t* d_words, uint32_t world, uq_stats* d_stats);
 /* Record index AND pass-1 statistics in one pass over the stream (reads the FASTQ once instead of twice):
  * equivalent to uq_index_lines(...) followed by uq_stats_accumulate(..., 0, nlines / 4, ...).  Needs
  * nlines % 4 == 0 (from uq_count_lines on the same buffer).  *h_fused = 1 when done; 0 when the input

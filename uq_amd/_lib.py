@@ -78,6 +78,8 @@ SIGNATURES = {
     'uq_index_lines': [_vp, _vp, _u64, _u64, _vp],
     'uq_stats_init': [_vp, _vp],
     'uq_stats_accumulate': [_vp, _vp, _vp, _u64, _u64, _vp],
+    'uq_stats_export': [_vp, _vp, _u32, _u32, _u64, _vp],
+    'uq_stats_import': [_vp, _vp, _u32, _vp],
     'uq_index_stats': [_vp, _vp, _u64, _u64, _vp, _vp, _P(_int)],
     'uq_first_occurrence': [_vp, _vp, _vp, _u64, _u64, _u64, _vp],
     'uq_pack': [_vp, _vp, _vp, _u64, _u64, _P(PackParams), _vp, _vp, _vp],

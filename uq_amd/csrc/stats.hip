@@ -260,6 +260,46 @@ __global__ __launch_bounds__(ST_THREADS) void stats_kernel(const uint8_t* __rest
     }
 }
 
+// ---- multi-GPU: a uq_stats as ONE summable buffer.  words [0, 65536) = counts; then 6 words per rank:
+// the rank's bad_plus / bad_len (made file-wide, sign bit flipped so that signed order == unsigned order), len_min,
+// len_max, max_record_bytes, the `incomplete` flag in its own slots and zeros in the others -- after an all-reduce SUM every rank holds
+// everybody's scalars and folds them with MIN / MAX.
+constexpr long long ST_SIGN = (long long)0x8000000000000000ull;
+
+__global__ void stats_export_kernel(const uq_stats* __restrict__ st, uint32_t rank, uint32_t world, uint64_t read_offset, long long* __restrict__ buf) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 65536) { buf[i] = (long long)st->counts[i]; return; }
+    const uint32_t j = i - 65536;
+    if (j >= world * 6) return;
+    long long v = 0;
+    if (j / 6 == rank) {
+        switch (j % 6) {
+            case 0: v = (long long)(st->bad_plus == UQ_NONE ? UQ_NONE : st->bad_plus + read_offset) ^ ST_SIGN; break;
+            case 1: v = (long long)(st->bad_len == UQ_NONE ? UQ_NONE : st->bad_len + read_offset) ^ ST_SIGN; break;
+            case 2: v = st->len_min; break;
+            case 3: v = st->len_max; break;
+            case 4: v = st->max_record_bytes; break;
+            default: v = st->reserved; break;
+        }
+    }
+    buf[i] = v;
+}
+
+__global__ void stats_import_kernel(const long long* __restrict__ buf, uint32_t world, uq_stats* __restrict__ st) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 65536) st->counts[i] = (uint64_t)buf[i];
+    if (i == 0) {
+        long long bp = 0x7FFFFFFFFFFFFFFFll, bl = bp, lmin = bp, lmax = 0, rmax = 0, inc = 0;
+        for (uint32_t r = 0; r < world; ++r) {
+            const long long* s = buf + 65536 + 6 * r;
+            bp = s[0] < bp ? s[0] : bp; bl = s[1] < bl ? s[1] : bl; lmin = s[2] < lmin ? s[2] : lmin;
+            lmax = s[3] > lmax ? s[3] : lmax; rmax = s[4] > rmax ? s[4] : rmax; inc = s[5] > inc ? s[5] : inc;
+        }
+        st->bad_plus = (uint64_t)(bp ^ ST_SIGN); st->bad_len = (uint64_t)(bl ^ ST_SIGN);
+        st->len_min = (uint32_t)lmin; st->len_max = (uint32_t)lmax; st->max_record_bytes = (uint32_t)rmax; st->reserved = (uint32_t)inc;
+    }
+}
+
 __global__ void stats_init_kernel(uq_stats* st) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < 65536) st->counts[i] = 0;
@@ -297,6 +337,21 @@ __global__ __launch_bounds__(256) void first_occurrence_kernel(const uint8_t* __
 extern "C" int uq_stats_init(uq_ctx* ctx, uq_stats* d_stats) {
     UQ_REQUIRE(ctx && d_stats, "uq_stats_init: null argument");
     stats_init_kernel<<<256, 256, 0, ctx->stream>>>(d_stats);
+    UQ_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int uq_stats_export(uq_ctx* ctx, const uq_stats* d_stats, uint32_t rank, uint32_t world, uint64_t read_offset, int64_t* d_words) {
+    UQ_REQUIRE(ctx && d_stats && d_words && world >= 1 && rank < world, "uq_stats_export: bad argument");
+    const uint32_t n = 65536 + 6 * world;
+    stats_export_kernel<<<(n + 255) / 256, 256, 0, ctx->stream>>>(d_stats, rank, world, read_offset, (long long*)d_words);
+    UQ_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int uq_stats_import(uq_ctx* ctx, const int64_t* d_words, uint32_t world, uq_stats* d_stats) {
+    UQ_REQUIRE(ctx && d_stats && d_words && world >= 1, "uq_stats_import: bad argument");
+    stats_import_kernel<<<256, 256, 0, ctx->stream>>>((const long long*)d_words, world, d_stats);
     UQ_LAUNCH_CHECK();
     return 0;
 }

@@ -76,9 +76,22 @@ def allreduce_stats_inplace(t, stats_bytes, read_offset=0):
 
 
 def allreduce_stats(ctx, d_stats, read_offset=0):
-    """All-reduce a device `uq_stats` over the process group and fetch it."""
+    """All-reduce a device `uq_stats` over the process group and fetch it: export kernel -> ONE all-reduce SUM ->
+    import kernel (uq_stats_export / uq_stats_import; allreduce_stats_inplace is the same exchange spelled in
+    tensor operations, for the CPU tests)."""
+    import ctypes
     from . import ops
-    allreduce_stats_inplace(ctx.torch, d_stats, read_offset)
+    from ._lib import call
+    dist, rank, world = _world()
+    if dist is not None:
+        t = ctx.torch
+        buf = t.empty(65536 + 6 * world, dtype=t.int64, device=ctx.device)
+        call('uq_stats_export', ctx.h, ctypes.c_void_p(d_stats.data_ptr()), rank, world, int(read_offset), ctypes.c_void_p(buf.data_ptr()))
+        if dist.get_backend() == 'gloo':
+            host = buf.cpu(); dist.all_reduce(host, op=dist.ReduceOp.SUM); buf.copy_(host)      # rehearsal on one card
+        else:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        call('uq_stats_import', ctx.h, ctypes.c_void_p(buf.data_ptr()), world, ctypes.c_void_p(d_stats.data_ptr()))
     return ops.stats_fetch(ctx, d_stats)
 
 
