@@ -198,6 +198,64 @@ def test_cli_errors(ctx, tmp_path):
         uq.validate_args(uq.build_parser().parse_args(['-i', str(p), '--sort', 'bogus']))
 
 
+def _fuzz_case(rng):
+    """A random FASTQ (alphabets, quality ranges, lengths, QNAME family) and random CLI flags."""
+    n = int(rng.integers(1, 500))
+    bases = [b'ACGT', b'ACGTN', b'ACGTNRYKM', b'acgtn', b'AC', b'ACGTUWSBDHVN-.'][int(rng.integers(0, 6))]
+    quals = [bytes(range(33, 74)), b'#-<F', bytes(range(64, 105)), b'!I', bytes(range(35, 127, 3)), b'5'][int(rng.integers(0, 6))]
+    fixed = rng.random() < 0.4
+    lo = int(rng.integers(1, 40)); hi = lo if fixed else lo + int(rng.integers(1, 120))
+    n_single_quality = rng.random() < 0.5            # N always with one quality (the N-trick applies)
+    fam = int(rng.integers(0, 8))                    # 0-5: separators the reference copes with; 6, 7: families it tends to refuse
+    s1, s2 = b':_#;='[int(rng.integers(0, 5))], b':_#;='[int(rng.integers(0, 5))]
+    recs = []
+    B = np.frombuffer(bases, np.uint8); Q = np.frombuffer(quals, np.uint8)
+    for i in range(n):
+        L = int(rng.integers(lo, hi + 1))
+        s = rng.choice(B, L); q = rng.choice(Q, L)
+        if n_single_quality and (b'N' in bases):
+            q[s == ord('N')] = Q[0]
+        if fam <= 5: name = b'@q%c%d%c%d' % (s1, i % 7, s2, 3 * i + 1)
+        elif fam == 6: name = b'@run7_%d/%d' % (1000 - i, 1 + i % 2)
+        else: name = b'@x.%s.%d' % ([b'aa', b'b', b'cde'][i % 3], i)
+        recs.append(name + b'\n' + bytes(s) + b'\n+\n' + bytes(q) + b'\n')
+    flags = []
+    if rng.random() < 0.6: flags += ['--sort', ['DNA', 'QUAL', 'QNAME', 'None'][int(rng.integers(0, 4))]]
+    raw = [t for t in ('DNA', 'QUAL', 'QNAME') if rng.random() < 0.5]
+    if raw: flags += ['--raw'] + raw
+    if rng.random() < 0.5:
+        ids = ['0.1', '0.2', '1.1', '1.2', '2.1', '2.2', '3.1', '3.2']
+        flags += ['--pattern', ids[int(rng.integers(0, 8))], ids[int(rng.integers(0, 8))]]
+    if rng.random() < 0.3: flags.append('--notricks')
+    if rng.random() < 0.3: flags.append('--pad')
+    return b''.join(recs), flags
+
+
+@pytest.mark.parametrize('seed', range(48))
+def test_cli_fuzz_against_oracle(ctx, tmp_path, seed):
+    """Differential fuzz of the whole CLI: random alphabets / bit widths / lengths / QNAME families / flag mixes."""
+    fq, flags = _fuzz_case(np.random.default_rng(1000 + seed))
+    of = _oracle_flags(flags)
+    try:
+        ocfg, omembers, _ = O.encode(fq, **of)
+    except Exception:                           # the reference refuses this input (e.g. no QNAME separator): so must the CLI
+        with pytest.raises((uq.UqError, Exception)):
+            _run_encode(ctx, tmp_path, fq, flags)
+        return
+    cfg, members, names, path = _run_encode(ctx, tmp_path, fq, flags)
+    assert set(members) == set(omembers)
+    for k in omembers:
+        assert members[k] == omembers[k], (k, flags)
+    for k in ocfg:
+        if k in ('sort', 'raw', 'pattern'): continue
+        assert json.loads(json.dumps(cfg[k])) == json.loads(json.dumps(ocfg[k])), k
+    if ocfg['N_qual'] and max(ocfg['N_qual'].values()) >= len(ocfg['qualities']):
+        return                                  # Q9: a NEW N quality code is not decodable by the reference's own decoder either
+    text = _run_decode(ctx, path)
+    assert text.decode('latin-1') == O.decode(ocfg, omembers)
+    if of['sort'] is None: assert text == fq
+
+
 def test_cli_one_pass_speculation(ctx, tmp_path):
     """--one-pass: the second encode of a process packs during the statistics pass with the first one's decisions; a file
     whose decisions differ falls back to the separate pack.  The output never depends on the path taken."""
