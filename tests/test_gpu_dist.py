@@ -62,28 +62,42 @@ def test_sharded_encode_equals_oracle(tmp_path, world, flags):
     _check(tmp_path, world, flags)
 
 
-def _check(tmp_path, world, flags, backend='gloo'):
-    fq = synth.fastq(20261003 + 40, 3000, (30, 61), n_rate=2, dup='both', dup_templates=40)
+def test_sharded_encode_with_idle_ranks(tmp_path):
+    """Two reads over three ranks: a rank without reads still takes part in every exchange."""
+    fq = b'@a:1:7\nACGTN\n+\nIHIH#\n@a:2:9\nACGTA\n+\nHIHII\n'
+    _check(tmp_path, 3, ['--sort', 'DNA'], fq=fq)
+    _check(tmp_path, 3, ['--raw', 'DNA', 'QUAL', 'QNAME'], fq=fq)
+
+
+@pytest.mark.parametrize('seed', [1000, 1007, 1013, 1021, 1034, 1046])
+def test_sharded_encode_fuzz(tmp_path, seed):
+    """Random alphabets / widths / lengths / flag mixes (the generator of test_gpu_e2e's CLI fuzz) through 2 or 3 ranks;
+    tiny files leave ranks without reads."""
+    import numpy as np
+    from test_gpu_e2e import _fuzz_case, _oracle_flags
+    fq, flags = _fuzz_case(np.random.default_rng(seed))
+    try:
+        O.encode(fq, **_oracle_flags(flags))
+    except Exception:
+        pytest.skip('the reference refuses this input')
+    _check(tmp_path, 2 + seed % 2, flags, fq=fq)
+
+
+def _check(tmp_path, world, flags, backend='gloo', fq=None):
+    if fq is None: fq = synth.fastq(20261003 + 40, 3000, (30, 61), n_rate=2, dup='both', dup_templates=40)
     inp = tmp_path / 'in.fastq'; inp.write_bytes(fq)
     out = tmp_path / 'out.uQ'
     _run_sharded(world, inp, out, flags, backend)
     cfg, members = O.read_tar(str(out))
 
-    def opt(k, n):
-        if k in flags:
-            i = flags.index(k); return flags[i + 1:i + 1 + n]
-    raw = None
-    if '--raw' in flags:
-        raw = []
-        for x in flags[flags.index('--raw') + 1:]:
-            if x.startswith('--'): break
-            raw.append(x)
-    sort = opt('--sort', 1)
-    ocfg, omembers, _ = O.encode(fq, sort=sort[0] if sort else None, raw=raw, pattern=opt('--pattern', 2), notricks='--notricks' in flags)
+    from test_gpu_e2e import _oracle_flags
+    of = _oracle_flags(flags)
+    ocfg, omembers, _ = O.encode(fq, **of)
     assert set(members) == set(omembers)
     for k in omembers:
         assert members[k] == omembers[k], k
     for k in ocfg:
         if k in ('sort', 'raw', 'pattern'): continue
         assert json.loads(json.dumps(cfg[k])) == json.loads(json.dumps(ocfg[k])), k
-    assert O.decode(cfg, members) == fq.decode('latin-1') or sort is not None
+    new_n_code = ocfg['N_qual'] and max(ocfg['N_qual'].values()) >= len(ocfg['qualities'])      # Q9: not decodable by the reference either
+    assert of['sort'] is not None or new_n_code or O.decode(cfg, members) == fq.decode('latin-1')

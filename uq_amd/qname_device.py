@@ -90,7 +90,7 @@ def infer_layout_device(ctx, d_buf, d_ls, nreads, shard=None):
         o = ctx.to_numpy(d_ls[4 * (nreads - 1):4 * (nreads - 1) + 2], np.uint64)
         last = _fetch_bytes(ctx, d_buf, int(o[0]), int(o[1]) - 1)
     if shard is not None:
-        last = [b for b in shard.gather_bytes(last + b'\n') if b][-1][:-1]   # the last QNAME of the whole file
+        last = [b for b in shard.gather_bytes(last + b'\n' if nreads else b'') if b][-1][:-1]   # the last QNAME of the whole file
     last = last.decode('latin-1')
 
     def order_seps(q):
