@@ -231,7 +231,7 @@ def _fuzz_case(rng):
     return b''.join(recs), flags
 
 
-@pytest.mark.parametrize('seed', range(48))
+@pytest.mark.parametrize('seed', range(int(os.environ.get('UQ_FUZZ_N', '48'))))      # UQ_FUZZ_N=2000 for a longer hunt
 def test_cli_fuzz_against_oracle(ctx, tmp_path, seed):
     """Differential fuzz of the whole CLI: random alphabets / bit widths / lengths / QNAME families / flag mixes."""
     fq, flags = _fuzz_case(np.random.default_rng(1000 + seed))
@@ -242,7 +242,7 @@ def test_cli_fuzz_against_oracle(ctx, tmp_path, seed):
         with pytest.raises((uq.UqError, Exception)):
             _run_encode(ctx, tmp_path, fq, flags)
         return
-    cfg, members, names, path = _run_encode(ctx, tmp_path, fq, flags)
+    cfg, members, names, path = _run_encode(ctx, tmp_path, fq, flags + os.environ.get('UQ_FUZZ_FLAGS', '').split())   # e.g. --one-pass
     assert set(members) == set(omembers)
     for k in omembers:
         assert members[k] == omembers[k], (k, flags)
