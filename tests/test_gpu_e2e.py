@@ -213,11 +213,12 @@ def test_cli_errors(ctx, tmp_path):
 
 def _fuzz_case(rng):
     """A random FASTQ (alphabets, quality ranges, lengths, QNAME family) and random CLI flags."""
-    n = int(rng.integers(1, 500))
+    scale = int(os.environ.get('UQ_FUZZ_SCALE', '1'))          # > 1: many tiles per kernel, reads up to 508 bp (slow oracle)
+    n = int(rng.integers(1, 500)) * scale
     bases = [b'ACGT', b'ACGTN', b'ACGTNRYKM', b'acgtn', b'AC', b'ACGTUWSBDHVN-.'][int(rng.integers(0, 6))]
     quals = [bytes(range(33, 74)), b'#-<F', bytes(range(64, 105)), b'!I', bytes(range(35, 127, 3)), b'5'][int(rng.integers(0, 6))]
     fixed = rng.random() < 0.4
-    lo = int(rng.integers(1, 40)); hi = lo if fixed else lo + int(rng.integers(1, 120))
+    lo = int(rng.integers(1, 40)); hi = lo if fixed else lo + int(rng.integers(1, 120 if scale == 1 else 460))
     n_single_quality = rng.random() < 0.5            # N always with one quality (the N-trick applies)
     fam = int(rng.integers(0, 8))                    # 0-5: separators the reference copes with; 6, 7: families it tends to refuse
     s1, s2 = b':_#;='[int(rng.integers(0, 5))], b':_#;='[int(rng.integers(0, 5))]
