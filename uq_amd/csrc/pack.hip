@@ -197,6 +197,8 @@ __global__ __launch_bounds__(PK_THREADS, 5) void pack_tile_kernel(const uint8_t*
                     // symbols t = 8gg .. 8gg+7 (t counts from the END of the read) = characters j = L-1-t, i.e. the
                     // 8 bytes ending at position L - 8gg; byte k of the window is character j = j0 + k
                     const int32_t j0 = (int32_t)L - 8 * (int32_t)gg - 8;
+                    uint64_t vd = 0, vq = 0;
+                    if (j0 > -8) {      // else: the whole group lies above the read (rows are sized for the longest one): zeros
                     uint32_t b_lo, b_hi, q_lo, q_hi;
                     lds_window8(stage, (int32_t)so + j0, b_lo, b_hi);
                     lds_window8(stage, (int32_t)qo + j0, q_lo, q_hi);
@@ -253,8 +255,9 @@ __global__ __launch_bounds__(PK_THREADS, 5) void pack_tile_kernel(const uint8_t*
                         }
                         ad0 = ad[0]; ad1 = ad[1]; aq0 = aq[0]; aq1 = aq[1];
                     }
-                    uint64_t vd = ((uint64_t)ad0 << (4 * BD)) | ad1;
-                    uint64_t vq = ((uint64_t)aq0 << (4 * BQ)) | aq1;
+                    vd = ((uint64_t)ad0 << (4 * BD)) | ad1;
+                    vq = ((uint64_t)aq0 << (4 * BQ)) | aq1;
+                    }
                     if (g.variable) {                                  // sentinel = code 1 at symbol index t = L
                         const int32_t i = (int32_t)L - 8 * (int32_t)gg;
                         if (i >= 0 && i < 8) { vd |= 1ull << (BD * i); vq |= 1ull << (BQ * i); }
