@@ -12,8 +12,8 @@ One step = one pass of the hot path over the shard:
     -> [N > 1: all-reduce of the statistics over RCCL, the path's only exchange without --sort]
     -> alphabet / N-trick / bit-width decisions on the host (uq.py:448-545)
     -> DNA 2-bit + QUAL 6-bit pack into the raw tables (pattern 0.1 = the tables as packed).
-QNAME column parsing is the reference's host-Python passes 2+4 ("next") and is not
-part of this step.  `value` = FASTQ bytes of all ranks / time, MAX over ranks.
+The QNAME passes (on the device in the CLI, tools/bench_e2e.py times them) are not part of this
+step.  `value` = FASTQ bytes of all ranks / time, MAX over ranks.
 Besides the contract fields the JSON line carries `roofline` (pack kernel, HIP-event timed inside the
 timed region on the launch stream) and `cpu_baseline` (the faithful per-base Python loops of the
 oracle on one host core, on a bounded sample of the same input; rank 0, N = 1 only).
@@ -168,7 +168,7 @@ def main():
         d = host_decide(hs, notricks=notricks)
         p = ops.make_pack_params(d['bases'], d['qualities'], d['N_qual'], d['bits_per_base'], d['bits_per_quality'],
                                  d['variable_read_lengths'], d['dna_bytes_per_row'], d['quality_bytes_per_row'],
-                                 d['dna_max'], hs.max_record_bytes)
+                                 d['dna_max'], hs.max_record_bytes, avg_record_bytes=fastq_bytes // max(nreads, 1))
         if spec is not None and ops.same_pack_params(p, guess):
             dna, qual, bad = spec[:3]
             kernel = 'pack_tile_kernel<STATS> (pack + pass-1 statistics in one pass)'

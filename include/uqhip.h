@@ -102,7 +102,7 @@ typedef struct uq_pack_params {
     int32_t dna_bytes_per_row, quality_bytes_per_row;
     int32_t max_record_bytes;   /* from uq_stats (tile sizing) */
     int32_t dna_max;            /* longest read */
-    int32_t reserved;
+    int32_t avg_record_bytes;   /* optional: mean record bytes (tile sizing for variable-length files), 0 = unknown */
 } uq_pack_params;
 /* Packs reads [first_read, first_read + nreads) into d_dna / d_qual rows [0, nreads).
  * *d_bad (device, 8 bytes, pre-set to UQ_NONE by the callee) = smallest local read index holding a

@@ -276,6 +276,41 @@ def test_pack_matches_reference_golden(ctx, name):
     assert np.array_equal(qual, O.unpattern(members['QUAL.raw']))
 
 
+@pytest.mark.parametrize('fused', [False, True], ids=['pack', 'pack_stats'])
+def test_pack_tiles_sized_from_the_average_record(ctx, fused):
+    """Tiles hold R reads with R taken from the AVERAGE record; a tile of unusually long records does not fit the
+    stage and is packed in pieces (and, fused, still counted completely)."""
+    rng = np.random.default_rng(5)
+    recs = []
+    for i in range(2600):
+        L = 480 if 900 <= i < 1010 or i % 577 == 3 else int(rng.integers(10, 31))      # a run of long reads among short ones
+        recs.append(b'@r:%d\n' % i + bytes(rng.choice(np.frombuffer(b'ACGT', np.uint8), L)) + b'\n+\n' +
+                    bytes(rng.integers(33, 74, L, dtype=np.uint8)) + b'\n')
+    host = np.frombuffer(b''.join(recs), dtype=np.uint8).copy()
+    n = len(recs)
+    d_buf = ctx.to_device(host)
+    nlines, ls = _index(ctx, d_buf)
+    st = ops.stats_new(ctx)
+    ops.stats_accumulate(ctx, st, d_buf, ls, 0, n)
+    hs = ops.stats_fetch(ctx, st)
+    d = _decide_from_stats(hs)
+    p = ops.make_pack_params(d['bases'], d['qualities'], d['N_qual'], d['bits_per_base'], d['bits_per_quality'], d['variable_read_lengths'],
+                             d['dna_bytes_per_row'], d['quality_bytes_per_row'], d['dna_max'], hs.max_record_bytes,
+                             avg_record_bytes=host.size // n)
+    assert host.size // n < hs.max_record_bytes // 8           # the average really is far below the longest record
+    if fused:
+        dna, qual, bad, st2 = ops.pack_stats(ctx, d_buf, ls, 0, n, p)
+        hs2 = ops.stats_fetch(ctx, st2)
+        assert not hs2.incomplete and np.array_equal(hs2.counts, hs.counts) and (hs2.len_min, hs2.len_max) == (hs.len_min, hs.len_max)
+    else:
+        dna, qual, bad = ops.pack(ctx, d_buf, ls, 0, n, p)
+    assert ops.bad_index(bad) is None
+    hls = oracle_c.index_lines(host)
+    rd, rq, rbad = oracle_c.pack(host, hls, 0, n, d['bases'], d['qualities'], d['N_qual'], d['bits_per_base'], d['bits_per_quality'],
+                                 d['variable_read_lengths'], d['dna_bytes_per_row'], d['quality_bytes_per_row'])
+    assert np.array_equal(ctx.to_numpy(dna).reshape(n, -1), rd) and np.array_equal(ctx.to_numpy(qual).reshape(n, -1), rq)
+
+
 FUSED_CASES = [('fixed150', 4096 + 37, 150, {}), ('fixed100', 3000, 100, {}), ('var_ntrick', 5000, (36, 301), dict(n_rate=1)),
                ('short_var', 2000, (1, 12), {})]
 

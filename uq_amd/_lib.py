@@ -25,7 +25,7 @@ class PackParams(C.Structure):
     _fields_ = [('dna_code', C.c_int16 * 256), ('qual_code', C.c_int16 * 256), ('n_qual', C.c_int32 * 256),
                 ('bits_per_base', C.c_int32), ('bits_per_quality', C.c_int32), ('variable', C.c_int32),
                 ('dna_bytes_per_row', C.c_int32), ('quality_bytes_per_row', C.c_int32),
-                ('max_record_bytes', C.c_int32), ('dna_max', C.c_int32), ('reserved', C.c_int32)]
+                ('max_record_bytes', C.c_int32), ('dna_max', C.c_int32), ('avg_record_bytes', C.c_int32)]
 
 
 class UnpackParams(C.Structure):

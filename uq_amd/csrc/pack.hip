@@ -35,7 +35,8 @@ struct PackLut {
 };
 
 struct PackGeom {
-    uint32_t R;            // reads per tile
+    uint32_t R;            // reads per tile (sized from the average record)
+    uint32_t Rs;           // reads per piece when a tile's records do not fit the stage (sized from the longest record)
     uint32_t Cd, Cq;       // bytes per row
     uint32_t G;            // 8-symbol groups per row = ceil((dna_max + variable) / 8)
     uint32_t variable;
@@ -132,38 +133,36 @@ __global__ __launch_bounds__(PK_THREADS, 5) void pack_tile_kernel(const uint8_t*
         }
         return b;
     };
-    auto issue = [&](uint64_t tt, Bounds b) {
+    auto tile_reads = [&](uint64_t tt) -> uint32_t { return tt < ntiles ? (uint32_t)((n - tt * R) < R ? (n - tt * R) : R) : 0u; };
+    // request the bytes and line offsets of reads [rfirst, rfirst + cnt) (their span is b); not ok = the span does not fit the stage
+    auto issue = [&](uint64_t rfirst, uint32_t cnt, Bounds b) {
         Regs x;
         x.ok = false; x.m0 = 0; x.g0 = b.g0; x.skew = 0; x.nvec = 0; x.Rt = 0;
 #pragma unroll
         for (int u = 0; u < NV; ++u) x.v[u] = make_uint4(0, 0, 0, 0);
-        if (tt >= ntiles) return x;
-        x.Rt = (uint32_t)((n - tt * R) < R ? (n - tt * R) : R);
+        if (cnt == 0) return x;
+        x.Rt = cnt;
         const uint64_t a0 = ((uint64_t)(uintptr_t)buf + b.g0) & ~uint64_t(15);   // absolute, 16-aligned
         x.skew = (uint32_t)(((uint64_t)(uintptr_t)buf + b.g0) - a0);
         const uint64_t span = b.g1 - b.g0 + x.skew;
         x.nvec = (uint32_t)((span + 15) >> 4);
         x.ok = span + 32 <= g.stage_bytes && x.nvec <= (uint32_t)(NV * PK_THREADS);
-        if (!x.ok) return x;                          // a record longer than the caller's max_record_bytes
+        if (!x.ok) return x;                          // tiles are sized from the AVERAGE record: a long-winded one is split below
         const uint4* src = (const uint4*)(uintptr_t)a0;
 #pragma unroll
         for (int u = 0; u < NV; ++u) { const uint32_t i = u * PK_THREADS + tid; if (i < x.nvec) x.v[u] = src[i]; }
-        if (tid <= 4 * x.Rt) x.m0 = ls[4 * (first + tt * R) + tid];
+        if (tid <= 4 * x.Rt) x.m0 = ls[4 * (first + rfirst) + tid];
         return x;
     };
 
     uint32_t rr, pp;                                  // this lane packs groups pp, pp + P, ... of read rr of every tile
     fast_divmod(tid, g.P, g.magicP, rr, pp);
-    uint64_t t = blockIdx.x;
-    Bounds b_next = load_bounds(t + S);
-    Regs cur = issue(t, load_bounds(t));
     uint32_t badr = 0xFFFFFFFFu;
     uint64_t bad_tile = UQ_NONE;
-    for (; t < ntiles; t += S) {
-        const uint64_t r0 = t * R;
+    // one tile: registers -> LDS (A), `between()` (the caller's prefetch of the next tile), pack (B), store (C)
+    auto do_tile = [&](const uint64_t r0, const Regs& cur, auto&& between) {
         const uint32_t Rt = cur.Rt;
         uint8_t* out_q = out_d + ((Rt * g.Cd + 15) & ~15u);
-        const Bounds b_nn = load_bounds(t + 2 * S);
         // ---- A: registers -> LDS
         if (cur.ok) {
             if (tid <= 4 * Rt) meta[tid] = (uint32_t)(cur.m0 - cur.g0) + cur.skew;
@@ -175,8 +174,7 @@ __global__ __launch_bounds__(PK_THREADS, 5) void pack_tile_kernel(const uint8_t*
         }
         __syncthreads();
         const bool ok = cur.ok;
-        cur = issue(t + S, b_next);
-        b_next = b_nn;
+        between();
         if (ok) {
             // ---- B: P lanes per read; a lane owns groups of 8 consecutive symbols, both streams:
             //         characters -> codes -> bits (8 symbols of b bits = b whole bytes)
@@ -288,6 +286,31 @@ __global__ __launch_bounds__(PK_THREADS, 5) void pack_tile_kernel(const uint8_t*
             // ---- C: coalesced stores of the two packed tiles (widest vector the tile's byte offset allows)
             store_tile(dna + r0 * g.Cd, out_d, Rt * g.Cd, tid);
             store_tile(qual + r0 * g.Cq, out_q, Rt * g.Cq, tid);
+        }
+    };
+
+    uint64_t t = blockIdx.x;
+    Bounds b_next = load_bounds(t + S);
+    Regs cur = issue(t * R, tile_reads(t), load_bounds(t));
+    for (; t < ntiles; t += S) {
+        const Bounds b_nn = load_bounds(t + 2 * S);
+        if (cur.ok) {
+            const Regs now = cur;
+            do_tile(t * R, now, [&] { cur = issue((t + S) * R, tile_reads(t + S), b_next); b_next = b_nn; });
+        } else {
+            // the tile's records add up to more than the stage holds (R comes from the average record length): pack it in
+            // pieces of g.Rs reads, which always fit, one after the other; then pick the pipeline up again
+            const uint32_t Rt = cur.Rt;
+            for (uint32_t sub = 0; sub < Rt; sub += g.Rs) {
+                const uint32_t cnt = Rt - sub < g.Rs ? Rt - sub : g.Rs;
+                const uint64_t rf = t * R + sub;
+                Bounds sb;
+                sb.g0 = ls[4 * (first + rf)]; sb.g1 = ls[4 * (first + rf) + 4 * cnt];
+                const Regs piece = issue(rf, cnt, sb);
+                do_tile(rf, piece, [] {});
+                __syncthreads();                      // the next piece overwrites the stage and the out tile
+            }
+            cur = issue((t + S) * R, tile_reads(t + S), b_next); b_next = b_nn;
         }
     }
     if (badr != 0xFFFFFFFFu) atomicMin(bad, (unsigned long long)badr);
@@ -426,8 +449,19 @@ static int pack_impl(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_s
     g.magicG = magic_u32(g.G);
     g.fill_d = 0x01010101u * (uint32_t)fill_d;
     g.fill_q = 0x01010101u * (uint32_t)fill_q;
-    uint32_t R = (stage_cap - 64) / rec;
-    if (R > (PK_THREADS - 1) / 4) R = (PK_THREADS - 1) / 4;     // 4R + 1 line offsets, one per lane
+    // Reads per tile.  Rs (from the LONGEST record) always fits the stage; R comes from the AVERAGE record (+15 %) when the
+    // caller knows it -- variable-length files fill the stage instead of leaving room for 48 longest reads -- and a tile
+    // whose records add up to more than the stage is packed in pieces of Rs reads.
+    uint32_t Rs = (stage_cap - 64) / rec;
+    if (Rs > (PK_THREADS - 1) / 4) Rs = (PK_THREADS - 1) / 4;   // 4R + 1 line offsets, one per lane
+    if (Rs == 0) Rs = 1;
+    uint32_t R = Rs;
+    const uint32_t avg = (uint32_t)hp->avg_record_bytes;        // 0 = unknown
+    if (avg >= 4 && avg < rec) {
+        R = (stage_cap - 64) / (avg + avg * 15 / 100 + 1);
+        if (R > (PK_THREADS - 1) / 4) R = (PK_THREADS - 1) / 4;
+        if (R < Rs) R = Rs;
+    }
     // R a multiple of 16 keeps every tile's output offset 16-byte aligned (uint4 stores); when that would waste
     // more than ~15 % of the tile, settle for a multiple of 8 or 4 (8- / 4-byte stores)
     if (R >= 4) {
@@ -435,7 +469,8 @@ static int pack_impl(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_s
         if (r16 * 100 >= R * 85) R = r16; else if (r8 * 100 >= R * 85) R = r8; else R = r4;
     }
     if (R == 0) R = 1;
-    g.R = R;
+    if (Rs > R) Rs = R;
+    g.R = R; g.Rs = Rs;
     g.stage_bytes = stage_cap + 32;
     g.out_bytes = (((R * Cd + 15) & ~15u) + R * Cq + 15) & ~15u;
     // phase B: P lanes per read

@@ -95,7 +95,7 @@ def first_occurrence(ctx, buf, line_start, first_read, nreads, index_base=0):
 
 # ------------------------------------------------------------------ pack
 def make_pack_params(bases, qualities, N_qual, bits_per_base, bits_per_quality, variable,
-                     dna_bytes_per_row, quality_bytes_per_row, dna_max, max_record_bytes):
+                     dna_bytes_per_row, quality_bytes_per_row, dna_max, max_record_bytes, avg_record_bytes=0):
     p = PackParams()
     dna_code = np.full(256, -1, dtype=np.int16); qual_code = np.full(256, -1, dtype=np.int16); n_qual = np.full(256, -1, dtype=np.int32)
     dna_code[np.frombuffer(bases.encode('latin-1'), dtype=np.uint8)] = np.arange(len(bases), dtype=np.int16)
@@ -106,7 +106,7 @@ def make_pack_params(bases, qualities, N_qual, bits_per_base, bits_per_quality, 
     p.bits_per_base = bits_per_base; p.bits_per_quality = bits_per_quality
     p.variable = 1 if variable else 0
     p.dna_bytes_per_row = dna_bytes_per_row; p.quality_bytes_per_row = quality_bytes_per_row
-    p.max_record_bytes = max_record_bytes; p.dna_max = dna_max
+    p.max_record_bytes = max_record_bytes; p.dna_max = dna_max; p.avg_record_bytes = int(avg_record_bytes)
     return p
 
 

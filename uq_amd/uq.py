@@ -259,7 +259,8 @@ class Session:
     def _encode(self, variable):
         ops, ctx, d = self.ops, self.ctx, self.d
         p = ops.make_pack_params(d['bases'], d['qualities'], d['N_qual'], d['bits_per_base'], d['bits_per_quality'],
-                                 variable, d['dna_bytes_per_row'], d['quality_bytes_per_row'], d['dna_max'], self.hs.max_record_bytes)
+                                 variable, d['dna_bytes_per_row'], d['quality_bytes_per_row'], d['dna_max'], self.hs.max_record_bytes,
+                                 avg_record_bytes=self.d_buf.numel() // max(self.total, 1))
         spec = getattr(self, '_spec', None)
         self._spec = None
         self.pack_path = 'one-pass' if (spec is not None and ops.same_pack_params(p, spec[0])) else 'two-pass'
