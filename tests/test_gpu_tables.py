@@ -12,6 +12,40 @@ from uq_amd import ops
 pytestmark = pytest.mark.gpu
 
 
+def test_hostio_staging_chunk_boundaries(ctx, tmp_path):
+    """uq_amd.hostio with tiny chunks: every path crosses many chunk / buffer-reuse boundaries."""
+    import io
+    import os
+    from uq_amd.hostio import Staging
+    rng = np.random.default_rng(3)
+    data = rng.integers(0, 256, 1_000_003, dtype=np.uint8)
+    path = tmp_path / 'blob.bin'
+    data.tofile(path)
+    for chunk, nbuf in ((1 << 16, 3), (4096, 2), (1 << 20, 4), (777 * 16, 5)):
+        io_ = Staging(ctx, chunk=chunk, nbuf=nbuf)
+        for off, size in ((0, None), (1, 999_999), (65_535, 65_538), (1_000_002, 1), (5, 0)):
+            d = io_.file_to_device(str(path), off, size)
+            want = data[off:] if size is None else data[off:off + size]
+            assert np.array_equal(ctx.to_numpy(d), want)
+        d = ctx.to_device(data)
+        out = tmp_path / ('out_%d.bin' % chunk)
+        with open(out, 'wb') as f:
+            f.write(b'head')
+            assert io_.device_to_stream(d, f) == data.size          # seekable file: pwrite path, then the position moves on
+            f.write(b'tail')
+        assert out.read_bytes() == b'head' + data.tobytes() + b'tail'
+        buf = io.BytesIO()
+        assert io_.device_to_stream(d[7:123_456], buf) == 123_449  # no descriptor: sequential path
+        assert buf.getvalue() == data[7:123_456].tobytes()
+        assert np.array_equal(io_.to_numpy(d[3:]), data[3:])
+        fd = os.open(str(out), os.O_WRONLY)
+        try:
+            assert io_.device_to_fd(d[:100_000], fd, 10) == 100_000
+        finally:
+            os.close(fd)
+        assert out.read_bytes()[10:100_010] == data[:100_000].tobytes()
+
+
 def _dev(ctx, a):
     return ctx.to_device(np.ascontiguousarray(a))
 
