@@ -43,6 +43,26 @@ __global__ void heads_first_kernel(const uint64_t* __restrict__ keys, uint64_t n
     heads[j] = (j == 0 || keys[j] != keys[j - 1]) ? 1 : 0;
 }
 
+// Do the rows that still tie with their predecessor (heads[j] == 0: equal through byte `from` - 1) differ anywhere in
+// bytes [from, C)?  Ties in real tables are overwhelmingly whole-row duplicates: when no pair differs the order is
+// final (stable = file order inside a group) and the remaining rounds are skipped.
+__global__ void tail_differs_kernel(const uint8_t* __restrict__ table, uint32_t C, uint32_t from, const uint32_t* __restrict__ perm,
+                                    const uint8_t* __restrict__ heads, uint64_t n, uint32_t* __restrict__ flag) {
+    uint64_t j = (uint64_t)blockIdx.x * ST + threadIdx.x;
+    if (j == 0 || j >= n || heads[j]) return;
+    const uint8_t* a = table + (uint64_t)perm[j] * C;
+    const uint8_t* b = table + (uint64_t)perm[j - 1] * C;
+    bool diff = false;
+    uint32_t i = from;
+    for (; i + 8 <= C; i += 8) {
+        uint64_t x, y;
+        __builtin_memcpy(&x, a + i, 8); __builtin_memcpy(&y, b + i, 8);
+        diff |= x != y;
+    }
+    for (; i < C; ++i) diff |= a[i] != b[i];
+    if (diff) *flag = 1u;
+}
+
 // a[j] = row j (in sorted position) belongs to a tie segment of size >= 2; h[j] = a[j] && heads[j]
 __global__ void active_flags_kernel(const uint8_t* __restrict__ heads, uint64_t n, uint32_t* __restrict__ a, uint32_t* __restrict__ h) {
     uint64_t j = (uint64_t)blockIdx.x * ST + threadIdx.x;
@@ -149,6 +169,13 @@ int sort_rows_core(uq_ctx* ctx, const uint8_t* table, uint64_t n, uint32_t C, ui
     // ---- refinement rounds
     const uint32_t nchunks = (C + 7) / 8;
     for (uint32_t k = 1; k < nchunks; ++k) {
+        // exact duplicates need no further rounds: stop as soon as no tying pair differs in what is left of the rows
+        UQ_CHECK_HIP(hipMemsetAsync(tot + 2, 0, 8, s));
+        tail_differs_kernel<<<blocks_for(n), ST, 0, s>>>(table, C, 8 * k, d_perm, heads, n, (uint32_t*)(tot + 2));
+        UQ_LAUNCH_CHECK();
+        UQ_CHECK_HIP(hipMemcpyAsync(ctx->h_pinned + 2, tot + 2, 8, hipMemcpyDeviceToHost, s));
+        UQ_CHECK_HIP(hipStreamSynchronize(s));
+        if (ctx->h_pinned[2] == 0) break;
         active_flags_kernel<<<blocks_for(n), ST, 0, s>>>(heads, n, fa, fh);
         UQ_LAUNCH_CHECK();
         UQ_TRY(uq_scan_exclusive_u32(ctx, fa, apos, n, tot));
