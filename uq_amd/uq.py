@@ -561,7 +561,7 @@ class Session:
         k = int(pattern[0])
         rows, cols = (shape if k % 2 == 0 else shape[::-1])
         # numpy flags 1-wide arrays as C order whatever the pattern asked for: the byte stream is the same
-        t = self.ops.unpattern(self.ctx, d_pay, rows, cols, pattern)
+        t = d_pay if pattern == '0.1' else self.ops.unpattern(self.ctx, d_pay, rows, cols, pattern)   # 0.1 is the table itself
         return (t, rows, cols)
 
     def split_bits(self, dna, qual, config):
