@@ -45,8 +45,7 @@ __device__ __forceinline__ uint32_t ndigits_u64(uint64_t v) {
     return n;
 }
 // text length of field c of read r; for integers also returns the magnitude and sign
-__device__ __forceinline__ uint32_t field_len(const EmitGeom& g, uint32_t c, uint64_t r, uint64_t& mag, bool& neg, uint32_t& moff) {
-    const uint64_t raw = load_col(g.col[c], g.itemsize[c], r);
+__device__ __forceinline__ uint32_t field_from_raw(const EmitGeom& g, uint32_t c, uint64_t raw, uint64_t& mag, bool& neg, uint32_t& moff) {
     if (g.map_chars[c]) {
         moff = g.map_offs[c][raw];
         mag = 0; neg = false;
@@ -58,6 +57,9 @@ __device__ __forceinline__ uint32_t field_len(const EmitGeom& g, uint32_t c, uin
     if (g.itemsize[c] == 8 && g.add[c] == 0) { mag = raw; neg = false; }
     moff = 0;
     return ndigits_u64(mag) + (neg ? 1u : 0u);
+}
+__device__ __forceinline__ uint32_t field_len(const EmitGeom& g, uint32_t c, uint64_t r, uint64_t& mag, bool& neg, uint32_t& moff) {
+    return field_from_raw(g, c, load_col(g.col[c], g.itemsize[c], r), mag, neg, moff);
 }
 
 __global__ void emit_sizes_kernel(EmitGeom g, const uint32_t* __restrict__ len, uint64_t n, uint64_t* __restrict__ sizes) {
@@ -129,25 +131,57 @@ __global__ __launch_bounds__(EM_THREADS) void emit_tile_kernel(EmitGeom g, const
     __shared__ uint32_t rec_off[EM_RMAX + 1];            // record start inside `tile`
     __shared__ uint32_t qend[EM_RMAX];                   // end of the QNAME text (position of its '\n') relative to the record
     __shared__ uint16_t flen[EM_RMAX * EM_MAXCOLS];
+    __shared__ unsigned long long s_off[EM_RMAX + 1];   // record offsets of the tile, as fetched
+    __shared__ uint32_t s_len[EM_RMAX];
     const uint32_t tid = threadIdx.x, lane = lane_id();
     const uint64_t ntiles = (n + R - 1) / R;
     const uint32_t ncols = g.ncols;
+    // Per-record metadata of the NEXT tile (offset, length, this lane's column value) is requested one tile ahead and
+    // waits in registers: without it every tile paid three dependent global-memory latencies before the first byte.
+    const bool one_item = R * ncols <= EM_THREADS;       // lane == (record, field) item; else the fields reload their values
+    struct Pre { unsigned long long off; uint64_t raw; uint32_t L; };
+    auto fetch = [&](uint64_t tt) {
+        Pre x; x.off = 0; x.raw = 0; x.L = 0;
+        if (tt >= ntiles) return x;
+        const uint64_t r0 = tt * R;
+        const uint32_t Rt = (uint32_t)((n - r0) < R ? (n - r0) : R);
+        if (tid <= Rt) x.off = offsets[r0 + tid];
+        if (tid < Rt) x.L = len[r0 + tid];
+        if (one_item && tid < Rt * ncols) { const uint32_t i = tid / ncols, c = tid - i * ncols; x.raw = load_col(g.col[c], g.itemsize[c], r0 + i); }
+        return x;
+    };
+    Pre nx = fetch(blockIdx.x);
     for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const uint64_t r0 = t * R;
         const uint32_t Rt = (uint32_t)((n - r0) < R ? (n - r0) : R);
-        const uint64_t o0 = offsets[r0], o1 = offsets[r0 + Rt];
+        const Pre cur = nx;
+        if (tid <= Rt) s_off[tid] = cur.off;
+        if (tid < Rt) s_len[tid] = cur.L;
+        __syncthreads();
+        nx = fetch(t + gridDim.x);
+        const uint64_t o0 = s_off[0], o1 = s_off[Rt];
         const uint32_t skew = (uint32_t)((uintptr_t)(out + o0) & 15);
         const uint64_t span = o1 - o0;
         if (span + skew > EM_CAP) {                      // does not fit: wave per record, straight to HBM
             for (uint32_t i = tid >> 6; i < Rt; i += EM_THREADS / 64) emit_record_direct(g, seq, qual, len, offsets, out, r0 + i, lane);
+            __syncthreads();
             continue;
         }
-        if (tid <= Rt) rec_off[tid] = (uint32_t)(offsets[r0 + tid] - o0) + skew;
+        if (tid <= Rt) rec_off[tid] = (uint32_t)(cur.off - o0) + skew;
         // ---- 1a: field lengths
-        for (uint32_t idx = tid; idx < Rt * ncols; idx += EM_THREADS) {
-            const uint32_t i = idx / ncols, c = idx - i * ncols;
-            uint64_t mag; bool neg; uint32_t moff;
-            flen[i * EM_MAXCOLS + c] = (uint16_t)field_len(g, c, r0 + i, mag, neg, moff);
+        uint64_t my_mag = 0; bool my_neg = false; uint32_t my_moff = 0, my_fl = 0;
+        if (one_item) {
+            if (tid < Rt * ncols) {
+                const uint32_t i = tid / ncols, c = tid - i * ncols;
+                my_fl = field_from_raw(g, c, cur.raw, my_mag, my_neg, my_moff);
+                flen[i * EM_MAXCOLS + c] = (uint16_t)my_fl;
+            }
+        } else {
+            for (uint32_t idx = tid; idx < Rt * ncols; idx += EM_THREADS) {
+                const uint32_t i = idx / ncols, c = idx - i * ncols;
+                uint64_t mag; bool neg; uint32_t moff;
+                flen[i * EM_MAXCOLS + c] = (uint16_t)field_len(g, c, r0 + i, mag, neg, moff);
+            }
         }
         __syncthreads();
         // ---- 1b: render the fields, the separators and (lane of the last field) the suffix + '\n'
@@ -156,8 +190,8 @@ __global__ __launch_bounds__(EM_THREADS) void emit_tile_kernel(EmitGeom g, const
             uint32_t pos = g.prefix_len;
             for (uint32_t k = 0; k < c; ++k) pos += flen[i * EM_MAXCOLS + k] + 1u;
             uint8_t* o = tile + rec_off[i] + pos;
-            uint64_t mag; bool neg; uint32_t moff;
-            const uint32_t fl = field_len(g, c, r0 + i, mag, neg, moff);
+            uint64_t mag = my_mag; bool neg = my_neg; uint32_t moff = my_moff;
+            const uint32_t fl = one_item ? my_fl : field_len(g, c, r0 + i, mag, neg, moff);
             if (g.map_chars[c]) {
                 for (uint32_t k = 0; k < fl; ++k) o[k] = g.map_chars[c][moff + k];
             } else {
@@ -191,7 +225,7 @@ __global__ __launch_bounds__(EM_THREADS) void emit_tile_kernel(EmitGeom g, const
             const uint32_t i = tid / P, p = tid - i * P;
             if (i < Rt) {
                 const uint64_t r = r0 + i;
-                const uint32_t L = len[r];
+                const uint32_t L = s_len[i];
                 const uint32_t ds = rec_off[i] + qend[i] + 1;           // first SEQ byte in the tile
                 const uint32_t dq = ds + L + 3;                         // first QUAL byte
                 if (p == 0) { tile[ds + L] = '\n'; tile[ds + L + 1] = '+'; tile[ds + L + 2] = '\n'; tile[dq + L] = '\n'; }
