@@ -221,7 +221,11 @@ int launch(uq_ctx* ctx, const uint8_t* in, uint64_t rows, uint32_t cols, int pat
         UQ_LAUNCH_CHECK();
         return 0;
     }
-    const uint32_t budget = 60 * 1024;
+    // LDS per tile: small enough for many workgroups per CU (these kernels do not prefetch: occupancy hides the latency).
+    // Measured on a 10 M x 113 B table: 60 KiB tiles 1.15 / 0.75 ms (column-major / row-major), 32 KiB 0.71 / 0.51, 16 KiB 0.83 / 0.47.
+    // Wide rows keep the larger budget so that a tile still holds a few rows.
+    uint32_t budget = (colmajor ? 32u : 16u) * 1024u;
+    if (budget / cols < 8) budget = 60 * 1024;
     size_t lds;
     if (!colmajor) {
         uint32_t TR = budget / cols;
