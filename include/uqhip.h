@@ -268,6 +268,18 @@ int uq_emit_fastq(uq_ctx* ctx, const uq_emit_params* h_params, const void* const
                   const uint32_t* const* h_d_map_offs, const uint8_t* d_seq, const uint8_t* d_qual, const uint32_t* d_len,
                   uint64_t nreads, uint64_t* d_offsets, uint8_t* d_out, uint64_t capacity, uint64_t* h_total);
 
+/* ---- a12 + f3 in one pass: packed DNA / QUAL rows (+ QNAME columns) -> FASTQ text.  The decoder's split_bits,
+ * character maps, N restore, sentinel strip (uq.py:1002-1007, 1031-1054), convert_qname (1010-1026) and prints
+ * (1042-1045) without the 2 x dna_max bytes per read of intermediate text uq_unpack + uq_emit_fastq pass through HBM.
+ * Same bytes as those two calls.  Protocol: call once with d_out == NULL -- read lengths (variable-length tables:
+ * d_len, uint32[nreads]; may be NULL for fixed-length tables), record offsets (d_offsets, uint64[nreads + 1]) and
+ * *h_total are computed, *h_bad = lowest row without a valid length sentinel (UINT64_MAX: none; also left in
+ * d_bad[0]) -- then again with the output buffer and the SAME d_len / d_offsets / d_bad, which are only read. */
+int uq_decode_fastq(uq_ctx* ctx, const uq_emit_params* h_emit, const uq_unpack_params* h_unpack, const void* const* h_d_cols,
+                    const uint8_t* const* h_d_map_chars, const uint32_t* const* h_d_map_offs, const uint8_t* d_dna,
+                    const uint8_t* d_qual, uint64_t nreads, uint32_t* d_len, uint64_t* d_offsets, uint64_t* d_bad,
+                    uint8_t* d_out, uint64_t capacity, uint64_t* h_total, uint64_t* h_bad);
+
 /* ---- synthetic FASTQ ("synth-v1"): workload generation for tests and bench.py.
  * Byte-identical to uq_amd/synth.py.  uq_synth_size: total bytes of reads [first, first+n).
  * uq_synth_fastq: writes them to d_out (capacity >= that size). */

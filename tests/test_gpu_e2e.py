@@ -33,11 +33,16 @@ def _run_encode(ctx, tmp_path, fastq_bytes, flags):
 
 
 def _run_decode(ctx, path):
-    args = uq.build_parser().parse_args(['-i', path, '--decode', '--quiet'])
-    uq.validate_args(args)
-    buf = io.BytesIO()
-    uq.Session(args, ctx=ctx).decode(out=buf)
-    return buf.getvalue()
+    # both decoders, every time: rows -> text in one kernel (the default) and uq_unpack + uq_emit_fastq
+    texts = []
+    for extra in ([], ['--two-pass-decode']):
+        args = uq.build_parser().parse_args(['-i', path, '--decode', '--quiet'] + extra)
+        uq.validate_args(args)
+        buf = io.BytesIO()
+        uq.Session(args, ctx=ctx).decode(out=buf)
+        texts.append(buf.getvalue())
+    assert texts[0] == texts[1]
+    return texts[0]
 
 
 def _records(fq):

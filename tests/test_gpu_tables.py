@@ -226,3 +226,46 @@ def test_unpack_roundtrip(ctx, name, n, length, kw, dk):
     for r in range(0, n, max(1, n // 97)):
         assert S[r, :L[r]].tobytes() == lines[4 * r + 1]
         assert Q[r, :L[r]].tobytes() == lines[4 * r + 3]
+
+
+DECODE_CASES = UNPACK_CASES + [('long_rows', 40, (2000, 9000), dict(n_rate=1), {}), ('ragged', 1031, (30, 60), {}, {}),
+                               ('one_tile_budget', 300, 508, dict(n_rate=3), dict(notricks=True))]
+
+
+@pytest.mark.parametrize('name,n,length,kw,dk', DECODE_CASES, ids=[c[0] for c in DECODE_CASES])
+def test_decode_fastq_is_the_input_and_the_two_pass_text(ctx, name, n, length, kw, dk):
+    """uq_decode_fastq (rows -> text in one kernel) against uq_unpack + uq_emit_fastq and against the FASTQ the rows
+    were packed from (oracle pack, host QNAME analysis)."""
+    from uq_amd import qname, synth
+    if name == 'long_rows':
+        rng = np.random.default_rng(5)
+        recs = []
+        for i in range(n):
+            L = int(rng.integers(length[0], length[1]))
+            recs.append(b'@r:%d:%d\n' % (1000 - i, i % 3) + bytes(rng.choice(list(b'ACGTN'), L, p=[.24, .25, .25, .25, .01]).astype(np.uint8)) + b'\n+\n' +
+                        bytes(rng.integers(35, 75, L).astype(np.uint8)) + b'\n')
+        host = np.frombuffer(b''.join(recs), dtype=np.uint8)
+    else:
+        host = synth.fastq_array(synth.Spec(20261011, length, **kw), n)
+    hls = oracle_c.index_lines(host)
+    st = oracle_c.stats(host, hls, 0, n)
+    d = O.decide(O.histogram_to_static_qualities(st['counts'], st['first_seen']), st['len_min'], st['len_max'], **dk)
+    rd, rq, _ = oracle_c.pack(host, hls, 0, n, d['bases'], d['qualities'], d['N_qual'], d['bits_per_base'], d['bits_per_quality'],
+                              d['variable_read_lengths'], d['dna_bytes_per_row'], d['quality_bytes_per_row'])
+    prefix, suffix, separators, columns, arrays = qname.analyse(qname.qname_lines(host, hls, n))
+    cfg = dict(bases=d['bases'], qualities=d['qualities'], N_qual=d['N_qual'], bits_per_base=d['bits_per_base'],
+               bits_per_quality=d['bits_per_quality'], variable_read_lengths=d['variable_read_lengths'], dna_max=d['dna_max'],
+               QNAME_prefix=prefix, QNAME_suffix=suffix, QNAME_separators=separators, QNAME_columns=columns)
+    cols = [_dev(ctx, np.ascontiguousarray(a)) for a in arrays]
+    dna, qual = _dev(ctx, rd.ravel()), _dev(ctx, rq.ravel())
+    text, bad = ops.decode_fastq(ctx, cfg, cols, dna, qual, n)
+    assert bad is None
+    assert ctx.to_numpy(text).tobytes() == host.tobytes()
+    seq, qt, ln, ubad = ops.unpack(ctx, dna, qual, n, ops.make_unpack_params(cfg))
+    two = ops.emit_fastq(ctx, cfg, cols, seq, qt, ln, n)
+    assert ctx.to_numpy(two).tobytes() == host.tobytes()
+    if d['variable_read_lengths'] and n > 10:
+        # a row without its sentinel: both paths name it
+        rd2 = rd.copy(); rd2[7, :] = 0
+        text, bad = ops.decode_fastq(ctx, cfg, cols, _dev(ctx, rd2.ravel()), qual, n)
+        assert text is None and bad == 7

@@ -10,6 +10,9 @@
 //           version wrote each record from one wave straight to HBM and is kept for oversize tiles)
 // Algorithmic HBM bytes per read: 2 L + column bytes read, record bytes written.
 #include "common.h"
+#include "swar.h"
+#include "codes.h"
+#include <type_traits>
 
 namespace {
 constexpr int EM_MAXCOLS = 32;
@@ -65,7 +68,7 @@ __device__ __forceinline__ uint32_t field_len(const EmitGeom& g, uint32_t c, uin
 __global__ void emit_sizes_kernel(EmitGeom g, const uint32_t* __restrict__ len, uint64_t n, uint64_t* __restrict__ sizes) {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
-    uint64_t s = g.prefix_len + g.suffix_len + (g.ncols ? g.ncols - 1 : 0) + 2ull * len[r] + 5;   // 4 '\n' and the '+'
+    uint64_t s = g.prefix_len + g.suffix_len + (g.ncols ? g.ncols - 1 : 0) + 2ull * (len ? len[r] : g.dna_max) + 5;   // 4 '\n' and the '+'
     for (uint32_t c = 0; c < g.ncols; ++c) {
         uint64_t mag; bool neg; uint32_t moff;
         s += field_len(g, c, r, mag, neg, moff);
@@ -74,38 +77,40 @@ __global__ void emit_sizes_kernel(EmitGeom g, const uint32_t* __restrict__ len, 
 }
 
 // One wave writes one record straight to HBM: the fallback for tiles that do not fit the LDS buffer of
-// emit_tile_kernel (very long reads).
+// emit_tile_kernel (very long reads).  emit_qname_direct writes the QNAME line and returns its length.
+__device__ uint32_t emit_qname_direct(const EmitGeom& g, uint8_t* __restrict__ o, uint64_t r, uint32_t lane) {
+    // lane 0 renders the integer fields (they are short), lanes copy prefix / suffix / mapping strings
+    uint32_t pos = g.prefix_len;
+    for (uint32_t i = lane; i < g.prefix_len; i += 64) o[i] = g.prefix[i];
+    for (uint32_t c = 0; c < g.ncols; ++c) {
+        uint64_t mag; bool neg; uint32_t moff;
+        const uint32_t fl = field_len(g, c, r, mag, neg, moff);     // wave-uniform (same r)
+        if (g.map_chars[c]) {
+            for (uint32_t i = lane; i < fl; i += 64) o[pos + i] = g.map_chars[c][moff + i];
+        } else if (lane == 0) {
+            uint32_t k = pos + fl;
+            do { o[--k] = (uint8_t)('0' + mag % 10); mag /= 10; } while (mag);
+            if (neg) o[--k] = '-';
+        }
+        pos += fl;
+        if (c + 1 < g.ncols) { if (lane == 0) o[pos] = g.seps[c]; ++pos; }
+    }
+    for (uint32_t i = lane; i < g.suffix_len; i += 64) o[pos + i] = g.suffix[i];
+    pos += g.suffix_len;
+    if (lane == 0) o[pos] = '\n';
+    return pos + 1;
+}
+
 __device__ void emit_record_direct(const EmitGeom& g, const uint8_t* __restrict__ seq, const uint8_t* __restrict__ qual,
                                    const uint32_t* __restrict__ len, const uint64_t* __restrict__ offsets, uint8_t* __restrict__ out,
                                    uint64_t r, uint32_t lane) {
-    {
-        uint8_t* o = out + offsets[r];
-        const uint32_t L = len[r];
-        // QNAME line: lane 0..ncols-1 render one field each (fields are short), lanes copy prefix / suffix
-        uint32_t pos = g.prefix_len;
-        for (uint32_t i = lane; i < g.prefix_len; i += 64) o[i] = g.prefix[i];
-        for (uint32_t c = 0; c < g.ncols; ++c) {
-            uint64_t mag; bool neg; uint32_t moff;
-            const uint32_t fl = field_len(g, c, r, mag, neg, moff);     // wave-uniform (same r)
-            if (g.map_chars[c]) {
-                for (uint32_t i = lane; i < fl; i += 64) o[pos + i] = g.map_chars[c][moff + i];
-            } else if (lane == 0) {
-                uint32_t k = pos + fl;
-                do { o[--k] = (uint8_t)('0' + mag % 10); mag /= 10; } while (mag);
-                if (neg) o[--k] = '-';
-            }
-            pos += fl;
-            if (c + 1 < g.ncols) { if (lane == 0) o[pos] = g.seps[c]; ++pos; }
-        }
-        for (uint32_t i = lane; i < g.suffix_len; i += 64) o[pos + i] = g.suffix[i];
-        pos += g.suffix_len;
-        if (lane == 0) o[pos] = '\n';
-        ++pos;
-        const uint8_t* s = seq + r * g.dna_max;
-        const uint8_t* q = qual + r * g.dna_max;
-        for (uint32_t i = lane; i < L; i += 64) { o[pos + i] = s[i]; o[pos + L + 3 + i] = q[i]; }
-        if (lane == 0) { o[pos + L] = '\n'; o[pos + L + 1] = '+'; o[pos + L + 2] = '\n'; o[pos + 2 * L + 3] = '\n'; }
-    }
+    uint8_t* o = out + offsets[r];
+    const uint32_t L = len[r];
+    const uint32_t pos = emit_qname_direct(g, o, r, lane);
+    const uint8_t* s = seq + r * g.dna_max;
+    const uint8_t* q = qual + r * g.dna_max;
+    for (uint32_t i = lane; i < L; i += 64) { o[pos + i] = s[i]; o[pos + L + 3 + i] = q[i]; }
+    if (lane == 0) { o[pos + L] = '\n'; o[pos + L + 1] = '+'; o[pos + L + 2] = '\n'; o[pos + 2 * L + 3] = '\n'; }
 }
 
 // ---- the tile kernel: a workgroup assembles the text of R consecutive records in LDS (their bytes are one
@@ -113,31 +118,110 @@ __device__ void emit_record_direct(const EmitGeom& g, const uint8_t* __restrict_
 //   1  one lane per (record, QNAME field): text length of the field -> LDS; after a barrier the lane sums the
 //      lengths before its field and renders it in place (decimal digits, or a copy from the string table);
 //      prefix / suffix / separators / newlines by the same lanes
-//   2  P lanes per record copy SEQ and QUAL: a lane owns destination-aligned dwords of the record's text and
-//      fetches the matching 4 source bytes with one (unaligned) global load -- the fixed-pitch source rows and
-//      the variable text offsets never share an alignment
+//   2  SEQ and QUAL text.  Two sources:
+//      text form   (uq_emit_fastq)    P lanes per record copy from the fixed-pitch character arrays uq_unpack left: a
+//                  lane owns destination-aligned dwords and fetches the matching 4 source bytes with one unaligned load
+//      packed form (uq_decode_fastq)  the records' packed DNA / QUAL rows -- prefetched into registers one tile ahead,
+//                  like the metadata -- are decoded straight into the image, a lane per 8 symbols (the arithmetic of
+//                  unpack_pipe_kernel).  The 2 x dna_max bytes per read of intermediate text never exist.
 //   3  the LDS image is stored to HBM: it mirrors the destination's 16-byte phase, so all interior stores are
 //      aligned uint4
 constexpr int EM_THREADS = 256;
-constexpr uint32_t EM_CAP = 24 * 1024;
 constexpr uint32_t EM_RMAX = 64;
+constexpr int DE_NV = 2;                 // 16-byte vectors per lane and table of packed rows in flight (<= 8 KiB per table and tile)
+constexpr uint32_t EM_BUDGET_TEXT = 19 * 1024, EM_BUDGET_PACKED = 36 * 1024;   // dynamic LDS per workgroup (the registers allow four workgroups per CU)
+
+struct TileGeom {
+    uint32_t R, P, cap;                                          // records per tile, lanes per record (text form), bytes of the text image
+    uint32_t o_off, o_len, o_flen, o_ind, o_inq;                 // LDS byte offsets behind the image
+    uint32_t magicP;                                             // magic_u32(prefix_len)
+    uint32_t bd, bq, Cd, Cq, G, magicG;                          // packed form: row geometry, G = 8-symbol groups per read
+    FastAlphabet fa;
+};
+struct NoLut {};
 
 __device__ __forceinline__ uint32_t load_u32_any(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 
-__global__ __launch_bounds__(EM_THREADS) void emit_tile_kernel(EmitGeom g, const uint8_t* __restrict__ seq, const uint8_t* __restrict__ qual,
+// ---- packed form, fast alphabet: eight symbols per lane without per-symbol work
+// byte k of the result = bits (7 - 2k .. 6 - 2k) of x: the four 2-bit base codes of one row byte, in text order
+__device__ __forceinline__ uint32_t spread2(uint32_t x) { return ((x >> 6) | (x << 4) | (x << 14) | (x << 24)) & 0x03030303u; }
+// the BQ row bytes at p hold eight BQ-bit quality codes, first character in the top bits: qlo = characters 0..3, qhi = 4..7, one per byte
+template <int BQ>
+__device__ __forceinline__ void qual8(const uint8_t* p, uint32_t& qlo, uint32_t& qhi) {
+    uint64_t V = 0;
+#pragma unroll
+    for (int i = 0; i < BQ; ++i) V = (V << 8) | p[i];
+    const uint32_t up = (uint32_t)(V >> (4 * BQ)), dn = (uint32_t)V & ((1u << (4 * BQ)) - 1u);       // 4 BQ <= 28 bits each
+    constexpr uint32_t M = (1u << BQ) - 1u;
+    qlo = ((up >> (3 * BQ)) & M) | (((up >> (2 * BQ)) & M) << 8) | (((up >> BQ) & M) << 16) | ((up & M) << 24);
+    qhi = ((dn >> (3 * BQ)) & M) | (((dn >> (2 * BQ)) & M) << 8) | (((dn >> BQ) & M) << 16) | ((dn & M) << 24);
+}
+// Eight text bytes (lo = 0..3, hi = 4..7) to the image at byte offset `at` (any alignment), as the ALIGNED dwords that
+// lie inside the run of whole groups: with at % 4 = a != 0 that is the dword the lane's bytes fill and -- when eight more
+// characters follow (has_dn; nb_lo = their first four, from the lane below) -- the dword that straddles the two groups.
+// The first 4 - a bytes of a read's top group and the last a of its bottom group are left to the per-read fix-up.
+__device__ __forceinline__ void store8(uint8_t* image, uint32_t at, uint32_t lo, uint32_t hi, uint32_t nb_lo, bool has_dn) {
+    const uint32_t a = at & 3u;
+    uint8_t* dst = image + at;
+    if (a == 0) { *(uint32_t*)dst = lo; *(uint32_t*)(dst + 4) = hi; return; }
+    const uint32_t sh = 4u - a;
+    *(uint32_t*)(dst + sh) = __builtin_amdgcn_alignbyte(hi, lo, sh);
+    if (has_dn) *(uint32_t*)(dst + sh + 4) = __builtin_amdgcn_alignbyte(nb_lo, hi, sh);
+}
+// one symbol through the tables: t = its index from the END of the read (rows are right-aligned)
+__device__ __forceinline__ void decode_symbol(const uint8_t* drow, const uint8_t* qrow, const TileGeom& tg, uint32_t t, const uint8_t* l_base,
+                                              const uint8_t* l_qual, const uint8_t* l_qn, uint8_t& cb, uint8_t& cc) {
+    const uint32_t bitd = t * tg.bd, bitq = t * tg.bq;
+    const uint32_t bd0 = tg.Cd - 1 - (bitd >> 3), bq0 = tg.Cq - 1 - (bitq >> 3);
+    const uint32_t vd = drow[bd0] | (bd0 ? (uint32_t)drow[bd0 - 1] << 8 : 0u);
+    const uint32_t vq = qrow[bq0] | (bq0 ? (uint32_t)qrow[bq0 - 1] << 8 : 0u);
+    const uint32_t cd = (vd >> (bitd & 7)) & ((1u << tg.bd) - 1), cq = (vq >> (bitq & 7)) & ((1u << tg.bq) - 1);
+    const uint8_t nb = l_qn[cq];
+    cb = nb ? nb : l_base[cd];
+    cc = l_qual[cq];
+}
+
+// packed form of emit_record_direct: symbols straight from the HBM rows (unpack_long_kernel's arithmetic)
+__device__ void decode_record_direct(const EmitGeom& g, const TileGeom& tg, const uint8_t* l_base, const uint8_t* l_qual, const uint8_t* l_qn,
+                                     const uint8_t* __restrict__ dna, const uint8_t* __restrict__ qual, uint32_t L,
+                                     const uint64_t* __restrict__ offsets, uint8_t* __restrict__ out, uint64_t r, uint32_t lane) {
+    uint8_t* o = out + offsets[r];
+    const uint32_t pos = emit_qname_direct(g, o, r, lane);
+    const uint8_t* drow = dna + r * tg.Cd;
+    const uint8_t* qrow = qual + r * tg.Cq;
+    for (uint32_t j = lane; j < L; j += 64) {
+        uint8_t cb, cc;
+        decode_symbol(drow, qrow, tg, L - 1 - j, l_base, l_qual, l_qn, cb, cc);
+        o[pos + j] = cb;
+        o[pos + L + 3 + j] = cc;
+    }
+    if (lane == 0) { o[pos + L] = '\n'; o[pos + L + 1] = '+'; o[pos + L + 2] = '\n'; o[pos + 2 * L + 3] = '\n'; }
+}
+
+template <bool PACKED>
+__global__ __launch_bounds__(EM_THREADS, 4) void emit_tile_kernel(EmitGeom g, TileGeom tg, std::conditional_t<PACKED, UnpackLut, NoLut> lut,
+                                                               const uint8_t* __restrict__ seq, const uint8_t* __restrict__ qual,
                                                                const uint32_t* __restrict__ len, uint64_t n, const uint64_t* __restrict__ offsets,
-                                                               uint8_t* __restrict__ out, uint32_t R, uint32_t P) {
-    __shared__ __align__(16) uint8_t tile[EM_CAP + 32];
-    __shared__ uint32_t rec_off[EM_RMAX + 1];            // record start inside `tile`
-    __shared__ uint32_t qend[EM_RMAX];                   // end of the QNAME text (position of its '\n') relative to the record
-    __shared__ uint16_t flen[EM_RMAX * EM_MAXCOLS];
-    __shared__ unsigned long long s_off[EM_RMAX + 1];   // record offsets of the tile, as fetched
-    __shared__ uint32_t s_len[EM_RMAX];
+                                                               uint8_t* __restrict__ out) {
+    extern __shared__ __align__(16) uint8_t tile[];                                  // [cap + 32] text image, then:
+    unsigned long long* s_off = (unsigned long long*)(tile + tg.o_off);              // [R + 1] record offsets of the tile, as fetched
+    uint32_t* s_len = (uint32_t*)(tile + tg.o_len);                                  // [R]
+    uint16_t* flen = (uint16_t*)(tile + tg.o_flen);                                  // [R][ncols]
+    __shared__ uint8_t l_tab[PACKED ? 768 : 4];
+    const uint8_t* l_base = l_tab; const uint8_t* l_qual = l_tab + 256; const uint8_t* l_qn = l_tab + 512;
+    // the QNAME layout (prefix, suffix, separators, the per-column pointers and offsets) is indexed per lane: an LDS copy
+    // answers in a tenth of the time of the kernel-argument segment
+    __shared__ EmitGeom sg;
     const uint32_t tid = threadIdx.x, lane = lane_id();
+    for (uint32_t i = tid; i < sizeof(EmitGeom) / 4; i += EM_THREADS) ((uint32_t*)&sg)[i] = ((const uint32_t*)&g)[i];
+    if constexpr (PACKED) { l_tab[tid] = lut.base_char[tid]; l_tab[256 + tid] = lut.qual_char[tid]; l_tab[512 + tid] = lut.qual_n_base[tid]; }
+    __syncthreads();
+    const uint32_t R = tg.R, P = tg.P, cap = tg.cap;
     const uint64_t ntiles = (n + R - 1) / R;
     const uint32_t ncols = g.ncols;
-    // Per-record metadata of the NEXT tile (offset, length, this lane's column value) is requested one tile ahead and
-    // waits in registers: without it every tile paid three dependent global-memory latencies before the first byte.
+    // Per-record metadata of the NEXT tile (offset, length, this lane's column value) -- and in the packed form its rows --
+    // is requested one tile ahead and waits in registers: without it every tile paid three dependent global-memory
+    // latencies before the first byte.
     const bool one_item = R * ncols <= EM_THREADS;       // lane == (record, field) item; else the fields reload their values
     struct Pre { unsigned long long off; uint64_t raw; uint32_t L; };
     auto fetch = [&](uint64_t tt) {
@@ -146,87 +230,224 @@ __global__ __launch_bounds__(EM_THREADS) void emit_tile_kernel(EmitGeom g, const
         const uint64_t r0 = tt * R;
         const uint32_t Rt = (uint32_t)((n - r0) < R ? (n - r0) : R);
         if (tid <= Rt) x.off = offsets[r0 + tid];
-        if (tid < Rt) x.L = len[r0 + tid];
-        if (one_item && tid < Rt * ncols) { const uint32_t i = tid / ncols, c = tid - i * ncols; x.raw = load_col(g.col[c], g.itemsize[c], r0 + i); }
+        if (tid < Rt) x.L = len ? len[r0 + tid] : g.dna_max;
+        if (one_item && tid < Rt * ncols) { const uint32_t i = tid / ncols, c = tid - i * ncols; x.raw = load_col(sg.col[c], sg.itemsize[c], r0 + i); }
         return x;
     };
+    struct Rows { uint4 d[DE_NV], q[DE_NV]; uint32_t skd, skq, nvd, nvq; };
+    auto fetch_rows = [&](uint64_t tt) {
+        Rows x;
+        x.skd = x.skq = x.nvd = x.nvq = 0;
+#pragma unroll
+        for (int u = 0; u < DE_NV; ++u) { x.d[u] = make_uint4(0, 0, 0, 0); x.q[u] = make_uint4(0, 0, 0, 0); }
+        if (!PACKED || cap == 0 || tt >= ntiles) return x;
+        const uint32_t Rt = (uint32_t)((n - tt * R) < R ? (n - tt * R) : R);
+        const uint64_t ad = (uint64_t)(uintptr_t)(seq + tt * R * tg.Cd), aq = (uint64_t)(uintptr_t)(qual + tt * R * tg.Cq);
+        x.skd = (uint32_t)(ad & 15); x.skq = (uint32_t)(aq & 15);
+        x.nvd = (x.skd + Rt * tg.Cd + 15) >> 4; x.nvq = (x.skq + Rt * tg.Cq + 15) >> 4;
+        const uint4* sd = (const uint4*)(uintptr_t)(ad & ~uint64_t(15));
+        const uint4* sq = (const uint4*)(uintptr_t)(aq & ~uint64_t(15));
+#pragma unroll
+        for (int u = 0; u < DE_NV; ++u) {
+            const uint32_t i = u * EM_THREADS + tid;
+            if (i < x.nvd) x.d[u] = sd[i];
+            if (i < x.nvq) x.q[u] = sq[i];
+        }
+        return x;
+    };
+    const uint32_t wj = PACKED ? lane / tg.G : 0u, wg = PACKED ? lane - wj * tg.G : 0u;   // packed form: the lane's (read slot, group) in its wave
     Pre nx = fetch(blockIdx.x);
+    Rows nr = fetch_rows(blockIdx.x);
     for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const uint64_t r0 = t * R;
         const uint32_t Rt = (uint32_t)((n - r0) < R ? (n - r0) : R);
         const Pre cur = nx;
         if (tid <= Rt) s_off[tid] = cur.off;
         if (tid < Rt) s_len[tid] = cur.L;
-        __syncthreads();
-        nx = fetch(t + gridDim.x);
-        const uint64_t o0 = s_off[0], o1 = s_off[Rt];
-        const uint32_t skew = (uint32_t)((uintptr_t)(out + o0) & 15);
-        const uint64_t span = o1 - o0;
-        if (span + skew > EM_CAP) {                      // does not fit: wave per record, straight to HBM
-            for (uint32_t i = tid >> 6; i < Rt; i += EM_THREADS / 64) emit_record_direct(g, seq, qual, len, offsets, out, r0 + i, lane);
-            __syncthreads();
-            continue;
+        uint32_t skd = 0, skq = 0;
+        if constexpr (PACKED) {
+            skd = nr.skd; skq = nr.skq;
+#pragma unroll
+            for (int u = 0; u < DE_NV; ++u) {
+                const uint32_t i = u * EM_THREADS + tid;
+                if (i < nr.nvd) ((uint4*)(tile + tg.o_ind))[i] = nr.d[u];
+                if (i < nr.nvq) ((uint4*)(tile + tg.o_inq))[i] = nr.q[u];
+            }
         }
-        if (tid <= Rt) rec_off[tid] = (uint32_t)(cur.off - o0) + skew;
-        // ---- 1a: field lengths
+        // ---- 1a: field lengths (from the prefetched column values)
         uint64_t my_mag = 0; bool my_neg = false; uint32_t my_moff = 0, my_fl = 0;
         if (one_item) {
             if (tid < Rt * ncols) {
                 const uint32_t i = tid / ncols, c = tid - i * ncols;
-                my_fl = field_from_raw(g, c, cur.raw, my_mag, my_neg, my_moff);
-                flen[i * EM_MAXCOLS + c] = (uint16_t)my_fl;
+                my_fl = field_from_raw(sg, c, cur.raw, my_mag, my_neg, my_moff);
+                flen[i * ncols + c] = (uint16_t)my_fl;
             }
         } else {
             for (uint32_t idx = tid; idx < Rt * ncols; idx += EM_THREADS) {
                 const uint32_t i = idx / ncols, c = idx - i * ncols;
                 uint64_t mag; bool neg; uint32_t moff;
-                flen[i * EM_MAXCOLS + c] = (uint16_t)field_len(g, c, r0 + i, mag, neg, moff);
+                flen[i * ncols + c] = (uint16_t)field_len(sg, c, r0 + i, mag, neg, moff);
             }
         }
         __syncthreads();
+        nx = fetch(t + gridDim.x);
+        if constexpr (PACKED) nr = fetch_rows(t + gridDim.x);
+        const uint64_t o0 = s_off[0], o1 = s_off[Rt];
+        const uint32_t skew = (uint32_t)((uintptr_t)(out + o0) & 15);
+        const uint64_t span = o1 - o0;
+        if (span + skew > cap) {                          // does not fit: wave per record, straight to HBM
+            for (uint32_t i = tid >> 6; i < Rt; i += EM_THREADS / 64) {
+                if constexpr (PACKED) decode_record_direct(g, tg, l_base, l_qual, l_qn, seq, qual, s_len[i], offsets, out, r0 + i, lane);
+                else emit_record_direct(g, seq, qual, len, offsets, out, r0 + i, lane);
+            }
+            __syncthreads();
+            continue;
+        }
+        // record i starts at image byte ro(i); its QUAL line ends right before ro(i + 1), so its SEQ text starts at
+        // ro(i + 1) - 2 L - 4 whatever the QNAME was: the three parts below need no barrier between them
+        auto ro = [&](uint32_t i) { return (uint32_t)(s_off[i] - o0) + skew; };
         // ---- 1b: render the fields, the separators and (lane of the last field) the suffix + '\n'
         for (uint32_t idx = tid; idx < Rt * ncols; idx += EM_THREADS) {
             const uint32_t i = idx / ncols, c = idx - i * ncols;
             uint32_t pos = g.prefix_len;
-            for (uint32_t k = 0; k < c; ++k) pos += flen[i * EM_MAXCOLS + k] + 1u;
-            uint8_t* o = tile + rec_off[i] + pos;
+            for (uint32_t k = 0; k < c; ++k) pos += flen[i * ncols + k] + 1u;
+            uint8_t* o = tile + ro(i) + pos;
             uint64_t mag = my_mag; bool neg = my_neg; uint32_t moff = my_moff;
-            const uint32_t fl = one_item ? my_fl : field_len(g, c, r0 + i, mag, neg, moff);
-            if (g.map_chars[c]) {
-                for (uint32_t k = 0; k < fl; ++k) o[k] = g.map_chars[c][moff + k];
+            const uint32_t fl = one_item ? my_fl : field_len(sg, c, r0 + i, mag, neg, moff);
+            if (sg.map_chars[c]) {
+                const uint8_t* mc = sg.map_chars[c];
+                for (uint32_t k = 0; k < fl; ++k) o[k] = mc[moff + k];
             } else {
                 uint32_t k = fl;
                 if (mag >> 32) { do { o[--k] = (uint8_t)('0' + mag % 10); mag /= 10; } while (mag); }
                 else { uint32_t m = (uint32_t)mag; do { const uint32_t q = m / 10; o[--k] = (uint8_t)('0' + (m - q * 10)); m = q; } while (m); }
                 if (neg) o[--k] = '-';
             }
-            if (c + 1 < ncols) o[fl] = g.seps[c];
+            if (c + 1 < ncols) o[fl] = sg.seps[c];
             else {
-                for (uint32_t k = 0; k < g.suffix_len; ++k) o[fl + k] = g.suffix[k];
+                for (uint32_t k = 0; k < g.suffix_len; ++k) o[fl + k] = sg.suffix[k];
                 o[fl + g.suffix_len] = '\n';
-                qend[i] = pos + fl + g.suffix_len;
             }
         }
         for (uint32_t idx = tid; idx < Rt * g.prefix_len; idx += EM_THREADS) {
-            const uint32_t i = idx / g.prefix_len, k = idx - i * g.prefix_len;
-            tile[rec_off[i] + k] = g.prefix[k];
+            uint32_t i, k;
+            fast_divmod(idx, g.prefix_len, tg.magicP, i, k);
+            tile[ro(i) + k] = sg.prefix[k];
         }
         if (ncols == 0) {                                 // no columns: QNAME = prefix + suffix
             for (uint32_t i = tid; i < Rt; i += EM_THREADS) {
-                uint8_t* o = tile + rec_off[i] + g.prefix_len;
-                for (uint32_t k = 0; k < g.suffix_len; ++k) o[k] = g.suffix[k];
+                uint8_t* o = tile + ro(i) + g.prefix_len;
+                for (uint32_t k = 0; k < g.suffix_len; ++k) o[k] = sg.suffix[k];
                 o[g.suffix_len] = '\n';
-                qend[i] = g.prefix_len + g.suffix_len;
             }
         }
-        __syncthreads();
-        // ---- 2: SEQ and QUAL text, P lanes per record
-        {
+        // ---- 2: SEQ and QUAL text
+        if constexpr (PACKED) {
+            const uint8_t* in_d = tile + tg.o_ind + skd;
+            const uint8_t* in_q = tile + tg.o_inq + skq;
+            const FastAlphabet& fa = tg.fa;
+            if (fa.fast && tg.G <= 64) {
+                // whole groups of the lookup-free alphabet: a wave takes 64 / G reads at a time, lane = (read, group); byte k of
+                // (lo, hi) is the character at L - 8 gg - 8 + k, and the image receives aligned dwords only (store8)
+                const uint32_t nper = 64u / tg.G;
+                for (uint32_t rb = (tid >> 6) * nper; rb < Rt; rb += (EM_THREADS / 64) * nper) {
+                    const uint32_t r = rb + wj;
+                    const uint32_t L = (wj < nper && r < Rt) ? s_len[r] : 0u;
+                    const bool full = 8 * wg + 8 <= L;
+                    uint32_t blo = 0, bhi = 0, qlo = 0, qhi = 0;
+                    if (full) {
+                        const uint8_t* pd = in_d + r * tg.Cd + (tg.Cd - 2 * wg - 2);
+                        const uint8_t* pq = in_q + r * tg.Cq + (tg.Cq - tg.bq * (wg + 1));
+                        const uint32_t clo = spread2(pd[0]), chi = spread2(pd[1]);
+                        switch (tg.bq) {
+                            case 1: qual8<1>(pq, qlo, qhi); break;
+                            case 2: qual8<2>(pq, qlo, qhi); break;
+                            case 3: qual8<3>(pq, qlo, qhi); break;
+                            case 4: qual8<4>(pq, qlo, qhi); break;
+                            case 5: qual8<5>(pq, qlo, qhi); break;
+                            case 6: qual8<6>(pq, qlo, qhi); break;
+                            default: qual8<7>(pq, qlo, qhi); break;
+                        }
+                        blo = __builtin_amdgcn_perm(0u, fa.base_tab, clo); bhi = __builtin_amdgcn_perm(0u, fa.base_tab, chi);
+                        if (fa.has_n) {
+                            const uint32_t mlo = ~nonzero_bytes(qlo ^ fa.n_code4), mhi = ~nonzero_bytes(qhi ^ fa.n_code4);
+                            blo = bfi(mlo, fa.n_char4, blo); bhi = bfi(mhi, fa.n_char4, bhi);
+                        }
+                        // code + qmin; a code beyond the alphabet decodes to the tables' 0
+                        const uint32_t olo = nonzero_bytes((qlo + fa.q_over) & 0x80808080u), ohi = nonzero_bytes((qhi + fa.q_over) & 0x80808080u);
+                        qlo = (qlo + fa.qmin4) & ~olo; qhi = (qhi + fa.qmin4) & ~ohi;
+                    }
+                    const uint32_t nb_b = __shfl_up(blo, 1, 64), nb_q = __shfl_up(qlo, 1, 64);      // lane - 1 = group gg - 1 = the next eight characters
+                    if (full) {
+                        const uint32_t at = ro(r + 1) - 2 * L - 4 + (L - 8 * wg - 8);
+                        store8(tile, at, blo, bhi, nb_b, wg > 0);
+                        store8(tile, at + L + 3, qlo, qhi, nb_q, wg > 0);
+                    }
+                }
+                // what is left of a read, a lane per byte: the symbols of the partial top group and those whose aligned dword is
+                // not wholly inside the run of whole groups (<= 3 at either end of each line) -- slots 0..9 from the front,
+                // 10..12 from the back -- and (slot 13) the separators
+                for (uint32_t idx = tid; idx < Rt * 16u; idx += EM_THREADS) {
+                    const uint32_t i = idx >> 4, k = idx & 15u;
+                    const uint32_t L = s_len[i], toff = ro(i + 1) - 2 * L - 4;
+                    uint8_t* ts = tile + toff;
+                    uint8_t* tq = ts + L + 3;
+                    if (k == 13) { ts[L] = '\n'; ts[L + 1] = '+'; ts[L + 2] = '\n'; tq[L] = '\n'; }
+                    if (k >= 13) continue;
+                    const uint32_t nsym = L & 7u;
+                    uint32_t headS = L, headQ = L, tailS = 0, tailQ = 0;
+                    if (L >= 8) {
+                        headS = nsym + ((0u - (toff + nsym)) & 3u); tailS = (toff + L) & 3u;
+                        headQ = nsym + ((0u - (toff + L + 3 + nsym)) & 3u); tailQ = (toff + L + 3 + L) & 3u;
+                    }
+                    uint32_t p; bool inS, inQ;
+                    if (k < 10) { p = k; inS = p < headS; inQ = p < headQ; }
+                    else { const uint32_t e = k - 10; p = L - 1 - e; inS = e < tailS; inQ = e < tailQ; }
+                    if (inS || inQ) {
+                        uint8_t cb, cc;
+                        decode_symbol(in_d + i * tg.Cd, in_q + i * tg.Cq, tg, L - 1 - p, l_base, l_qual, l_qn, cb, cc);
+                        if (inS) ts[p] = cb;
+                        if (inQ) tq[p] = cc;
+                    }
+                }
+            } else {
+                // any other alphabet: a lane per 8 symbols, every symbol through the tables
+                for (uint32_t i = tid; i < Rt; i += EM_THREADS) {
+                    const uint32_t L = s_len[i];
+                    uint8_t* ts = tile + ro(i + 1) - 2 * L - 4;
+                    ts[L] = '\n'; ts[L + 1] = '+'; ts[L + 2] = '\n'; ts[2 * L + 3] = '\n';
+                }
+                const uint32_t items = Rt * tg.G;
+                const uint32_t md = (1u << tg.bd) - 1;
+                const uint64_t mq = (1ull << tg.bq) - 1;
+                for (uint32_t idx = tid; idx < items; idx += EM_THREADS) {
+                    uint32_t r, gg;
+                    fast_divmod(idx, tg.G, tg.magicG, r, gg);
+                    const uint32_t L = s_len[r];
+                    if (8 * gg >= L) continue;
+                    uint8_t* ts = tile + ro(r + 1) - 2 * L - 4;             // first SEQ byte in the tile
+                    uint8_t* tq = ts + L + 3;                               // first QUAL byte
+                    const uint64_t vd = group_bits(in_d + r * tg.Cd, tg.Cd, tg.bd, gg);
+                    const uint64_t vq = group_bits(in_q + r * tg.Cq, tg.Cq, tg.bq, gg);
+#pragma unroll
+                    for (uint32_t i = 0; i < 8; ++i) {
+                        const uint32_t tt = 8 * gg + i;
+                        if (tt < L) {
+                            const uint32_t cd = (uint32_t)(vd >> (tg.bd * i)) & md, cq = (uint32_t)((vq >> (tg.bq * i)) & mq);
+                            const uint8_t nb = l_qn[cq];
+                            ts[L - 1 - tt] = nb ? nb : l_base[cd];
+                            tq[L - 1 - tt] = l_qual[cq];
+                        }
+                    }
+                }
+            }
+        } else {
+            // P lanes per record
             const uint32_t i = tid / P, p = tid - i * P;
             if (i < Rt) {
                 const uint64_t r = r0 + i;
                 const uint32_t L = s_len[i];
-                const uint32_t ds = rec_off[i] + qend[i] + 1;           // first SEQ byte in the tile
+                const uint32_t ds = ro(i + 1) - 2 * L - 4;              // first SEQ byte in the tile
                 const uint32_t dq = ds + L + 3;                         // first QUAL byte
                 if (p == 0) { tile[ds + L] = '\n'; tile[ds + L + 1] = '+'; tile[ds + L + 2] = '\n'; tile[dq + L] = '\n'; }
 #pragma unroll
@@ -274,45 +495,154 @@ __global__ __launch_bounds__(EM_THREADS) void emit_tile_kernel(EmitGeom g, const
         __syncthreads();
     }
 }
+
+// read lengths of variable-length DNA rows (the sentinel's position); W lanes scan one row
+template <int W>
+__global__ __launch_bounds__(256) void row_lengths_kernel(const uint8_t* __restrict__ dna, uint64_t n, uint32_t Cd, uint32_t bd, uint32_t dmax,
+                                                          uint32_t* __restrict__ len, unsigned long long* __restrict__ bad) {
+    const uint64_t r = ((uint64_t)blockIdx.x * 256 + threadIdx.x) / W;
+    const uint32_t w = threadIdx.x % W;
+    if (r >= n) return;
+    const uint8_t* row = dna + r * Cd;
+    uint32_t first = Cd;
+    for (uint32_t k = w; k < Cd; k += W) if (row[k]) { first = k; break; }
+    if (W > 1) first = wave_min(first);
+    uint32_t L;
+    const bool ok = row_length(row, Cd, first, bd, dmax, L);
+    if (w == 0) {
+        len[r] = L;
+        if (!ok) atomicMin(bad, (unsigned long long)r);
+    }
+}
+
+int make_emit_geom(uq_ctx* ctx, const char* who, const uq_emit_params* hp, const void* const* h_d_cols, const uint8_t* const* h_d_map_chars,
+                   const uint32_t* const* h_d_map_offs, EmitGeom& g) {
+    UQ_REQUIRE(hp->ncols >= 0 && hp->ncols <= EM_MAXCOLS && hp->prefix_len >= 0 && hp->prefix_len <= 256 && hp->suffix_len >= 0 && hp->suffix_len <= 256,
+               "%s: QNAME layout out of range (<= 32 columns, prefix / suffix <= 256 bytes)", who);
+    UQ_REQUIRE(hp->ncols == 0 || h_d_cols, "%s: null column table", who);
+    memset(&g, 0, sizeof(g));
+    memcpy(g.prefix, hp->prefix, 256); memcpy(g.suffix, hp->suffix, 256); memcpy(g.seps, hp->separators, EM_MAXCOLS);
+    g.prefix_len = hp->prefix_len; g.suffix_len = hp->suffix_len; g.ncols = hp->ncols; g.dna_max = hp->dna_max;
+    for (int c = 0; c < hp->ncols; ++c) {
+        g.col[c] = h_d_cols[c]; g.itemsize[c] = hp->itemsize[c]; g.add[c] = hp->add[c];
+        UQ_REQUIRE(g.itemsize[c] == 1 || g.itemsize[c] == 2 || g.itemsize[c] == 4 || g.itemsize[c] == 8, "%s: bad column itemsize", who);
+        g.map_chars[c] = h_d_map_chars ? h_d_map_chars[c] : nullptr;
+        g.map_offs[c] = h_d_map_offs ? h_d_map_offs[c] : nullptr;
+        UQ_REQUIRE((g.map_chars[c] == nullptr) == (g.map_offs[c] == nullptr), "%s: mapping column needs both string tables", who);
+    }
+    return 0;
+}
+
+// record sizes -> offsets (exclusive scan); the total (and *d_bad, when given) come back with one synchronisation
+int emit_offsets(uq_ctx* ctx, const EmitGeom& g, const uint32_t* d_len, uint64_t nreads, uint64_t* d_offsets, uint64_t* h_total,
+                 const uint64_t* d_bad, uint64_t* h_bad) {
+    emit_sizes_kernel<<<(uint32_t)((nreads + 255) / 256), 256, 0, ctx->stream>>>(g, d_len, nreads, d_offsets);
+    UQ_LAUNCH_CHECK();
+    UQ_TRY(uq_scan_exclusive_u64(ctx, d_offsets, d_offsets, nreads, d_offsets + nreads));
+    UQ_CHECK_HIP(hipMemcpyAsync(ctx->h_pinned, d_offsets + nreads, 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (d_bad) UQ_CHECK_HIP(hipMemcpyAsync(ctx->h_pinned + 1, d_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
+    UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    *h_total = ctx->h_pinned[0];
+    if (d_bad && h_bad) *h_bad = ctx->h_pinned[1];
+    return 0;
+}
+
+// LDS carve for a tile of records of `avg` text bytes; packed != 0 adds the staged rows.  R = 0: nothing fits (direct path only).
+size_t plan_tile(TileGeom& tg, uint64_t avg, const EmitGeom& g, bool packed) {
+    const uint32_t ncols = g.ncols;
+    tg.magicP = g.prefix_len ? magic_u32(g.prefix_len) : 0;
+    const uint64_t text = avg + avg / 8 + 1;
+    const uint64_t per = text + 8 + 4 + 2ull * ncols + (packed ? tg.Cd + tg.Cq : 0);
+    uint64_t R = ((packed ? EM_BUDGET_PACKED : EM_BUDGET_TEXT) - 256) / per;
+    if (R > EM_RMAX) R = EM_RMAX;
+    if (packed) while (R > 0 && (R * tg.Cd + 48 > DE_NV * EM_THREADS * 16u || R * tg.Cq + 48 > DE_NV * EM_THREADS * 16u)) --R;
+    const bool fits = R >= 1;
+    if (!fits) R = 1;
+    tg.R = (uint32_t)R;
+    tg.P = EM_THREADS / tg.R;
+    tg.cap = fits ? (uint32_t)(R * text + 64) & ~15u : 0u;
+    uint32_t off = fits ? tg.cap + 32 : 32;
+    auto carve = [&](uint32_t bytes) { uint32_t o = off; off += (bytes + 15) & ~15u; return o; };
+    tg.o_off = carve((tg.R + 1) * 8); tg.o_len = carve(tg.R * 4);
+    tg.o_flen = carve(tg.R * (ncols ? ncols : 1) * 2);
+    tg.o_ind = tg.o_inq = 0;
+    if (packed && fits) { tg.o_ind = carve(tg.R * tg.Cd + 32); tg.o_inq = carve(tg.R * tg.Cq + 32); }
+    return off;
+}
+
+uint32_t tile_blocks(uint64_t tiles, size_t lds) {
+    uint64_t per_cu = (160u * 1024u) / (lds + 3072);       // + the static tables
+    if (per_cu > 4) per_cu = 4;                            // what the kernel's registers allow
+    if (per_cu < 1) per_cu = 1;
+    return (uint32_t)(tiles < UQ_NUM_CU * per_cu ? tiles : UQ_NUM_CU * per_cu);
+}
 }  // namespace
 
 extern "C" int uq_emit_fastq(uq_ctx* ctx, const uq_emit_params* hp, const void* const* h_d_cols, const uint8_t* const* h_d_map_chars,
                              const uint32_t* const* h_d_map_offs, const uint8_t* d_seq, const uint8_t* d_qual, const uint32_t* d_len,
                              uint64_t nreads, uint64_t* d_offsets, uint8_t* d_out, uint64_t capacity, uint64_t* h_total) {
     UQ_REQUIRE(ctx && hp && d_offsets && h_total, "uq_emit_fastq: null argument");
-    UQ_REQUIRE(hp->ncols >= 0 && hp->ncols <= EM_MAXCOLS && hp->prefix_len >= 0 && hp->prefix_len <= 256 && hp->suffix_len >= 0 && hp->suffix_len <= 256,
-               "uq_emit_fastq: QNAME layout out of range (<= 32 columns, prefix / suffix <= 256 bytes)");
     *h_total = 0;
-    if (nreads == 0) return 0;
-    UQ_REQUIRE(d_seq && d_qual && d_len && (hp->ncols == 0 || h_d_cols), "uq_emit_fastq: null buffer");
     EmitGeom g;
-    memset(&g, 0, sizeof(g));
-    memcpy(g.prefix, hp->prefix, 256); memcpy(g.suffix, hp->suffix, 256); memcpy(g.seps, hp->separators, EM_MAXCOLS);
-    g.prefix_len = hp->prefix_len; g.suffix_len = hp->suffix_len; g.ncols = hp->ncols; g.dna_max = hp->dna_max;
-    for (int c = 0; c < hp->ncols; ++c) {
-        g.col[c] = h_d_cols[c]; g.itemsize[c] = hp->itemsize[c]; g.add[c] = hp->add[c];
-        UQ_REQUIRE(g.itemsize[c] == 1 || g.itemsize[c] == 2 || g.itemsize[c] == 4 || g.itemsize[c] == 8, "uq_emit_fastq: bad column itemsize");
-        g.map_chars[c] = h_d_map_chars ? h_d_map_chars[c] : nullptr;
-        g.map_offs[c] = h_d_map_offs ? h_d_map_offs[c] : nullptr;
-        UQ_REQUIRE((g.map_chars[c] == nullptr) == (g.map_offs[c] == nullptr), "uq_emit_fastq: mapping column needs both string tables");
-    }
-    emit_sizes_kernel<<<(uint32_t)((nreads + 255) / 256), 256, 0, ctx->stream>>>(g, d_len, nreads, d_offsets);
-    UQ_LAUNCH_CHECK();
-    UQ_TRY(uq_scan_exclusive_u64(ctx, d_offsets, d_offsets, nreads, d_offsets + nreads));
-    UQ_CHECK_HIP(hipMemcpyAsync(ctx->h_pinned, d_offsets + nreads, 8, hipMemcpyDeviceToHost, ctx->stream));
-    UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-    *h_total = ctx->h_pinned[0];
+    UQ_TRY(make_emit_geom(ctx, "uq_emit_fastq", hp, h_d_cols, h_d_map_chars, h_d_map_offs, g));
+    if (nreads == 0) return 0;
+    UQ_REQUIRE(d_seq && d_qual && d_len, "uq_emit_fastq: null buffer");
+    UQ_TRY(emit_offsets(ctx, g, d_len, nreads, d_offsets, h_total, nullptr, nullptr));
     if (!d_out) return 0;                       // size query
     UQ_REQUIRE(capacity >= *h_total, "uq_emit_fastq: output buffer too small (%llu < %llu)", (unsigned long long)capacity, (unsigned long long)*h_total);
     // tile = R records sized from the average record so that a typical tile fits the LDS image
-    const uint64_t avg = *h_total / nreads + 1;
-    uint64_t R = (EM_CAP - 64) / (avg + avg / 8 + 1);
-    if (R > EM_RMAX) R = EM_RMAX;
-    if (R < 1) R = 1;
-    const uint32_t P = EM_THREADS / (uint32_t)R;
-    const uint64_t tiles = (nreads + R - 1) / R;
-    const uint64_t blocks = tiles < (uint64_t)UQ_NUM_CU * 6 ? tiles : (uint64_t)UQ_NUM_CU * 6;
-    emit_tile_kernel<<<(uint32_t)blocks, EM_THREADS, 0, ctx->stream>>>(g, d_seq, d_qual, d_len, nreads, d_offsets, d_out, (uint32_t)R, P);
+    TileGeom tg;
+    memset(&tg, 0, sizeof(tg));
+    const size_t lds = plan_tile(tg, *h_total / nreads + 1, g, false);
+    const uint64_t tiles = (nreads + tg.R - 1) / tg.R;
+    emit_tile_kernel<false><<<tile_blocks(tiles, lds), EM_THREADS, lds, ctx->stream>>>(g, tg, NoLut{}, d_seq, d_qual, d_len, nreads, d_offsets, d_out);
+    UQ_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int uq_decode_fastq(uq_ctx* ctx, const uq_emit_params* hp, const uq_unpack_params* up, const void* const* h_d_cols,
+                               const uint8_t* const* h_d_map_chars, const uint32_t* const* h_d_map_offs, const uint8_t* d_dna,
+                               const uint8_t* d_qual, uint64_t nreads, uint32_t* d_len, uint64_t* d_offsets, uint64_t* d_bad,
+                               uint8_t* d_out, uint64_t capacity, uint64_t* h_total, uint64_t* h_bad) {
+    UQ_REQUIRE(ctx && hp && up && d_offsets && d_bad && h_total && h_bad, "uq_decode_fastq: null argument");
+    *h_total = 0; *h_bad = ~0ull;
+    EmitGeom g;
+    UQ_TRY(make_emit_geom(ctx, "uq_decode_fastq", hp, h_d_cols, h_d_map_chars, h_d_map_offs, g));
+    UQ_REQUIRE(up->bits_per_base >= 1 && up->bits_per_base <= 8 && up->bits_per_quality >= 1 && up->bits_per_quality <= 8,
+               "uq_decode_fastq: bits per symbol must be 1..8");
+    UQ_REQUIRE(up->dna_max >= 1 && up->dna_max == hp->dna_max, "uq_decode_fastq: dna_max must be positive and the same in both parameter blocks");
+    TileGeom tg;
+    memset(&tg, 0, sizeof(tg));
+    tg.bd = up->bits_per_base; tg.bq = up->bits_per_quality; tg.Cd = up->dna_bytes_per_row; tg.Cq = up->quality_bytes_per_row;
+    const uint32_t variable = up->variable ? 1 : 0, Lv = up->dna_max + variable;
+    UQ_REQUIRE(tg.Cd == (tg.bd * Lv + 7) / 8 && tg.Cq == (tg.bq * Lv + 7) / 8, "uq_decode_fastq: row bytes do not match the geometry");
+    tg.G = (up->dna_max + 7) / 8;
+    tg.magicG = magic_u32(tg.G);
+    tg.fa = fast_alphabet(up);
+    if (nreads == 0) return 0;
+    UQ_REQUIRE(d_dna && d_qual && (d_len || !variable), "uq_decode_fastq: null buffer");
+    const uint32_t* lens = variable ? d_len : nullptr;       // fixed-length tables: every read is dna_max long
+    if (!d_out) {                                            // first call: lengths, record offsets, total size
+        UQ_CHECK_HIP(hipMemsetAsync(d_bad, 0xFF, 8, ctx->stream));
+        if (variable) {
+            if (tg.Cd > 512) row_lengths_kernel<64><<<(uint32_t)((nreads + 3) / 4), 256, 0, ctx->stream>>>(d_dna, nreads, tg.Cd, tg.bd, up->dna_max, d_len, (unsigned long long*)d_bad);
+            else row_lengths_kernel<1><<<(uint32_t)((nreads + 255) / 256), 256, 0, ctx->stream>>>(d_dna, nreads, tg.Cd, tg.bd, up->dna_max, d_len, (unsigned long long*)d_bad);
+            UQ_LAUNCH_CHECK();
+        }
+        UQ_TRY(emit_offsets(ctx, g, lens, nreads, d_offsets, h_total, d_bad, h_bad));
+        return 0;
+    }
+    // second call: d_len / d_offsets hold what the first one left; the total is its last offset
+    UQ_CHECK_HIP(hipMemcpyAsync(ctx->h_pinned, d_offsets + nreads, 8, hipMemcpyDeviceToHost, ctx->stream));
+    UQ_CHECK_HIP(hipMemcpyAsync(ctx->h_pinned + 1, d_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
+    UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    *h_total = ctx->h_pinned[0]; *h_bad = ctx->h_pinned[1];
+    UQ_REQUIRE(capacity >= *h_total, "uq_decode_fastq: output buffer too small (%llu < %llu)", (unsigned long long)capacity, (unsigned long long)*h_total);
+    UnpackLut lut;
+    memcpy(lut.base_char, up->base_char, 256); memcpy(lut.qual_char, up->qual_char, 256); memcpy(lut.qual_n_base, up->qual_n_base, 256);
+    const size_t lds = plan_tile(tg, *h_total / nreads + 1, g, true);
+    const uint64_t tiles = (nreads + tg.R - 1) / tg.R;
+    emit_tile_kernel<true><<<tile_blocks(tiles, lds), EM_THREADS, lds, ctx->stream>>>(g, tg, lut, d_dna, d_qual, lens, nreads, d_offsets, d_out);
     UQ_LAUNCH_CHECK();
     return 0;
 }

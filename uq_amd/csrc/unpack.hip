@@ -11,11 +11,11 @@
 #include "common.h"
 #include "swar.h"
 #include "tile_io.h"
+#include "codes.h"
 
 namespace {
 constexpr int UT = TIO_THREADS;
 
-struct UnpackLut { uint8_t base_char[256], qual_char[256], qual_n_base[256]; };
 struct UnpackGeom {
     uint32_t R, bd, bq, Cd, Cq, dmax, variable, G;   // G = 8-symbol groups per read
     uint32_t in_d, in_q, out_s, out_q, lens;         // LDS byte offsets
@@ -39,16 +39,6 @@ struct LinearFn {
         }
     }
 };
-
-__device__ __forceinline__ uint64_t group_bits(const uint8_t* row, uint32_t C, uint32_t b, uint32_t g) {
-    // bytes i = b*g .. b*g + b - 1 counted from the row's LAST byte, little-endian into a u64
-    uint64_t v = 0;
-    for (uint32_t i = 0; i < b; ++i) {
-        uint32_t bi = b * g + i;
-        if (bi < C) v |= (uint64_t)row[C - 1 - bi] << (8 * i);
-    }
-    return v;
-}
 
 __global__ __launch_bounds__(UT) void unpack_kernel(const uint8_t* __restrict__ dna, const uint8_t* __restrict__ qual, uint64_t n,
                                                     UnpackLut lut, UnpackGeom g, uint8_t* __restrict__ seq, uint8_t* __restrict__ qtxt,
@@ -334,23 +324,8 @@ extern "C" int uq_unpack(uq_ctx* ctx, const uint8_t* d_dna, const uint8_t* d_qua
     auto carve = [&](uint32_t bytes) { uint32_t o = off; off += (bytes + 15) & ~15u; return o; };
     {
         // is this alphabet one the lookup-free path decodes?  (anything else: the table path, same results)
-        g.fast = 0; g.base_tab = g.qmin4 = g.q_over = g.has_n = g.n_code4 = g.n_char4 = 0;
-        int nq = 0;
-        while (nq < (1 << g.bq) && hp->qual_char[nq] != 0) ++nq;
-        bool ok = g.bd == 2 && g.bq <= 7 && nq >= 1;
-        for (int c = 0; ok && c < nq; ++c) ok = hp->qual_char[c] == hp->qual_char[0] + c;
-        for (int c = nq; ok && c < (1 << g.bq); ++c) ok = hp->qual_char[c] == 0 && hp->qual_n_base[c] == 0;
-        int ncodes = 0, ncode = 0;
-        for (int c = 0; ok && c < nq; ++c) if (hp->qual_n_base[c]) { ++ncodes; ncode = c; }
-        ok = ok && ncodes <= 1;
-        for (int c = 0; ok && c < 4; ++c) ok = hp->base_char[c] != 0;
-        if (ok) {
-            g.fast = 1;
-            g.base_tab = (uint32_t)hp->base_char[0] | ((uint32_t)hp->base_char[1] << 8) | ((uint32_t)hp->base_char[2] << 16) | ((uint32_t)hp->base_char[3] << 24);
-            g.qmin4 = 0x01010101u * hp->qual_char[0];
-            g.q_over = 0x01010101u * (uint32_t)(0x80 - nq);
-            g.has_n = (uint32_t)ncodes; g.n_code4 = 0x01010101u * (uint32_t)ncode; g.n_char4 = 0x01010101u * hp->qual_n_base[ncode];
-        }
+        const FastAlphabet a = fast_alphabet(hp);
+        g.fast = a.fast; g.base_tab = a.base_tab; g.qmin4 = a.qmin4; g.q_over = a.q_over; g.has_n = a.has_n; g.n_code4 = a.n_code4; g.n_char4 = a.n_char4;
     }
     // the pipelined kernel: tiles of R reads within ~31 KiB of LDS (five workgroups per CU) and the register budget
     uint32_t Rp = (31 * 1024) / per_read;

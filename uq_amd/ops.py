@@ -301,11 +301,9 @@ def unpack(ctx, dna, qual, nreads, params):
 
 
 # ------------------------------------------------------------------ FASTQ text emit (decode)
-def emit_fastq(ctx, config, column_tensors, seq, qual, ln, nreads):
-    """Device-side FASTQ text: returns a uint8 tensor with the whole decoded file.
-    `column_tensors`: one device tensor per QNAME column (values per read, the column's dtype)."""
+def _emit_params(ctx, config, column_tensors):
+    """config.json's QNAME layout -> (uq_emit_params, column / string-table pointer arrays, tensors to keep alive)."""
     from ._lib import EmitParams
-    t = ctx.torch
     cols = config['QNAME_columns']
     if len(cols) > 32: raise ValueError('more than 32 QNAME columns')
     p = EmitParams()
@@ -330,6 +328,14 @@ def emit_fastq(ctx, config, column_tensors, seq, qual, ln, nreads):
             offt = ctx.to_device(offs)
             keep += [chars, offt]
             d_chars[i] = chars.data_ptr(); d_offs[i] = offt.data_ptr()
+    return p, d_cols, d_chars, d_offs, keep
+
+
+def emit_fastq(ctx, config, column_tensors, seq, qual, ln, nreads):
+    """Device-side FASTQ text: returns a uint8 tensor with the whole decoded file.
+    `column_tensors`: one device tensor per QNAME column (values per read, the column's dtype)."""
+    t = ctx.torch
+    p, d_cols, d_chars, d_offs, keep = _emit_params(ctx, config, column_tensors)
     offsets = t.empty(nreads + 1, dtype=t.int64, device=ctx.device)
     total = C.c_uint64()
     call('uq_emit_fastq', ctx.h, C.byref(p), d_cols, d_chars, d_offs, _p(seq), _p(qual), _p(ln), nreads, _p(offsets), None, 0, C.byref(total))
@@ -337,6 +343,25 @@ def emit_fastq(ctx, config, column_tensors, seq, qual, ln, nreads):
     call('uq_emit_fastq', ctx.h, C.byref(p), d_cols, d_chars, d_offs, _p(seq), _p(qual), _p(ln), nreads, _p(offsets), _p(out), total.value, C.byref(total))
     del keep
     return out
+
+
+def decode_fastq(ctx, config, column_tensors, dna, qual, nreads):
+    """Packed DNA / QUAL tables + QNAME columns -> the FASTQ text (uint8 device tensor), in one pass over the rows
+    (uq_decode_fastq).  Returns (text, bad): bad = lowest row without a length sentinel, or None."""
+    t = ctx.torch
+    p, d_cols, d_chars, d_offs, keep = _emit_params(ctx, config, column_tensors)
+    up = make_unpack_params(config)
+    offsets = t.empty(nreads + 1, dtype=t.int64, device=ctx.device)
+    ln = t.empty(nreads if up.variable else 0, dtype=t.int32, device=ctx.device)
+    d_bad = t.empty(1, dtype=t.int64, device=ctx.device)
+    total = C.c_uint64(); bad = C.c_uint64()
+    args = (ctx.h, C.byref(p), C.byref(up), d_cols, d_chars, d_offs, _p(dna), _p(qual), nreads, _p(ln) if up.variable else None, _p(offsets), _p(d_bad))
+    call('uq_decode_fastq', *args, None, 0, C.byref(total), C.byref(bad))
+    if bad.value != 2 ** 64 - 1: return None, int(bad.value)
+    out = t.empty(total.value, dtype=t.uint8, device=ctx.device)
+    call('uq_decode_fastq', *args, _p(out), total.value, C.byref(total), C.byref(bad))
+    del keep
+    return out, None
 
 
 # ------------------------------------------------------------------ synthetic input

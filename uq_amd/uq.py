@@ -59,6 +59,8 @@ def build_parser():
     p.add_argument('--host-qname', action='store_true', default=False, help='run the QNAME passes sequentially on the host (extension)')
     p.add_argument('--one-pass', action='store_true', default=False,
                    help='pack speculatively during the statistics pass with the decisions of the previous encode of this process, verify afterwards (extension)')
+    p.add_argument('--two-pass-decode', action='store_true', default=False,
+                   help='decode through the fixed-pitch text arrays (uq_unpack + uq_emit_fastq) instead of the fused kernel (extension)')
     return p
 
 
@@ -606,14 +608,19 @@ class Session:
                 d_cols.append(ops.gather_rows(ctx, c.view(u8), c.numel(), c.element_size(), d_key).view(c.dtype))
         else:
             d_cols = [self.load_from_tar(members, 'QNAME_%d.raw' % (i + 1)) for i in range(ncols)]
-        seq, qt, ln = self.split_bits(DNA, QUAL, config)
         n = DNA[1]
         w = out.buffer if hasattr(out, 'buffer') else out
         if len(config['QNAME_columns']) <= 32 and len(config['QNAME_prefix']) <= 256 and len(config['QNAME_suffix']) <= 256:
-            # the text is assembled on the device (uq_emit_fastq) and streams out through the pinned buffers
-            text = ops.emit_fastq(ctx, config, d_cols, seq, qt, ln, n)
+            # rows -> text in one kernel (uq_decode_fastq); the text streams out through the pinned buffers
+            if getattr(args, 'two_pass_decode', False):
+                seq, qt, ln = self.split_bits(DNA, QUAL, config)
+                text = ops.emit_fastq(ctx, config, d_cols, seq, qt, ln, n)
+            else:
+                text, bad = ops.decode_fastq(ctx, config, d_cols, DNA[0], QUAL[0], n)
+                if bad is not None: error('ERROR: row %d of the DNA table carries no length sentinel; is this a uQ file?' % bad)
             self.io.device_to_stream(text, w)
         else:
+            seq, qt, ln = self.split_bits(DNA, QUAL, config)
             dmax = config['dna_max']
             S = ctx.to_numpy(seq).reshape(n, dmax); Q = ctx.to_numpy(qt).reshape(n, dmax); L = ctx.to_numpy(ln, np.uint32)
             cols = [ctx.to_numpy(c, np.dtype(cc['dtype'])) for c, cc in zip(d_cols, config['QNAME_columns'])]
