@@ -161,12 +161,13 @@ __device__ __forceinline__ void qual8(const uint8_t* p, uint32_t& qlo, uint32_t&
 // characters follow (has_dn; nb_lo = their first four, from the lane below) -- the dword that straddles the two groups.
 // The first 4 - a bytes of a read's top group and the last a of its bottom group are left to the per-read fix-up.
 __device__ __forceinline__ void store8(uint8_t* image, uint32_t at, uint32_t lo, uint32_t hi, uint32_t nb_lo, bool has_dn) {
-    const uint32_t a = at & 3u;
-    uint8_t* dst = image + at;
-    if (a == 0) { *(uint32_t*)dst = lo; *(uint32_t*)(dst + 4) = hi; return; }
-    const uint32_t sh = 4u - a;
-    *(uint32_t*)(dst + sh) = __builtin_amdgcn_alignbyte(hi, lo, sh);
-    if (has_dn) *(uint32_t*)(dst + sh + 4) = __builtin_amdgcn_alignbyte(nb_lo, hi, sh);
+    // branch-free: with sh = -a mod 4, t1 = (hi:lo) >> 8 sh and t2 = (nb_lo:hi) >> 8 sh are (lo, hi) when a = 0 and the
+    // filled / the straddling dword otherwise
+    const uint32_t a = at & 3u, sh = (0u - a) & 3u;
+    uint8_t* base = image + (at & ~3u);
+    const uint32_t t1 = __builtin_amdgcn_alignbyte(hi, lo, sh), t2 = __builtin_amdgcn_alignbyte(nb_lo, hi, sh);
+    *(uint32_t*)(base + 4) = a ? t1 : t2;
+    if (!a || has_dn) *(uint32_t*)(base + (a ? 8 : 0)) = a ? t2 : t1;
 }
 // one symbol through the tables: t = its index from the END of the read (rows are right-aligned)
 __device__ __forceinline__ void decode_symbol(const uint8_t* drow, const uint8_t* qrow, const TileGeom& tg, uint32_t t, const uint8_t* l_base,
@@ -329,10 +330,18 @@ __global__ __launch_bounds__(EM_THREADS, 4) void emit_tile_kernel(EmitGeom g, Ti
                 o[fl + g.suffix_len] = '\n';
             }
         }
-        for (uint32_t idx = tid; idx < Rt * g.prefix_len; idx += EM_THREADS) {
-            uint32_t i, k;
-            fast_divmod(idx, g.prefix_len, tg.magicP, i, k);
-            tile[ro(i) + k] = sg.prefix[k];
+        if (one_item && ncols) {                          // the prefix: shared out among the record's field lanes
+            if (tid < Rt * ncols) {
+                const uint32_t i = tid / ncols, c = tid - i * ncols;
+                uint8_t* o = tile + ro(i);
+                for (uint32_t k = c; k < g.prefix_len; k += ncols) o[k] = sg.prefix[k];
+            }
+        } else {
+            for (uint32_t idx = tid; idx < Rt * g.prefix_len; idx += EM_THREADS) {
+                uint32_t i, k;
+                fast_divmod(idx, g.prefix_len, tg.magicP, i, k);
+                tile[ro(i) + k] = sg.prefix[k];
+            }
         }
         if (ncols == 0) {                                 // no columns: QNAME = prefix + suffix
             for (uint32_t i = tid; i < Rt; i += EM_THREADS) {
