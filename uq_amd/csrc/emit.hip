@@ -128,7 +128,7 @@ __device__ void emit_record_direct(const EmitGeom& g, const uint8_t* __restrict_
 //      aligned uint4
 constexpr int EM_THREADS = 256;
 constexpr uint32_t EM_RMAX = 64;
-constexpr int DE_NV = 2;                 // 16-byte vectors per lane and table of packed rows in flight (<= 8 KiB per table and tile)
+constexpr int DE_NVD = 2, DE_NVQ = 3;    // 16-byte vectors per lane of packed rows in flight: DNA rows <= 8 KiB, QUAL rows <= 12 KiB per tile
 constexpr uint32_t EM_BUDGET_TEXT = 19 * 1024, EM_BUDGET_PACKED = 36 * 1024;   // dynamic LDS per workgroup (the registers allow four workgroups per CU)
 
 struct TileGeom {
@@ -136,6 +136,7 @@ struct TileGeom {
     uint32_t o_off, o_len, o_flen, o_ind, o_inq;                 // LDS byte offsets behind the image
     uint32_t magicP;                                             // magic_u32(prefix_len)
     uint32_t bd, bq, Cd, Cq, G, magicG;                          // packed form: row geometry, G = 8-symbol groups per read
+    uint32_t variable, Gf, magicGf, o_cum;                       // Gf = whole groups of a fixed-length read
     FastAlphabet fa;
 };
 struct NoLut {};
@@ -208,6 +209,7 @@ __global__ __launch_bounds__(EM_THREADS, 4) void emit_tile_kernel(EmitGeom g, Ti
     unsigned long long* s_off = (unsigned long long*)(tile + tg.o_off);              // [R + 1] record offsets of the tile, as fetched
     uint32_t* s_len = (uint32_t*)(tile + tg.o_len);                                  // [R]
     uint16_t* flen = (uint16_t*)(tile + tg.o_flen);                                  // [R][ncols]
+    uint32_t* cum = (uint32_t*)(tile + tg.o_cum);                                    // [R + 1] packed form: whole 8-symbol groups before record i
     __shared__ uint8_t l_tab[PACKED ? 768 : 4];
     const uint8_t* l_base = l_tab; const uint8_t* l_qual = l_tab + 256; const uint8_t* l_qn = l_tab + 512;
     // the QNAME layout (prefix, suffix, separators, the per-column pointers and offsets) is indexed per lane: an LDS copy
@@ -235,12 +237,14 @@ __global__ __launch_bounds__(EM_THREADS, 4) void emit_tile_kernel(EmitGeom g, Ti
         if (one_item && tid < Rt * ncols) { const uint32_t i = tid / ncols, c = tid - i * ncols; x.raw = load_col(sg.col[c], sg.itemsize[c], r0 + i); }
         return x;
     };
-    struct Rows { uint4 d[DE_NV], q[DE_NV]; uint32_t skd, skq, nvd, nvq; };
+    struct Rows { uint4 d[DE_NVD], q[DE_NVQ]; uint32_t skd, skq, nvd, nvq; };
     auto fetch_rows = [&](uint64_t tt) {
         Rows x;
         x.skd = x.skq = x.nvd = x.nvq = 0;
 #pragma unroll
-        for (int u = 0; u < DE_NV; ++u) { x.d[u] = make_uint4(0, 0, 0, 0); x.q[u] = make_uint4(0, 0, 0, 0); }
+        for (int u = 0; u < DE_NVD; ++u) x.d[u] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < DE_NVQ; ++u) x.q[u] = make_uint4(0, 0, 0, 0);
         if (!PACKED || cap == 0 || tt >= ntiles) return x;
         const uint32_t Rt = (uint32_t)((n - tt * R) < R ? (n - tt * R) : R);
         const uint64_t ad = (uint64_t)(uintptr_t)(seq + tt * R * tg.Cd), aq = (uint64_t)(uintptr_t)(qual + tt * R * tg.Cq);
@@ -249,14 +253,11 @@ __global__ __launch_bounds__(EM_THREADS, 4) void emit_tile_kernel(EmitGeom g, Ti
         const uint4* sd = (const uint4*)(uintptr_t)(ad & ~uint64_t(15));
         const uint4* sq = (const uint4*)(uintptr_t)(aq & ~uint64_t(15));
 #pragma unroll
-        for (int u = 0; u < DE_NV; ++u) {
-            const uint32_t i = u * EM_THREADS + tid;
-            if (i < x.nvd) x.d[u] = sd[i];
-            if (i < x.nvq) x.q[u] = sq[i];
-        }
+        for (int u = 0; u < DE_NVD; ++u) { const uint32_t i = u * EM_THREADS + tid; if (i < x.nvd) x.d[u] = sd[i]; }
+#pragma unroll
+        for (int u = 0; u < DE_NVQ; ++u) { const uint32_t i = u * EM_THREADS + tid; if (i < x.nvq) x.q[u] = sq[i]; }
         return x;
     };
-    const uint32_t wj = PACKED ? lane / tg.G : 0u, wg = PACKED ? lane - wj * tg.G : 0u;   // packed form: the lane's (read slot, group) in its wave
     Pre nx = fetch(blockIdx.x);
     Rows nr = fetch_rows(blockIdx.x);
     for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
@@ -267,13 +268,18 @@ __global__ __launch_bounds__(EM_THREADS, 4) void emit_tile_kernel(EmitGeom g, Ti
         if (tid < Rt) s_len[tid] = cur.L;
         uint32_t skd = 0, skq = 0;
         if constexpr (PACKED) {
+            if (tid < 64) {                               // wave 0 holds every length of the tile (R <= 64): running count of whole groups
+                uint32_t v = tid < Rt ? cur.L >> 3 : 0u;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(v, d, 64); if (lane >= (uint32_t)d) v += o; }
+                cum[tid + 1] = v;
+                if (tid == 0) cum[0] = 0;
+            }
             skd = nr.skd; skq = nr.skq;
 #pragma unroll
-            for (int u = 0; u < DE_NV; ++u) {
-                const uint32_t i = u * EM_THREADS + tid;
-                if (i < nr.nvd) ((uint4*)(tile + tg.o_ind))[i] = nr.d[u];
-                if (i < nr.nvq) ((uint4*)(tile + tg.o_inq))[i] = nr.q[u];
-            }
+            for (int u = 0; u < DE_NVD; ++u) { const uint32_t i = u * EM_THREADS + tid; if (i < nr.nvd) ((uint4*)(tile + tg.o_ind))[i] = nr.d[u]; }
+#pragma unroll
+            for (int u = 0; u < DE_NVQ; ++u) { const uint32_t i = u * EM_THREADS + tid; if (i < nr.nvq) ((uint4*)(tile + tg.o_inq))[i] = nr.q[u]; }
         }
         // ---- 1a: field lengths (from the prefetched column values)
         uint64_t my_mag = 0; bool my_neg = false; uint32_t my_moff = 0, my_fl = 0;
@@ -355,14 +361,27 @@ __global__ __launch_bounds__(EM_THREADS, 4) void emit_tile_kernel(EmitGeom g, Ti
             const uint8_t* in_d = tile + tg.o_ind + skd;
             const uint8_t* in_q = tile + tg.o_inq + skq;
             const FastAlphabet& fa = tg.fa;
-            if (fa.fast && tg.G <= 64) {
-                // whole groups of the lookup-free alphabet: a wave takes 64 / G reads at a time, lane = (read, group); byte k of
-                // (lo, hi) is the character at L - 8 gg - 8 + k, and the image receives aligned dwords only (store8)
-                const uint32_t nper = 64u / tg.G;
-                for (uint32_t rb = (tid >> 6) * nper; rb < Rt; rb += (EM_THREADS / 64) * nper) {
-                    const uint32_t r = rb + wj;
-                    const uint32_t L = (wj < nper && r < Rt) ? s_len[r] : 0u;
-                    const bool full = 8 * wg + 8 <= L;
+            if (fa.fast) {
+                // whole groups of the lookup-free alphabet, flat over the tile: item = (read, group) in the order of cum[] (the
+                // running count of whole groups, left by wave 0 before the first barrier); byte k of (lo, hi) is the
+                // character at L - 8 gg - 8 + k, and the image receives aligned dwords only (store8).  A wave-step takes
+                // 63 items: lane 0 recomputes the item before them, which only supplies its bytes to lane 1.
+                const uint32_t total = cum[Rt];
+                for (uint32_t start = (tid >> 6) * 63u; start < total; start += (EM_THREADS / 64) * 63u) {
+                    const uint32_t item = start + lane - 1u;                 // lane 0 of the first step: none (wraps)
+                    const bool full = item < total;
+                    uint32_t r = 0, wg = 0, L = 0;
+                    if (full) {
+                        if (tg.variable) {                                   // largest r with cum[r] <= item
+                            uint32_t hi = Rt;
+#pragma unroll
+                            for (int it = 0; it < 6; ++it) { const uint32_t mid = (r + hi) >> 1; if (cum[mid] <= item) r = mid; else hi = mid; }
+                            wg = item - cum[r];
+                        } else {
+                            fast_divmod(item, tg.Gf, tg.magicGf, r, wg);
+                        }
+                        L = s_len[r];
+                    }
                     uint32_t blo = 0, bhi = 0, qlo = 0, qhi = 0;
                     if (full) {
                         const uint8_t* pd = in_d + r * tg.Cd + (tg.Cd - 2 * wg - 2);
@@ -389,8 +408,10 @@ __global__ __launch_bounds__(EM_THREADS, 4) void emit_tile_kernel(EmitGeom g, Ti
                     const uint32_t nb_b = __shfl_up(blo, 1, 64), nb_q = __shfl_up(qlo, 1, 64);      // lane - 1 = group gg - 1 = the next eight characters
                     if (full) {
                         const uint32_t at = ro(r + 1) - 2 * L - 4 + (L - 8 * wg - 8);
-                        store8(tile, at, blo, bhi, nb_b, wg > 0);
-                        store8(tile, at + L + 3, qlo, qhi, nb_q, wg > 0);
+                        if (lane > 0) {
+                            store8(tile, at, blo, bhi, nb_b, wg > 0);
+                            store8(tile, at + L + 3, qlo, qhi, nb_q, wg > 0);
+                        }
                     }
                 }
                 // what is left of a read, a lane per byte: the symbols of the partial top group and those whose aligned dword is
@@ -505,17 +526,32 @@ __global__ __launch_bounds__(EM_THREADS, 4) void emit_tile_kernel(EmitGeom g, Ti
     }
 }
 
-// read lengths of variable-length DNA rows (the sentinel's position); W lanes scan one row
+// read lengths of variable-length DNA rows (the sentinel's position).  W lanes scan one row a dword each per step
+// (unaligned loads: rows start anywhere), the first non-zero byte is the minimum over the group.
 template <int W>
 __global__ __launch_bounds__(256) void row_lengths_kernel(const uint8_t* __restrict__ dna, uint64_t n, uint32_t Cd, uint32_t bd, uint32_t dmax,
                                                           uint32_t* __restrict__ len, unsigned long long* __restrict__ bad) {
     const uint64_t r = ((uint64_t)blockIdx.x * 256 + threadIdx.x) / W;
     const uint32_t w = threadIdx.x % W;
-    if (r >= n) return;
+    if (r >= n) return;                                   // whole groups leave together (256 % W == 0)
     const uint8_t* row = dna + r * Cd;
+    const uint32_t nd = Cd >> 2;
     uint32_t first = Cd;
-    for (uint32_t k = w; k < Cd; k += W) if (row[k]) { first = k; break; }
-    if (W > 1) first = wave_min(first);
+    for (uint32_t d0 = 0; d0 < nd && first == Cd; d0 += W) {      // `first` is the same in all lanes of the group
+        const uint32_t d = d0 + w;
+        const uint32_t v = d < nd ? load_u32_any(row + 4 * d) : 0u;
+        uint32_t cand = v ? 4 * d + ((uint32_t)__builtin_ctz(v) >> 3) : Cd;
+#pragma unroll
+        for (int s = 1; s < W; s <<= 1) { const uint32_t o = __shfl_xor(cand, s, 64); cand = o < cand ? o : cand; }
+        first = cand;
+    }
+    if (first == Cd) {                                     // the last Cd % 4 bytes
+        uint32_t cand = Cd;
+        for (uint32_t k = 4 * nd + w; k < Cd; k += W) if (row[k]) { cand = k; break; }
+#pragma unroll
+        for (int s = 1; s < W; s <<= 1) { const uint32_t o = __shfl_xor(cand, s, 64); cand = o < cand ? o : cand; }
+        first = cand;
+    }
     uint32_t L;
     const bool ok = row_length(row, Cd, first, bd, dmax, L);
     if (w == 0) {
@@ -561,10 +597,10 @@ size_t plan_tile(TileGeom& tg, uint64_t avg, const EmitGeom& g, bool packed) {
     const uint32_t ncols = g.ncols;
     tg.magicP = g.prefix_len ? magic_u32(g.prefix_len) : 0;
     const uint64_t text = avg + avg / 8 + 1;
-    const uint64_t per = text + 8 + 4 + 2ull * ncols + (packed ? tg.Cd + tg.Cq : 0);
+    const uint64_t per = text + 8 + 4 + 4 + 2ull * ncols + (packed ? tg.Cd + tg.Cq : 0);
     uint64_t R = ((packed ? EM_BUDGET_PACKED : EM_BUDGET_TEXT) - 256) / per;
     if (R > EM_RMAX) R = EM_RMAX;
-    if (packed) while (R > 0 && (R * tg.Cd + 48 > DE_NV * EM_THREADS * 16u || R * tg.Cq + 48 > DE_NV * EM_THREADS * 16u)) --R;
+    if (packed) while (R > 0 && (R * tg.Cd + 48 > DE_NVD * EM_THREADS * 16u || R * tg.Cq + 48 > DE_NVQ * EM_THREADS * 16u)) --R;
     const bool fits = R >= 1;
     if (!fits) R = 1;
     tg.R = (uint32_t)R;
@@ -572,7 +608,7 @@ size_t plan_tile(TileGeom& tg, uint64_t avg, const EmitGeom& g, bool packed) {
     tg.cap = fits ? (uint32_t)(R * text + 64) & ~15u : 0u;
     uint32_t off = fits ? tg.cap + 32 : 32;
     auto carve = [&](uint32_t bytes) { uint32_t o = off; off += (bytes + 15) & ~15u; return o; };
-    tg.o_off = carve((tg.R + 1) * 8); tg.o_len = carve(tg.R * 4);
+    tg.o_off = carve((tg.R + 1) * 8); tg.o_len = carve(tg.R * 4); tg.o_cum = carve((tg.R + 2) * 4);
     tg.o_flen = carve(tg.R * (ncols ? ncols : 1) * 2);
     tg.o_ind = tg.o_inq = 0;
     if (packed && fits) { tg.o_ind = carve(tg.R * tg.Cd + 32); tg.o_inq = carve(tg.R * tg.Cq + 32); }
@@ -627,6 +663,7 @@ extern "C" int uq_decode_fastq(uq_ctx* ctx, const uq_emit_params* hp, const uq_u
     UQ_REQUIRE(tg.Cd == (tg.bd * Lv + 7) / 8 && tg.Cq == (tg.bq * Lv + 7) / 8, "uq_decode_fastq: row bytes do not match the geometry");
     tg.G = (up->dna_max + 7) / 8;
     tg.magicG = magic_u32(tg.G);
+    tg.variable = variable; tg.Gf = up->dna_max / 8; tg.magicGf = tg.Gf ? magic_u32(tg.Gf) : 0;
     tg.fa = fast_alphabet(up);
     if (nreads == 0) return 0;
     UQ_REQUIRE(d_dna && d_qual && (d_len || !variable), "uq_decode_fastq: null buffer");
@@ -635,7 +672,7 @@ extern "C" int uq_decode_fastq(uq_ctx* ctx, const uq_emit_params* hp, const uq_u
         UQ_CHECK_HIP(hipMemsetAsync(d_bad, 0xFF, 8, ctx->stream));
         if (variable) {
             if (tg.Cd > 512) row_lengths_kernel<64><<<(uint32_t)((nreads + 3) / 4), 256, 0, ctx->stream>>>(d_dna, nreads, tg.Cd, tg.bd, up->dna_max, d_len, (unsigned long long*)d_bad);
-            else row_lengths_kernel<1><<<(uint32_t)((nreads + 255) / 256), 256, 0, ctx->stream>>>(d_dna, nreads, tg.Cd, tg.bd, up->dna_max, d_len, (unsigned long long*)d_bad);
+            else row_lengths_kernel<8><<<(uint32_t)((nreads + 31) / 32), 256, 0, ctx->stream>>>(d_dna, nreads, tg.Cd, tg.bd, up->dna_max, d_len, (unsigned long long*)d_bad);
             UQ_LAUNCH_CHECK();
         }
         UQ_TRY(emit_offsets(ctx, g, lens, nreads, d_offsets, h_total, d_bad, h_bad));
