@@ -101,3 +101,37 @@ def _check(tmp_path, world, flags, backend='gloo', fq=None):
         assert json.loads(json.dumps(cfg[k])) == json.loads(json.dumps(ocfg[k])), k
     new_n_code = ocfg['N_qual'] and max(ocfg['N_qual'].values()) >= len(ocfg['qualities'])      # Q9: not decodable by the reference either
     assert of['sort'] is not None or new_n_code or O.decode(cfg, members) == fq.decode('latin-1')
+
+
+DECODE_CASES = [
+    (2, []),                                                             # keys + unique tables: key slices, whole tables
+    (3, ['--sort', 'QUAL', '--raw', 'DNA', 'QUAL', 'QNAME']),            # raw row slices read straight from the file
+    (2, ['--sort', 'DNA', '--pattern', '2.2', '1.2']),                   # column-major payloads: loaded whole, sliced after
+    (3, ['--raw', 'DNA', 'QNAME', '--pattern', '3.1', '0.2', '--notricks']),
+    (5, ['--sort', 'QNAME']),
+]
+
+
+@pytest.mark.parametrize('world,flags', DECODE_CASES, ids=lambda v: str(v).replace(' ', ''))
+def test_sharded_decode_equals_oracle_decode(tmp_path, world, flags):
+    """`--decode` over several ranks: the file the ranks write together is the oracle's decode of the same container
+    (and, unsorted, the input)."""
+    fq = synth.fastq(20261003 + 41, 2500, (30, 61), n_rate=2, dup='both', dup_templates=40)
+    inp = tmp_path / 'in.fastq'; inp.write_bytes(fq)
+    enc = tmp_path / 'out.uQ'
+    _run_sharded(1, inp, enc, flags)                                    # written by the same program on one rank
+    cfg, members = O.read_tar(str(enc))
+    out = tmp_path / 'back.fastq'
+    _run_sharded(world, enc, out, ['--decode'])
+    assert out.read_bytes().decode('latin-1') == O.decode(cfg, members)
+    if '--sort' not in flags: assert out.read_bytes() == fq
+
+
+def test_sharded_decode_with_idle_ranks(tmp_path):
+    fq = b'@a:1:7\nACGTN\n+\nIHIH#\n@a:2:9\nACGTA\n+\nHIHII\n'
+    inp = tmp_path / 'in.fastq'; inp.write_bytes(fq)
+    enc = tmp_path / 'out.uQ'
+    _run_sharded(1, inp, enc, ['--raw', 'DNA', 'QUAL', 'QNAME'])
+    out = tmp_path / 'back.fastq'
+    _run_sharded(3, enc, out, ['--decode'])
+    assert out.read_bytes() == fq

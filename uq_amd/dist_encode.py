@@ -2,6 +2,7 @@
 one `.uQ` file together (BASELINE configs[3] is this with `--sort QUAL --raw DNA QUAL QNAME`).
 
     python -m torch.distributed.run --nproc-per-node N -m uq_amd.dist_encode -i reads.fastq [uq flags]
+    python -m torch.distributed.run --nproc-per-node N -m uq_amd.dist_encode --decode -i reads.uQ -o reads.fastq
 
 The result is byte-for-byte the file the single-GPU CLI writes (members and config; tar mtimes aside):
   load      each rank streams its byte range of the file (+ slack) to HBM; an all-gather of the number of line
@@ -294,6 +295,50 @@ class ShardedSession(Session):
             os.replace(tmp, path)
 
 
+    # ------------------------------------------------------------------ decode
+    def decode_sharded(self, out_path):
+        """uq.py:926-1058 over the ranks: rank r decodes reads [n r / W, n (r + 1) / W) of the stored order -- key slices
+        and raw row slices come from the file, the tables the keys index are loaded by every rank -- and writes its
+        text in place; the offsets are an all-gather of the text sizes.  The result is the single-GPU decoder's output."""
+        members, config = self.open_container()
+        if not self.device_text_possible(config):
+            error('ERROR: this QNAME layout decodes on one GPU only (python -m uq_amd.uq --decode)')
+        if 'DNA.raw' in members: n = self.member_rows(members, 'DNA.raw', (config['pattern'] or ['0.1', '0.1'])[0])
+        else: n = self.member_rows(members, 'DNA.key')
+        lo, hi = n * self.rank // self.world, n * (self.rank + 1) // self.world
+        DNA, QUAL, d_cols = self.load_tables(members, config, rows=(lo, hi))
+        text = self.decode_text(config, DNA, QUAL, d_cols) if hi > lo else self.ctx.torch.empty(0, dtype=self.ctx.torch.uint8, device=self.ctx.device)
+        shard = uqdist.Shard(self.be, lo, n, self.group)
+        sizes = shard.gather_ints(int(text.numel()))
+        offset, total = sum(sizes[:self.rank]), sum(sizes)
+        tmp = out_path + '.part'
+        if self.rank == 0:
+            fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+            os.ftruncate(fd, total)
+        shard.reduce([0], 'sum')                                   # barrier: the file exists at its final size
+        if self.rank != 0:
+            fd = os.open(tmp, os.O_WRONLY)
+        try:
+            if text.numel(): self.io.device_to_fd(text, fd, offset)
+        finally:
+            os.close(fd)
+        shard.reduce([0], 'sum')                                   # barrier: all pieces are in place
+        if self.rank == 0:
+            os.replace(tmp, out_path)
+
+    def member_rows(self, members, name, pattern='0.1'):
+        """Rows of a 2-D member / elements of a 1-D one, from its .npy header."""
+        import io as _io
+        offset, size = members[name]
+        with open(self.tar_path, 'rb') as fh:
+            fh.seek(offset)
+            f = _io.BytesIO(fh.read(min(size, 65536)))
+        version = np.lib.format.read_magic(f)
+        shape, _, _ = np.lib.format.read_array_header_1_0(f) if version == (1, 0) else np.lib.format.read_array_header_2_0(f)
+        if len(shape) == 1: return int(shape[0])
+        return int(shape[0] if int(pattern[0]) % 2 == 0 else shape[1])
+
+
 def main(argv=None):
     import torch
     import torch.distributed as dist
@@ -312,8 +357,11 @@ def main(argv=None):
     try:
         args.device = device
         validate_args(args)
-        if args.decode: error('ERROR: decode runs on one GPU (python -m uq_amd.uq --decode)')
-        ShardedSession(args).encode()
+        if args.decode:
+            if not args.output: error('ERROR: the sharded decoder writes a file: give it -o reads.fastq')
+            ShardedSession(args).decode_sharded(args.output)
+        else:
+            ShardedSession(args).encode()
     except UqError as e:
         if rank == 0: print(e)
         code = 1

@@ -545,10 +545,12 @@ class Session:
         self.say('All Done! :) ')
 
     # ------------------------------------------------------------------ decode (uq.py:926-1058)
-    def load_from_tar(self, members, file_name, pattern='0.1'):
+    def load_from_tar(self, members, file_name, pattern='0.1', rows=None):
         """uq.py:943-945 on the device: payload -> table.  `members`: name -> (offset, size) inside the tar
         `self.tar_path`; the payload streams file -> pinned -> HBM.  Returns (device tensor, rows, cols) for
-        2-D members; for 1-D ones a device tensor typed by width (its bytes are the member's dtype)."""
+        2-D members; for 1-D ones a device tensor typed by width (its bytes are the member's dtype).
+        `rows` = (lo, hi): only that range of rows / elements (the sharded decoder; a row-major payload is read
+        as a slice of the file, any other layout whole)."""
         offset, size = members[file_name]
         with open(self.tar_path, 'rb') as fh:
             fh.seek(offset)
@@ -556,15 +558,24 @@ class Session:
         version = np.lib.format.read_magic(f)
         shape, fortran, dtype = np.lib.format.read_array_header_1_0(f) if version == (1, 0) else np.lib.format.read_array_header_2_0(f)
         hdr = f.tell()
-        d_pay = self.io.file_to_device(self.tar_path, offset + hdr, size - hdr)
         if len(shape) == 1:
             tt = self.ctx.torch
-            return d_pay.view({1: tt.uint8, 2: tt.int16, 4: tt.int32, 8: tt.int64}[np.dtype(dtype).itemsize])
+            isz = np.dtype(dtype).itemsize
+            lo, hi = rows if rows is not None else (0, shape[0])
+            d_pay = self.io.file_to_device(self.tar_path, offset + hdr + lo * isz, (hi - lo) * isz)
+            return d_pay.view({1: tt.uint8, 2: tt.int16, 4: tt.int32, 8: tt.int64}[isz])
         k = int(pattern[0])
-        rows, cols = (shape if k % 2 == 0 else shape[::-1])
+        nrows, cols = (shape if k % 2 == 0 else shape[::-1])
+        if rows is not None and pattern == '0.1':
+            lo, hi = rows
+            return (self.io.file_to_device(self.tar_path, offset + hdr + lo * cols, (hi - lo) * cols), hi - lo, cols)
+        d_pay = self.io.file_to_device(self.tar_path, offset + hdr, size - hdr)
         # numpy flags 1-wide arrays as C order whatever the pattern asked for: the byte stream is the same
-        t = d_pay if pattern == '0.1' else self.ops.unpattern(self.ctx, d_pay, rows, cols, pattern)   # 0.1 is the table itself
-        return (t, rows, cols)
+        t = d_pay if pattern == '0.1' else self.ops.unpattern(self.ctx, d_pay, nrows, cols, pattern)   # 0.1 is the table itself
+        if rows is not None:
+            lo, hi = rows
+            return (t[lo * cols:hi * cols].contiguous(), hi - lo, cols)
+        return (t, nrows, cols)
 
     def split_bits(self, dna, qual, config):
         """uq.py:1002-1007 + 1031-1054 on the device: rows -> characters (fixed pitch) + lengths."""
@@ -575,10 +586,9 @@ class Session:
         if b is not None: error('ERROR: row %d of the DNA table carries no length sentinel; is this a uQ file?' % b)
         return seq, qt, ln
 
-    def decode(self, out=None):
-        from . import qname
-        args, ops, ctx = self.args, self.ops, self.ctx
-        out = out or sys.stdout
+    def open_container(self):
+        """Tar members (name -> (payload offset, size)) and config.json of args.input."""
+        args = self.args
         if not tarfile.is_tarfile(args.input):
             error('ERROR: Sorry, the path you have provided as input is a file, but not a tar file, and therefore cannot be a .uq file!')
         self.tar_path = args.input
@@ -586,14 +596,21 @@ class Session:
             members = {m.name: (m.offset_data, m.size) for m in t.getmembers()}
             if 'config.json' not in members: error('ERROR: No config.json file was found in your input path! I cannot decode data without it!')
             config = json.loads(t.extractfile('config.json').read().decode())
+        return members, config
+
+    def load_tables(self, members, config, rows=None):
+        """uq.py:943-973 on the device: the DNA / QUAL tables as (tensor, reads, row bytes) and the QNAME columns, in
+        stored read order; `rows` = (lo, hi) restricts all of them to that range of reads (keys are sliced, the
+        tables they index are loaded whole)."""
+        ops, ctx = self.ops, self.ctx
         pat = config['pattern'] or ['0.1', '0.1']
 
         def table(name, pattern):
-            if name + '.raw' in members: return self.load_from_tar(members, name + '.raw', pattern)
+            if name + '.raw' in members: return self.load_from_tar(members, name + '.raw', pattern, rows)
             if name in members and name + '.key' in members:
-                t, rows, cols = self.load_from_tar(members, name, pattern)
-                d_key = self.load_from_tar(members, name + '.key')
-                return (ops.gather_rows(ctx, t, rows, cols, d_key), d_key.numel(), cols)          # uq.py:953, 957
+                t, nrows, cols = self.load_from_tar(members, name, pattern)
+                d_key = self.load_from_tar(members, name + '.key', rows=rows)
+                return (ops.gather_rows(ctx, t, nrows, cols, d_key), d_key.numel(), cols)          # uq.py:953, 957
             error('ERROR: No ' + name + ' data was found in this uQ file?!')
 
         DNA = table('DNA', pat[0])
@@ -601,24 +618,41 @@ class Session:
         ncols = len(config['QNAME_columns'])
         u8 = ctx.torch.uint8
         if 'QNAME.key' in members:
-            d_key = self.load_from_tar(members, 'QNAME.key')
+            d_key = self.load_from_tar(members, 'QNAME.key', rows=rows)
             d_cols = []
             for i in range(ncols):                                                                # uq.py:973, numeric order (Q6)
                 c = self.load_from_tar(members, 'QNAME_%d' % (i + 1))
                 d_cols.append(ops.gather_rows(ctx, c.view(u8), c.numel(), c.element_size(), d_key).view(c.dtype))
         else:
-            d_cols = [self.load_from_tar(members, 'QNAME_%d.raw' % (i + 1)) for i in range(ncols)]
+            d_cols = [self.load_from_tar(members, 'QNAME_%d.raw' % (i + 1), rows=rows) for i in range(ncols)]
+        return DNA, QUAL, d_cols
+
+    @staticmethod
+    def device_text_possible(config):
+        return len(config['QNAME_columns']) <= 32 and len(config['QNAME_prefix']) <= 256 and len(config['QNAME_suffix']) <= 256
+
+    def decode_text(self, config, DNA, QUAL, d_cols):
+        """uq.py:1002-1058 on the device: the FASTQ text of these reads as one uint8 device tensor."""
+        ops, ctx, n = self.ops, self.ctx, DNA[1]
+        if getattr(self.args, 'two_pass_decode', False):
+            seq, qt, ln = self.split_bits(DNA, QUAL, config)
+            return ops.emit_fastq(ctx, config, d_cols, seq, qt, ln, n)
+        # rows -> text in one kernel (uq_decode_fastq)
+        text, bad = ops.decode_fastq(ctx, config, d_cols, DNA[0], QUAL[0], n)
+        if bad is not None: error('ERROR: row %d of the DNA table carries no length sentinel; is this a uQ file?' % bad)
+        return text
+
+    def decode(self, out=None):
+        from . import qname
+        ctx = self.ctx
+        out = out or sys.stdout
+        members, config = self.open_container()
+        DNA, QUAL, d_cols = self.load_tables(members, config)
         n = DNA[1]
         w = out.buffer if hasattr(out, 'buffer') else out
-        if len(config['QNAME_columns']) <= 32 and len(config['QNAME_prefix']) <= 256 and len(config['QNAME_suffix']) <= 256:
-            # rows -> text in one kernel (uq_decode_fastq); the text streams out through the pinned buffers
-            if getattr(args, 'two_pass_decode', False):
-                seq, qt, ln = self.split_bits(DNA, QUAL, config)
-                text = ops.emit_fastq(ctx, config, d_cols, seq, qt, ln, n)
-            else:
-                text, bad = ops.decode_fastq(ctx, config, d_cols, DNA[0], QUAL[0], n)
-                if bad is not None: error('ERROR: row %d of the DNA table carries no length sentinel; is this a uQ file?' % bad)
-            self.io.device_to_stream(text, w)
+        if self.device_text_possible(config):
+            # the text streams out through the pinned buffers
+            self.io.device_to_stream(self.decode_text(config, DNA, QUAL, d_cols), w)
         else:
             seq, qt, ln = self.split_bits(DNA, QUAL, config)
             dmax = config['dna_max']
