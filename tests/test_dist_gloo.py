@@ -1,6 +1,7 @@
 """CPU, world_size 2 and 3 over gloo: the multi-GPU exchange logic of uq_amd.dist (statistics all-reduce,
 sample-sort all-to-all, distributed gather).  The row operations are supplied by a numpy backend defined
 here (test infrastructure); on the GPU the same code runs with dist.HipRows."""
+import json
 import os
 import socket
 
@@ -202,3 +203,35 @@ def test_shard_ranges_cover():
         for world in (1, 2, 3, 8):
             r = [uqdist.shard_range(total, k, world) for k in range(world)]
             assert r[0][0] == 0 and r[-1][1] == total and all(a[1] == b[0] for a, b in zip(r[:-1], r[1:]))
+
+
+def _decode_job(rank, world, enc, out):
+    import fake_decode_ops as F
+    from uq_amd import dist_encode, uq
+    args = uq.validate_args(uq.build_parser().parse_args(['-i', enc, '-o', out, '--decode', '--quiet']))
+    s = dist_encode.ShardedSession(args, ctx=F.FakeCtx())
+    s.io, s.ops = F.FakeIO(), F.FakeOps()
+    s.decode_sharded(out)
+    return True
+
+
+@pytest.mark.parametrize('world,flags', [(2, {}), (3, dict(sort='QUAL', raw=['DNA', 'QNAME'], pattern=['2.2', '1.2'])),
+                                         (2, dict(raw=['DNA', 'QUAL', 'QNAME'])), (4, dict(sort='DNA', pattern=['0.2', '3.1']))],
+                         ids=['keyed', 'sorted-mixed-patterns', 'raw', 'sorted-keyed'])
+def test_sharded_decoder_ranges_and_offsets(tmp_path, world, flags):
+    """uq_amd.dist_encode.decode_sharded with the device layer replaced by numpy / the oracle: every rank reads its
+    slices of an oracle-written container, and the file the ranks write together is the oracle's decode."""
+    import functools
+    import io as _io
+    import tarfile
+    import uq_oracle as O
+    from uq_amd import synth
+    fq = synth.fastq(20261003 + 42, 700, (20, 45), n_rate=2, dup='both', dup_templates=25)
+    cfg, members, _ = O.encode(fq, **flags)
+    enc = str(tmp_path / 'x.uQ')
+    with tarfile.open(enc, 'w') as t:
+        for name, data in [('config.json', json.dumps(cfg).encode())] + sorted(members.items()):
+            ti = tarfile.TarInfo(name); ti.size = len(data); t.addfile(ti, _io.BytesIO(data))
+    out = str(tmp_path / 'back.fastq')
+    assert all(_run(world, functools.partial(_decode_job, enc=enc, out=out)))
+    assert open(out, 'rb').read().decode('latin-1') == O.decode(cfg, members)
