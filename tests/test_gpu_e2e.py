@@ -318,3 +318,23 @@ def test_cli_long_reads(ctx, tmp_path, flags):
     text = _run_decode(ctx, path)
     assert text.decode('latin-1') == O.decode(ocfg, omembers)
     if '--sort' not in flags: assert text == fq
+
+
+def test_decode_many_qname_columns(ctx, tmp_path):
+    """Twelve QNAME fields: a tile holds more (record, field) items than the workgroup has lanes, so the emit / decode
+    kernels take their looped field passes; mixed widths, a mapping column and negative numbers included."""
+    import random
+    rnd = random.Random(5)
+    recs = []
+    for i in range(2500):
+        L = rnd.randint(20, 90)
+        seq = ''.join(rnd.choice('ACGTN') for _ in range(L)); q = ''.join(rnd.choice('#+5AFI') for _ in range(L))
+        f = [i, rnd.randint(0, 9), rnd.randint(-5, 5), 70000 + rnd.randint(0, 10 ** 6), rnd.choice(['x', 'yy', 'zzz']), rnd.randint(0, 255),
+             rnd.randint(0, 65535), 2 ** 33 + rnd.randint(0, 1000), i % 3, rnd.randint(100, 999), i * 7, rnd.randint(0, 1)]
+        recs.append('@m%d:%d_%d %d/%s;%d,%d:%d:%d:%d:%d:%d#z\n%s\n+\n%s\n' % (*f, seq, q))
+    fq = ''.join(recs).encode()
+    for flags in (['--raw', 'DNA', 'QUAL', 'QNAME'], []):
+        cfg, members, names, path = _run_encode(ctx, tmp_path, fq, flags)
+        assert len(cfg['QNAME_columns']) >= 10
+        assert sorted(_records(_run_decode(ctx, path))) == sorted(_records(fq))
+        if flags: assert _run_decode(ctx, path) == fq
