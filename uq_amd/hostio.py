@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 
 CHUNK = int(os.environ.get('UQ_IO_CHUNK_MB', '32')) << 20
-NBUF = int(os.environ.get('UQ_IO_NBUF', '4'))
+NBUF = int(os.environ.get('UQ_IO_NBUF', '8'))
 
 
 class Staging:
