@@ -272,7 +272,7 @@ __global__ __launch_bounds__(EM_THREADS, 4) void emit_tile_kernel(EmitGeom g, Ti
                 uint32_t v = tid < Rt ? cur.L >> 3 : 0u;
 #pragma unroll
                 for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(v, d, 64); if (lane >= (uint32_t)d) v += o; }
-                cum[tid + 1] = v;
+                if (tid < R) cum[tid + 1] = v;            // R + 1 entries: lanes beyond the tile have nowhere to write
                 if (tid == 0) cum[0] = 0;
             }
             skd = nr.skd; skq = nr.skq;

@@ -114,6 +114,7 @@ __global__ __launch_bounds__(ST_THREADS) void stats_kernel(const uint8_t* __rest
     const uint32_t hw = (tid >> 6) * 2 + (lane >> 5);       // half-wave index inside the workgroup, 0..7
     constexpr uint32_t NHW = 2 * (ST_THREADS / 64);
     Acc acc;
+    uint32_t fill_fast = 0, fill_hist = 0;      // pairs (window base + 1, quality slot 0) counted for bytes beyond a read's end
     const uint64_t ntiles = (n + R - 1) / R;
     const uint32_t rr = tid / P, pp = tid - rr * P;   // this lane counts groups pp, pp + P, ... of read rr of every tile
     const uint32_t q_addlo = 0x01010101u * (0x80u - qbase), q_addhi = 0x01010101u * (0x80u - qbase - ST_NQ);
@@ -184,6 +185,18 @@ __global__ __launch_bounds__(ST_THREADS) void stats_kernel(const uint8_t* __rest
                     lds_window8(stage, (int32_t)(s + j), b_lo, b_hi);
                     lds_window8(stage, (int32_t)(q + j), q_lo, q_hi);
                     const uint32_t cnt = Lc - j;
+                    // The read's last group holds cnt < 8 pairs.  One lane in ceil(L / 8) holds it, i.e. every wave: sent down
+                    // the per-byte path it made every wave run both forms.  Instead its missing bytes become (window base + 1,
+                    // quality slot 0) -- in range, so the group takes the same tier as its neighbours -- and the
+                    // pairs counted too many are taken off that one bin when the tables are flushed (fill_fast / fill_hist).
+                    const uint32_t nb = cnt < 8 ? cnt : 8u;
+                    {
+                        const uint32_t nlo = nb < 4 ? nb : 4u, nhi = nb - nlo;
+                        const uint32_t keep_lo = nlo == 4 ? 0xFFFFFFFFu : (1u << (8 * nlo)) - 1u, keep_hi = nhi == 4 ? 0xFFFFFFFFu : (1u << (8 * nhi)) - 1u;
+                        const uint32_t bfill = 0x01010101u * (bbase + 1), qfill = 0x01010101u * qbase;
+                        b_lo = bfi(keep_lo, b_lo, bfill); b_hi = bfi(keep_hi, b_hi, bfill);
+                        q_lo = bfi(keep_lo, q_lo, qfill); q_hi = bfi(keep_hi, q_hi, qfill);
+                    }
                     // byte - window base, valid when the top bits vanish: bases bbase..bbase+31, qualities qbase..qbase+63
                     const uint32_t sb0 = b_lo ^ b_xor, sb1 = b_hi ^ b_xor;
                     const uint32_t u0 = q_lo + q_addlo, u1 = q_hi + q_addlo;
@@ -195,7 +208,7 @@ __global__ __launch_bounds__(ST_THREADS) void stats_kernel(const uint8_t* __rest
                     // <= 2-way, which ds_add_u32 absorbs at no cost; the single-copy table is ~3.5-way on random data)
                     const uint32_t c0 = (b_lo >> 1) & 0x03030303u, c1 = (b_hi >> 1) & 0x03030303u;
                     const bool acgt = __builtin_amdgcn_perm(0u, 0x47544341u, c0) == b_lo && __builtin_amdgcn_perm(0u, 0x47544341u, c1) == b_hi;
-                    if (cnt >= 8 && bad == 0 && acgt) {
+                    if (bad == 0 && acgt) {
                         const uint32_t bin0 = (c0 << 6) | (u0 & 0x7F7F7F7Fu), bin1 = (c1 << 6) | (u1 & 0x7F7F7F7Fu);
                         uint8_t* hb = (uint8_t*)fast + ((lane & (ST_COPIES - 1)) << 2);
 #pragma unroll
@@ -203,7 +216,8 @@ __global__ __launch_bounds__(ST_THREADS) void stats_kernel(const uint8_t* __rest
                             atomicAdd((uint32_t*)(hb + (((bin0 >> (8 * k)) & 0xFFu) << 5)), 1u);
                             atomicAdd((uint32_t*)(hb + (((bin1 >> (8 * k)) & 0xFFu) << 5)), 1u);
                         }
-                    } else if (cnt >= 8 && bad == 0) {
+                        fill_fast += 8u - nb;
+                    } else if (bad == 0) {
                         const uint32_t sq0 = (u0 & 0x7F7F7F7Fu) << 2, sq1 = (u1 & 0x7F7F7F7Fu) << 2;   // quality slot * 4 per byte
                         uint8_t* hb = (uint8_t*)hist;
 #pragma unroll
@@ -211,6 +225,7 @@ __global__ __launch_bounds__(ST_THREADS) void stats_kernel(const uint8_t* __rest
                             atomicAdd((uint32_t*)(hb + ((((sb0 >> (8 * k)) & 0xFFu) << 8) | ((sq0 >> (8 * k)) & 0xFFu))), 1u);
                             atomicAdd((uint32_t*)(hb + ((((sb1 >> (8 * k)) & 0xFFu) << 8) | ((sq1 >> (8 * k)) & 0xFFu))), 1u);
                         }
+                        fill_hist += 8u - nb;
                     } else {
                         count_quad(b_lo, q_lo, cnt, win, hist, st);
                         if (cnt > 4) count_quad(b_hi, q_hi, cnt - 4, win, hist, st);
@@ -235,6 +250,8 @@ __global__ __launch_bounds__(ST_THREADS) void stats_kernel(const uint8_t* __rest
         }
         __syncthreads();
     }
+    if (fill_fast) atomicSub(&fast[lane & (ST_COPIES - 1)], fill_fast);          // bin 0 = ('A', slot 0); any copy: the flush sums them mod 2^32
+    if (fill_hist) atomicSub(&hist[1 * ST_NQ], fill_hist);                                                               // base bbase + 1, slot 0
     __syncthreads();
     for (int i = threadIdx.x; i < (int)(ST_NB * ST_NQ); i += ST_THREADS) {
         const uint32_t v = hist[i];
