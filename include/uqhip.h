@@ -42,6 +42,9 @@ int uq_dev_alloc(uq_ctx* ctx, size_t bytes, void** d_out);
 int uq_dev_free(uq_ctx* ctx, void* d_ptr);
 int uq_h2d(uq_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
 int uq_d2h(uq_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
+/* Test aid: overwrite the LDS of every CU with `pattern`-derived words (LDS survives between launches, which hides
+ * reads of LDS a kernel never wrote).  No effect on results. */
+int uq_debug_scribble_lds(uq_ctx* ctx, uint32_t pattern);
 int uq_memset(uq_ctx* ctx, void* d_dst, int value, size_t bytes);
 /* Device-side timing on the context's stream (hipEvents), for bench.py's roofline leg. */
 int uq_timer_start(uq_ctx* ctx);

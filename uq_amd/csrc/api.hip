@@ -111,6 +111,23 @@ extern "C" int uq_d2h(uq_ctx* c, void* h_dst, const void* d_src, size_t bytes) {
     return 0;
 }
 
+// Test aid: LDS keeps its contents between launches, so a kernel that reads LDS it never wrote usually sees the (correct)
+// bytes its previous launch left there.  This fills every CU's LDS with `pattern` so that such a read shows in the result.
+__global__ __launch_bounds__(256) void scribble_lds_kernel(uint32_t pattern, uint32_t words, uint32_t* sink) {
+    extern __shared__ uint32_t lds[];
+    for (uint32_t i = threadIdx.x; i < words; i += 256) lds[i] = pattern ^ i;
+    __syncthreads();
+    if (lds[(threadIdx.x * 61u) % words] == 0x12345678u && sink) *sink = 1;     // keeps the stores alive
+}
+
+extern "C" int uq_debug_scribble_lds(uq_ctx* c, uint32_t pattern) {
+    UQ_REQUIRE(c, "null context");
+    const uint32_t bytes = 40u * 1024u;                 // four resident workgroups cover a CU's 160 KiB
+    scribble_lds_kernel<<<UQ_NUM_CU * 16, 256, bytes, c->stream>>>(pattern, bytes / 4, nullptr);
+    UQ_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int uq_memset(uq_ctx* c, void* d_dst, int value, size_t bytes) {
     UQ_REQUIRE(c, "null context");
     if (!bytes) return 0;

@@ -141,6 +141,11 @@ def same_pack_params(a, b):
     return bytes(a.dna_code) == bytes(b.dna_code) and bytes(a.qual_code) == bytes(b.qual_code) and bytes(a.n_qual) == bytes(b.n_qual)
 
 
+def scribble_lds(ctx, pattern=0xA5A5A5A5):
+    """Test aid (uq_debug_scribble_lds): overwrite every CU's LDS so that reads of never-written LDS show."""
+    call('uq_debug_scribble_lds', ctx.h, pattern & 0xFFFFFFFF)
+
+
 def bad_index(bad_tensor):
     v = int(bad_tensor.cpu().numpy().view(np.uint64)[0])
     return None if v == UQ_NONE else v
