@@ -302,11 +302,7 @@ __global__ __launch_bounds__(EM_THREADS, 4) void emit_tile_kernel(EmitGeom g, Ti
         const uint64_t o0 = s_off[0], o1 = s_off[Rt];
         const uint32_t skew = (uint32_t)((uintptr_t)(out + o0) & 15);
         const uint64_t span = o1 - o0;
-        if (span + skew > cap) {                          // does not fit: wave per record, straight to HBM
-            for (uint32_t i = tid >> 6; i < Rt; i += EM_THREADS / 64) {
-                if constexpr (PACKED) decode_record_direct(g, tg, l_base, l_qual, l_qn, seq, qual, s_len[i], offsets, out, r0 + i, lane);
-                else emit_record_direct(g, seq, qual, len, offsets, out, r0 + i, lane);
-            }
+        if (span + skew > cap) {                          // does not fit the image: direct_tiles_kernel writes this tile
             __syncthreads();
             continue;
         }
@@ -526,6 +522,33 @@ __global__ __launch_bounds__(EM_THREADS, 4) void emit_tile_kernel(EmitGeom g, Ti
     }
 }
 
+// The tiles emit_tile_kernel skips (their text does not fit the LDS image: reads of tens of kbp, or a tile far above the
+// average the image was sized for): a wave per record, straight to HBM.  A separate kernel so that this cold code does
+// not weigh on the tile kernel's registers; on ordinary inputs it reads two offsets per tile and writes nothing.
+template <bool PACKED>
+__global__ __launch_bounds__(EM_THREADS) void direct_tiles_kernel(EmitGeom g, TileGeom tg, std::conditional_t<PACKED, UnpackLut, NoLut> lut,
+                                                                  const uint8_t* __restrict__ seq, const uint8_t* __restrict__ qual,
+                                                                  const uint32_t* __restrict__ len, uint64_t n, const uint64_t* __restrict__ offsets,
+                                                                  uint8_t* __restrict__ out) {
+    __shared__ uint8_t l_tab[PACKED ? 768 : 4];
+    const uint8_t* l_base = l_tab; const uint8_t* l_qual = l_tab + 256; const uint8_t* l_qn = l_tab + 512;
+    const uint32_t tid = threadIdx.x, lane = lane_id();
+    if constexpr (PACKED) { l_tab[tid] = lut.base_char[tid]; l_tab[256 + tid] = lut.qual_char[tid]; l_tab[512 + tid] = lut.qual_n_base[tid]; }
+    __syncthreads();
+    const uint64_t R = tg.R, ntiles = (n + R - 1) / R;
+    for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const uint64_t r0 = t * R;
+        const uint32_t Rt = (uint32_t)((n - r0) < R ? (n - r0) : R);
+        const uint64_t o0 = offsets[r0], o1 = offsets[r0 + Rt];
+        const uint32_t skew = (uint32_t)((uintptr_t)(out + o0) & 15);
+        if (o1 - o0 + skew <= tg.cap) continue;            // emit_tile_kernel's condition, negated
+        for (uint32_t i = tid >> 6; i < Rt; i += EM_THREADS / 64) {
+            if constexpr (PACKED) decode_record_direct(g, tg, l_base, l_qual, l_qn, seq, qual, len ? len[r0 + i] : g.dna_max, offsets, out, r0 + i, lane);
+            else emit_record_direct(g, seq, qual, len, offsets, out, r0 + i, lane);
+        }
+    }
+}
+
 // read lengths of variable-length DNA rows (the sentinel's position).  W lanes scan one row a dword each per step
 // (unaligned loads: rows start anywhere), the first non-zero byte is the minimum over the group.
 template <int W>
@@ -615,12 +638,13 @@ size_t plan_tile(TileGeom& tg, uint64_t avg, const EmitGeom& g, bool packed) {
     return off;
 }
 
-uint32_t tile_blocks(uint64_t tiles, size_t lds) {
+uint32_t tile_blocks(uint64_t tiles, size_t lds, uint64_t by_registers) {
     uint64_t per_cu = (160u * 1024u) / (lds + 3072);       // + the static tables
-    if (per_cu > 4) per_cu = 4;                            // what the kernel's registers allow
+    if (per_cu > by_registers) per_cu = by_registers;      // workgroups per CU the kernel's registers allow
     if (per_cu < 1) per_cu = 1;
     return (uint32_t)(tiles < UQ_NUM_CU * per_cu ? tiles : UQ_NUM_CU * per_cu);
 }
+uint32_t direct_blocks(uint64_t tiles) { return (uint32_t)(tiles < UQ_NUM_CU * 8ull ? tiles : UQ_NUM_CU * 8ull); }
 }  // namespace
 
 extern "C" int uq_emit_fastq(uq_ctx* ctx, const uq_emit_params* hp, const void* const* h_d_cols, const uint8_t* const* h_d_map_chars,
@@ -640,7 +664,9 @@ extern "C" int uq_emit_fastq(uq_ctx* ctx, const uq_emit_params* hp, const void* 
     memset(&tg, 0, sizeof(tg));
     const size_t lds = plan_tile(tg, *h_total / nreads + 1, g, false);
     const uint64_t tiles = (nreads + tg.R - 1) / tg.R;
-    emit_tile_kernel<false><<<tile_blocks(tiles, lds), EM_THREADS, lds, ctx->stream>>>(g, tg, NoLut{}, d_seq, d_qual, d_len, nreads, d_offsets, d_out);
+    emit_tile_kernel<false><<<tile_blocks(tiles, lds, 5), EM_THREADS, lds, ctx->stream>>>(g, tg, NoLut{}, d_seq, d_qual, d_len, nreads, d_offsets, d_out);
+    UQ_LAUNCH_CHECK();
+    direct_tiles_kernel<false><<<direct_blocks(tiles), EM_THREADS, 0, ctx->stream>>>(g, tg, NoLut{}, d_seq, d_qual, d_len, nreads, d_offsets, d_out);
     UQ_LAUNCH_CHECK();
     return 0;
 }
@@ -688,7 +714,9 @@ extern "C" int uq_decode_fastq(uq_ctx* ctx, const uq_emit_params* hp, const uq_u
     memcpy(lut.base_char, up->base_char, 256); memcpy(lut.qual_char, up->qual_char, 256); memcpy(lut.qual_n_base, up->qual_n_base, 256);
     const size_t lds = plan_tile(tg, *h_total / nreads + 1, g, true);
     const uint64_t tiles = (nreads + tg.R - 1) / tg.R;
-    emit_tile_kernel<true><<<tile_blocks(tiles, lds), EM_THREADS, lds, ctx->stream>>>(g, tg, lut, d_dna, d_qual, lens, nreads, d_offsets, d_out);
+    emit_tile_kernel<true><<<tile_blocks(tiles, lds, 4), EM_THREADS, lds, ctx->stream>>>(g, tg, lut, d_dna, d_qual, lens, nreads, d_offsets, d_out);
+    UQ_LAUNCH_CHECK();
+    direct_tiles_kernel<true><<<direct_blocks(tiles), EM_THREADS, 0, ctx->stream>>>(g, tg, lut, d_dna, d_qual, lens, nreads, d_offsets, d_out);
     UQ_LAUNCH_CHECK();
     return 0;
 }
