@@ -147,11 +147,16 @@ __device__ __forceinline__ uint32_t load_u32_any(const uint8_t* p) { uint32_t v;
 // byte k of the result = bits (7 - 2k .. 6 - 2k) of x: the four 2-bit base codes of one row byte, in text order
 __device__ __forceinline__ uint32_t spread2(uint32_t x) { return ((x >> 6) | (x << 4) | (x << 14) | (x << 24)) & 0x03030303u; }
 // the BQ row bytes at p hold eight BQ-bit quality codes, first character in the top bits: qlo = characters 0..3, qhi = 4..7, one per byte
+// (x, y) = the eight bytes at p as two little-endian dwords, fetched as the three ALIGNED dwords around them: half the LDS
+// instructions of BQ byte reads, and no 64-bit shifting to put the bytes together
 template <int BQ>
 __device__ __forceinline__ void qual8(const uint8_t* p, uint32_t& qlo, uint32_t& qhi) {
-    uint64_t V = 0;
-#pragma unroll
-    for (int i = 0; i < BQ; ++i) V = (V << 8) | p[i];
+    const uint32_t a = (uint32_t)(uintptr_t)p & 3u;
+    const uint32_t* q = (const uint32_t*)(p - a);
+    const uint32_t d0 = q[0], d1 = q[1], d2 = BQ + 3 > 8 ? q[2] : 0u;          // BQ <= 5: bytes a .. a + BQ - 1 end inside d1
+    const uint32_t x = __builtin_amdgcn_alignbyte(d1, d0, a), y = __builtin_amdgcn_alignbyte(d2, d1, a);
+    const uint64_t be = ((uint64_t)__builtin_bswap32(x) << 32) | __builtin_bswap32(y);   // the bytes as one big-endian number
+    const uint64_t V = be >> (64 - 8 * BQ);
     const uint32_t up = (uint32_t)(V >> (4 * BQ)), dn = (uint32_t)V & ((1u << (4 * BQ)) - 1u);       // 4 BQ <= 28 bits each
     constexpr uint32_t M = (1u << BQ) - 1u;
     qlo = ((up >> (3 * BQ)) & M) | (((up >> (2 * BQ)) & M) << 8) | (((up >> BQ) & M) << 16) | ((up & M) << 24);
