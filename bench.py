@@ -117,8 +117,16 @@ def main():
         os.dup2(2, 1)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        # UQ_DIST_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks share cards,
+        # the statistics exchange is staged through the host).  The driver's runs use nccl = RCCL, one rank per GPU.
+        backend = os.environ.get('UQ_DIST_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+            local_rank %= max(torch.cuda.device_count(), 1)
     ctx = Context(local_rank)
+    red_dev = ctx.device if not (use_dist and dist.get_backend() == 'gloo') else 'cpu'     # where the closing all-reduces live
 
     n = args.reads
     notricks = args.workload == 'cfg5-notricks'
@@ -195,10 +203,10 @@ def main():
     dt = time.perf_counter() - t0
     total_bytes, total_reads = fastq_bytes, None
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=ctx.device)
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        tot = torch.tensor([fastq_bytes, state['nreads']], dtype=torch.int64, device=ctx.device)   # shards differ by a few bytes
+        tot = torch.tensor([fastq_bytes, state['nreads']], dtype=torch.int64, device=red_dev)   # shards differ by a few bytes
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         total_bytes, total_reads = int(tot[0].item()), int(tot[1].item())
 

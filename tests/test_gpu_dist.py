@@ -135,3 +135,18 @@ def test_sharded_decode_with_idle_ranks(tmp_path):
     out = tmp_path / 'back.fastq'
     _run_sharded(3, enc, out, ['--decode'])
     assert out.read_bytes() == fq
+
+
+def test_bench_two_ranks_rehearsal():
+    """bench.py's N > 1 path (sharded synthetic input, all-reduced statistics, MAX-over-ranks timing, one JSON line from
+    rank 0) with two ranks sharing the card over gloo; the driver runs the same code over RCCL, one rank per GPU."""
+    env = dict(os.environ, UQ_DIST_BACKEND='gloo', PYTHONPATH=REPO)
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                          '--master-port', str(_free_port()), os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                          '--reads', '200000'], env=env, cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode(errors='replace')[-2000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r['n_gpus'] == 2 and r['scaling'] == 'weak' and r['value'] > 0 and r['config']['reads_per_gpu'] == 200000
+    assert r['roofline']['bound'] == 'hbm' and 'cpu_baseline' not in r          # the CPU baseline is timed at N = 1 only
