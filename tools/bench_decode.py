@@ -37,6 +37,7 @@ def main():
     ap.add_argument('--var-min', type=int, default=0, help='variable read lengths from this minimum (0 = fixed)')
     ap.add_argument('--n-rate', type=int, default=0)
     ap.add_argument('--reps', type=int, default=5)
+    ap.add_argument('--only-fused', action='store_true', help='time uq_decode_fastq only (clean kernel / counter profiles)')
     args = ap.parse_args()
     ctx = Context(0)
     n = args.reads
@@ -54,9 +55,10 @@ def main():
     def report(op, ms, nbytes, **kw):
         print(json.dumps(dict(op=op, reads=n, ms=round(ms, 3), algorithmic_GBps=round(nbytes / 1e9 / (ms / 1e3), 1), **kw)), flush=True)
 
-    ms, (seq, qt, ln, ubad) = timed(lambda: ops.unpack(ctx, dna, qual, n, up), args.reps)
-    report('unpack', ms, dna.numel() + qual.numel() + seq.numel() + qt.numel() + 4 * n, dna_max=d['dna_max'],
-           bits=[d['bits_per_base'], d['bits_per_quality']])
+    if not args.only_fused:
+        ms, (seq, qt, ln, ubad) = timed(lambda: ops.unpack(ctx, dna, qual, n, up), args.reps)
+        report('unpack', ms, dna.numel() + qual.numel() + seq.numel() + qt.numel() + 4 * n, dna_max=d['dna_max'],
+               bits=[d['bits_per_base'], d['bits_per_quality']])
     # QNAME columns the way the encoder stores them (device analysis: layout, typing, values)
     import time
     t0 = time.perf_counter()
@@ -65,17 +67,18 @@ def main():
     report('qname_analyse', (time.perf_counter() - t0) * 1e3, d_buf.numel(), columns=[c['format'] + ':' + c['dtype'] for c in columns])
     cols = [a if torch.is_tensor(a) else ctx.to_device(a) for a in arrays]
     config.update(QNAME_prefix=prefix, QNAME_suffix=suffix, QNAME_separators=separators, QNAME_columns=columns)
-    ms, text = timed(lambda: ops.emit_fastq(ctx, config, cols, seq, qt, ln, n), args.reps)
-    same = text.numel() == d_buf.numel() and bool(torch.equal(text, d_buf))
-    report('emit_fastq', ms, seq.numel() + qt.numel() + 4 * n + sum(c.numel() * c.element_size() for c in cols) + text.numel(), round_trip=same,
-           text_bytes=text.numel())
-    if not same and not os.environ.get('UQ_EM_SKIP'): sys.exit('decode bench: the emitted text differs from the input')
-    del text, seq, qt
-    torch.cuda.empty_cache()
+    if not args.only_fused:
+        ms, text = timed(lambda: ops.emit_fastq(ctx, config, cols, seq, qt, ln, n), args.reps)
+        same = text.numel() == d_buf.numel() and bool(torch.equal(text, d_buf))
+        report('emit_fastq', ms, seq.numel() + qt.numel() + 4 * n + sum(c.numel() * c.element_size() for c in cols) + text.numel(), round_trip=same,
+               text_bytes=text.numel())
+        if not same: sys.exit('decode bench: the emitted text differs from the input')
+        del text, seq, qt
+        torch.cuda.empty_cache()
     ms, (text, bad) = timed(lambda: ops.decode_fastq(ctx, config, cols, dna, qual, n), args.reps)
     same = bad is None and text.numel() == d_buf.numel() and bool(torch.equal(text, d_buf))
     report('decode_fastq', ms, dna.numel() + qual.numel() + sum(c.numel() * c.element_size() for c in cols) + text.numel(), round_trip=same)
-    if not same and not os.environ.get('UQ_EM_SKIP'): sys.exit('decode bench: the one-pass text differs from the input')
+    if not same: sys.exit('decode bench: the one-pass text differs from the input')
 
 
 if __name__ == '__main__':
