@@ -71,6 +71,31 @@ def test_index_edge_cases(ctx):
         assert np.array_equal(ctx.to_numpy(ls, np.uint64), oracle_c.index_lines(host))
 
 
+@pytest.mark.parametrize('misalign', [0, 5])
+def test_index_dense_newlines(ctx, misalign):
+    """The census keeps a tile's newlines in a list slot of 1024 entries; tiles with more (lines shorter than 16 bytes)
+    make the index fall back to the bitmap form.  Line lengths around that limit, tiles of nothing but newlines, and a
+    mix of dense and sparse tiles in one buffer."""
+    t = ctx.torch
+    rng = np.random.default_rng(7)
+    cases = [b'\n' * 70000, b'ab\n' * 40000, (b'x' * 15 + b'\n') * 5000, (b'x' * 14 + b'\n') * 5000, (b'x' * 16 + b'\n') * 5000,
+             (b'x' * 15 + b'\n') * 1024 + b'\n' + (b'y' * 15 + b'\n') * 3000,                      # exactly 1024, then 1025 in a tile
+             b'q' * 50000 + b'\n' * 3000 + b'r' * 40001 + b'\n',
+             b''.join(b'z' * int(k) + b'\n' for k in rng.integers(0, 40, 30000))]
+    for data in cases:
+        host = np.frombuffer(data, dtype=np.uint8)
+        backing = ctx.empty(host.size + 64)
+        d = backing[misalign:misalign + host.size]
+        d.copy_(t.from_numpy(host.copy()))
+        ref = oracle_c.index_lines(host)
+        nlines = ops.count_lines(ctx, d)
+        assert nlines == len(ref) - 1
+        assert np.array_equal(ctx.to_numpy(ops.index_lines(ctx, d, nlines), np.uint64), ref)
+        # and without the census of this buffer in the context (another buffer counted in between)
+        ops.count_lines(ctx, backing[:17])
+        assert np.array_equal(ctx.to_numpy(ops.index_lines(ctx, d, nlines), np.uint64), ref)
+
+
 @pytest.mark.parametrize('n,length,kw', [
     (2000, 100, {}), (3000, (36, 301), dict(n_rate=1)), (500, 50, dict(n_rate=3, n_qual_exclusive=False)),
     (1, 5, {}), (2, (1, 3), {}),

@@ -10,6 +10,12 @@
 // one u64 of bitmap (64 stream bytes), ranks its newlines with a block prefix sum and writes them.
 // HBM traffic: nbytes read + nbytes/8 written, then nbytes/8 read + 8 B per line written
 // (algorithmic: nbytes + 8 B/line).
+//
+// uq_count_lines runs the LIST form of the census instead: the tile's newlines are ranked in the census itself (two packed
+// wave scans) and their 14-bit in-tile offsets go, in stream order, to the tile's slot of IDX_LIST_CAP u16 entries; the
+// index pass then only expands the lists (2 B read + 8 B written per line).  The bitmap's 2 x nbytes/8 of traffic
+// becomes 2 x 2 B per line: 0.86 -> 0.7x ms for census + index at 10 M x 150 bp.  A tile with more newlines than its slot
+// holds (lines shorter than 16 bytes on average) raises a flag and uq_index_lines falls back to the bitmap form.
 #include "common.h"
 #include "swar.h"
 
@@ -19,6 +25,7 @@ constexpr int IDX_LOADS = 4;                                  // 16-byte loads p
 constexpr uint64_t IDX_WAVE_BYTES = 64 * 16 * IDX_LOADS;      // 4096
 constexpr uint64_t IDX_TILE = IDX_WAVE_BYTES * (IDX_THREADS / 64);  // 16384
 constexpr uint64_t IDX_TILE_VECS = IDX_TILE / 16;             // 1024 vectors = 256 bitmap words of 64 bits
+constexpr uint32_t IDX_LIST_CAP = 1024;                       // newline offsets a tile's list slot holds
 
 // `abuf` = buf rounded down to 16 bytes, `mis` = buf - abuf.  Stream position of abuf[x] is x - mis.
 // bitmap[vi] = newline mask of vector vi (0 beyond the stream; every vector of every tile is written).
@@ -47,6 +54,70 @@ __global__ __launch_bounds__(IDX_THREADS) void count_newlines_kernel(const uint4
     if (threadIdx.x == 0) partials[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
 }
 
+// The list form.  Stream order inside a tile = (wave, load, lane, bit); the counts of a lane's four vectors are scanned two
+// to a word (16-bit fields: a wave's sum stays below 2^16).
+__global__ __launch_bounds__(IDX_THREADS) void census_list_kernel(const uint4* __restrict__ abuf, uint32_t mis, uint64_t nbytes, uint64_t nvec,
+                                                                   uint32_t* __restrict__ partials, uint16_t* __restrict__ list,
+                                                                   uint32_t* __restrict__ overflow) {
+    // one tile per workgroup, like the bitmap form: a persistent, register-prefetching variant (the shape that pays in the
+    // pack / statistics kernels) was slower here (0.81 vs 0.65 ms) -- eight small workgroups per CU already keep HBM busy
+    __shared__ uint32_t lds[IDX_THREADS / 64];
+    const uint32_t lane = lane_id(), w = threadIdx.x >> 6;
+    const uint64_t v0 = ((uint64_t)blockIdx.x * IDX_TILE + (uint64_t)w * IDX_WAVE_BYTES) / 16 + lane;
+    uint32_t m[IDX_LOADS];
+#pragma unroll
+    for (int it = 0; it < IDX_LOADS; ++it) {
+        const uint64_t vi = v0 + (uint64_t)it * 64;
+        m[it] = 0;
+        if (vi < nvec) {
+            const uint4 q = abuf[vi];
+            const int64_t p = (int64_t)(vi * 16) - (int64_t)mis;
+            m[it] = nl_mask16(q) & valid_mask16(p, nbytes);
+        }
+    }
+    const uint32_t c0 = __popc(m[0]), c1 = __popc(m[1]), c2 = __popc(m[2]), c3 = __popc(m[3]);
+    const uint32_t i01 = wave_inclusive_sum(c0 | (c1 << 16)), i23 = wave_inclusive_sum(c2 | (c3 << 16));
+    const uint32_t t01 = __shfl(i01, 63, 64), t23 = __shfl(i23, 63, 64);
+    const uint32_t T0 = t01 & 0xFFFFu, T1 = t01 >> 16, T2 = t23 & 0xFFFFu, T3 = t23 >> 16;
+    if (lane == 0) lds[w] = T0 + T1 + T2 + T3;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < IDX_THREADS / 64; ++i) { const uint32_t x = lds[i]; if (i < w) base += x; total += x; }
+    if (threadIdx.x == 0) partials[blockIdx.x] = total;
+    const uint32_t ex[IDX_LOADS] = {base + (i01 & 0xFFFFu) - c0, base + T0 + (i01 >> 16) - c1, base + T0 + T1 + (i23 & 0xFFFFu) - c2,
+                                    base + T0 + T1 + T2 + (i23 >> 16) - c3};
+    uint16_t* slot = list + (uint64_t)blockIdx.x * IDX_LIST_CAP;
+    bool over = false;
+#pragma unroll
+    for (int it = 0; it < IDX_LOADS; ++it) {
+        uint32_t mm = m[it], k = ex[it];
+        const uint32_t pos0 = ((w * IDX_LOADS + it) * 64 + lane) * 16;
+        while (mm) {
+            const uint32_t b = (uint32_t)__ffs((int)mm) - 1u;
+            mm &= mm - 1;
+            if (k < IDX_LIST_CAP) slot[k] = (uint16_t)(pos0 + b); else over = true;
+            ++k;
+        }
+    }
+    if (over) atomicOr(overflow, 1u);
+}
+
+// A wave per tile: line_start[rank + 1] = stream position of the byte after the newline.
+__global__ __launch_bounds__(IDX_THREADS) void expand_list_kernel(const uint16_t* __restrict__ list, uint32_t mis, const uint32_t* __restrict__ offsets,
+                                                                   uint64_t nb, uint64_t nlines, uint64_t* __restrict__ line_start) {
+    const uint32_t lane = lane_id();
+    const uint64_t tile = (uint64_t)blockIdx.x * (IDX_THREADS / 64) + (threadIdx.x >> 6);
+    if (tile >= nb) return;
+    if (tile == 0 && lane == 0) line_start[0] = 0;
+    const uint64_t P = offsets[tile];
+    const uint64_t end = tile + 1 < nb ? (uint64_t)offsets[tile + 1] : nlines;
+    const uint32_t cnt = (uint32_t)(end - P);
+    const uint16_t* slot = list + tile * IDX_LIST_CAP;
+    const int64_t p0 = (int64_t)(tile * IDX_TILE) - (int64_t)mis + 1;
+    for (uint32_t j = lane; j < cnt; j += 64) line_start[P + j + 1] = (uint64_t)(p0 + slot[j]);
+}
+
 // One workgroup per census tile: 256 lanes x one 64-bit bitmap word (= 64 stream bytes) each.
 __global__ __launch_bounds__(IDX_THREADS) void scatter_newlines_kernel(const uint64_t* __restrict__ bitmap, uint32_t mis,
                                                                         const uint32_t* __restrict__ offsets,
@@ -67,7 +138,7 @@ __global__ __launch_bounds__(IDX_THREADS) void scatter_newlines_kernel(const uin
     }
 }
 
-int run_count(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint64_t* nblocks_out) {
+int run_count(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint64_t* nblocks_out, bool list_form) {
     const uint32_t mis = (uint32_t)((uintptr_t)d_buf & 15);
     const uint64_t nvec = (nbytes + mis + 15) / 16;
     const uint64_t nb = (nvec * 16 + IDX_TILE - 1) / IDX_TILE;
@@ -78,11 +149,20 @@ int run_count(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint64_t* nblo
         if (ctx->idx_bitmap) UQ_CHECK_HIP(hipFree(ctx->idx_bitmap));
         ctx->idx_partials = nullptr; ctx->idx_bitmap = nullptr; ctx->idx_partials_cap = 0;
         UQ_CHECK_HIP(hipMalloc((void**)&ctx->idx_partials, (nb + 1) * sizeof(uint32_t)));
-        UQ_CHECK_HIP(hipMalloc((void**)&ctx->idx_bitmap, nb * IDX_TILE_VECS * sizeof(uint16_t)));
+        // one buffer serves both forms: nb * 1024 u16 = the bitmap of nb tiles = nb list slots of IDX_LIST_CAP entries
+        static_assert(IDX_TILE_VECS == IDX_LIST_CAP, "bitmap words and list entries per tile share one allocation");
+        UQ_CHECK_HIP(hipMalloc((void**)&ctx->idx_bitmap, nb * IDX_TILE_VECS * sizeof(uint16_t) + 16));
         ctx->idx_partials_cap = nb + 1;
     }
-    count_newlines_kernel<<<(uint32_t)nb, IDX_THREADS, 0, ctx->stream>>>((const uint4*)(d_buf - mis), mis, nbytes, nvec, ctx->idx_partials,
-                                                                        ctx->idx_bitmap);
+    if (list_form) {
+        uint32_t* d_over = (uint32_t*)(ctx->idx_bitmap + nb * IDX_TILE_VECS);          // the 16 spare bytes behind the slots
+        UQ_CHECK_HIP(hipMemsetAsync(d_over, 0, 4, ctx->stream));
+        census_list_kernel<<<(uint32_t)nb, IDX_THREADS, 0, ctx->stream>>>((const uint4*)(d_buf - mis), mis, nbytes, nvec, ctx->idx_partials,
+                                                                         ctx->idx_bitmap, d_over);
+    } else {
+        count_newlines_kernel<<<(uint32_t)nb, IDX_THREADS, 0, ctx->stream>>>((const uint4*)(d_buf - mis), mis, nbytes, nvec, ctx->idx_partials,
+                                                                            ctx->idx_bitmap);
+    }
     UQ_LAUNCH_CHECK();
     *nblocks_out = nb;
     return 0;
@@ -95,7 +175,7 @@ int uq_index_run_census(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint
     const uint32_t mis = (uint32_t)((uintptr_t)d_buf & 15);
     const uint64_t nvec = (nbytes + mis + 15) / 16;
     if (have_scanned) { *nblocks_out = (nvec * 16 + IDX_TILE - 1) / IDX_TILE; return 0; }
-    UQ_TRY(run_count(ctx, d_buf, nbytes, nblocks_out));
+    UQ_TRY(run_count(ctx, d_buf, nbytes, nblocks_out, false));
     UQ_TRY(uq_scan_exclusive_u32(ctx, ctx->idx_partials, ctx->idx_partials, *nblocks_out, nullptr));
     return 0;
 }
@@ -106,16 +186,18 @@ extern "C" int uq_count_lines(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes
     if (nbytes == 0) { *h_nlines = 0; return 0; }
     UQ_REQUIRE(d_buf, "uq_count_lines: null buffer");
     uint64_t nb;
-    UQ_TRY(run_count(ctx, d_buf, nbytes, &nb));
+    UQ_TRY(run_count(ctx, d_buf, nbytes, &nb, true));
     // exclusive scan of the per-tile counts right away: its total is the census, and uq_index_lines
     // reuses the scanned offsets (and the bitmap) for the same buffer
     void* scr;
     UQ_TRY(uq_scratch(ctx, 256, &scr));
     UQ_TRY(uq_scan_exclusive_u32(ctx, ctx->idx_partials, ctx->idx_partials, nb, (uint64_t*)scr));
     UQ_CHECK_HIP(hipMemcpyAsync(ctx->h_pinned, scr, 8, hipMemcpyDeviceToHost, ctx->stream));
+    UQ_CHECK_HIP(hipMemcpyAsync(ctx->h_pinned + 1, ctx->idx_bitmap + nb * IDX_TILE_VECS, 4, hipMemcpyDeviceToHost, ctx->stream));
     UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     *h_nlines = ctx->h_pinned[0];
-    ctx->idx_buf = d_buf; ctx->idx_nbytes = nbytes; ctx->idx_nlines = *h_nlines;
+    // the lists are only good when every tile's newlines fitted its slot; otherwise uq_index_lines runs the bitmap form
+    if ((uint32_t)ctx->h_pinned[1] == 0) { ctx->idx_buf = d_buf; ctx->idx_nbytes = nbytes; ctx->idx_nlines = *h_nlines; }
     return 0;
 }
 
@@ -133,10 +215,14 @@ extern "C" int uq_index_lines(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes
         UQ_REQUIRE(ctx->idx_nlines == nlines, "uq_index_lines: nlines %llu does not match the census %llu",
                    (unsigned long long)nlines, (unsigned long long)ctx->idx_nlines);
         nb = (nvec * 16 + IDX_TILE - 1) / IDX_TILE;
-    } else {
-        UQ_TRY(run_count(ctx, d_buf, nbytes, &nb));
-        UQ_TRY(uq_scan_exclusive_u32(ctx, ctx->idx_partials, ctx->idx_partials, nb, nullptr));
+        ctx->idx_buf = nullptr;
+        expand_list_kernel<<<(uint32_t)((nb + IDX_THREADS / 64 - 1) / (IDX_THREADS / 64)), IDX_THREADS, 0, ctx->stream>>>(ctx->idx_bitmap, mis, ctx->idx_partials,
+                                                                                                                     nb, nlines, d_line_start);
+        UQ_LAUNCH_CHECK();
+        return 0;
     }
+    UQ_TRY(run_count(ctx, d_buf, nbytes, &nb, false));
+    UQ_TRY(uq_scan_exclusive_u32(ctx, ctx->idx_partials, ctx->idx_partials, nb, nullptr));
     ctx->idx_buf = nullptr;
     scatter_newlines_kernel<<<(uint32_t)nb, IDX_THREADS, 0, ctx->stream>>>((const uint64_t*)ctx->idx_bitmap, mis, ctx->idx_partials, nlines,
                                                                            d_line_start);
