@@ -96,7 +96,7 @@ constexpr int PK_NV_STATS = 4;   // the fused pack + statistics kernel keeps 16 
 // (uq_pack_stats).  `st->reserved` is raised when the counts are incomplete (a record longer than the guess
 // allowed for, or malformed): the caller then runs the plain statistics pass.
 template <int BD, int BQ, bool NTRICK, bool FAST, bool STATS>
-__global__ __launch_bounds__(PK_THREADS, 5) void pack_tile_kernel(const uint8_t* __restrict__ buf,
+__global__ __launch_bounds__(PK_THREADS, STATS ? 4 : 5) void pack_tile_kernel(const uint8_t* __restrict__ buf,
                                                                const uint64_t* __restrict__ ls, uint64_t first,
                                                                uint64_t n, PackLut lut, PackGeom g,
                                                                uint8_t* __restrict__ dna, uint8_t* __restrict__ qual,
