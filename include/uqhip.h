@@ -149,6 +149,12 @@ int uq_lower_bound_rows(uq_ctx* ctx, const uint8_t* d_sorted_table, uint64_t row
 int uq_gather_rows(uq_ctx* ctx, const uint8_t* d_table, uint64_t table_rows, uint32_t cols,
                    const void* d_index, int index_itemsize, uint64_t n_out, uint8_t* d_out);
 
+/* Decode-side validation of a stored key / mapping column before it indexes a table (a .uQ file is untrusted input):
+ * *h_first_bad = lowest position j with index[j] >= limit, or UQ_NONE.  The reference's numpy raises IndexError on
+ * such a file (uq.py:953, 957, 973 `table[key]`; 1016 `column['map'][row[i]]`); uq_gather_rows itself reads row 0 for an
+ * out-of-range index (never out of bounds), so callers that want the error check first. */
+int uq_check_index_range(uq_ctx* ctx, const void* d_index, int index_itemsize, uint64_t n, uint64_t limit, uint64_t* h_first_bad);
+
 /* ---- a6: unique rows + inverse.  Replaces numpy.unique(rows as void, return_inverse=True)
  * (uq.py:784-789).  Outputs: d_perm = stable sort order of the rows (== argsort(key, stable),
  * uq.py:796), d_key[i] = rank of row i among the distinct rows, d_sorted_key[j] = d_key[d_perm[j]]

@@ -76,9 +76,10 @@ def test_sharded_encode_fuzz(tmp_path, seed):
     import numpy as np
     from test_gpu_e2e import _fuzz_case, _oracle_flags
     fq, flags = _fuzz_case(np.random.default_rng(seed))
+    import re
     try:
         O.encode(fq, **_oracle_flags(flags))
-    except Exception:
+    except (O.UqError, ValueError, IndexError, re.error):
         pytest.skip('the reference refuses this input')
     _check(tmp_path, 2 + seed % 2, flags, fq=fq)
 

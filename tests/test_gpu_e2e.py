@@ -4,6 +4,7 @@
 import io
 import json
 import os
+import re
 import tarfile
 
 import numpy as np
@@ -259,8 +260,9 @@ def test_cli_fuzz_against_oracle(ctx, tmp_path, seed):
     of = _oracle_flags(flags)
     try:
         ocfg, omembers, _ = O.encode(fq, **of)
-    except Exception:                           # the reference refuses this input (e.g. no QNAME separator): so must the CLI
-        with pytest.raises((uq.UqError, Exception)):
+    except (O.UqError, ValueError, IndexError, re.error):   # the reference refuses this input (e.g. no QNAME separator): so must the
+        from uq_amd import qname                             # CLI, with ITS error types -- a crash of the product is not a refusal
+        with pytest.raises((uq.UqError, qname.QnameError)):
             _run_encode(ctx, tmp_path, fq, flags)
         return
     cfg, members, names, path = _run_encode(ctx, tmp_path, fq, flags + os.environ.get('UQ_FUZZ_FLAGS', '').split())   # e.g. --one-pass

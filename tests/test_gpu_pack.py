@@ -399,3 +399,29 @@ def test_pack_stats_wrong_guesses(ctx):
     # (d) no fused kernel for 3-bit DNA: nothing launched
     d3 = _decide_from_stats(hs, notricks=True)
     assert ops.pack_stats(ctx, d_buf, ls, 0, n, mk(d3, hs.max_record_bytes)) is None
+
+
+@pytest.mark.parametrize('variable', [False, True])
+def test_encoder_reference_signature(ctx, tmp_path, variable):
+    """uq.encoder_fixed / encoder_variable called as the reference calls them (uq.py:707-708): ten positional arguments,
+    `((dna_array, dna_ptr), (qual_array, qual_ptr), lib)` back, `lib.free(ptr)` afterwards (uq.py:712-713)."""
+    import uq_oracle as O
+    from uq_amd import uq
+    n = 700
+    fq = synth.fastq(20261003 + 61, n, (20, 75) if variable else 64, n_rate=2)
+    path = tmp_path / 'in.fastq'; path.write_bytes(fq)
+    lines = O.read_lines(fq)
+    p1 = O.pass1(lines)
+    d = O.decide(p1['static_qualities'], p1['dna_min'], p1['dna_max'])
+    fn = uq.encoder_variable if variable else uq.encoder_fixed
+
+    class Status: current = 0
+    st = Status()
+    (dna_array, dna_ptr), (qual_array, qual_ptr), lib = fn(n, d['bases'], d['qualities'], d['N_qual'], d['dna_bytes_per_row'],
+                                                            d['quality_bytes_per_row'], st, str(path), d['bits_per_base'], d['bits_per_quality'], ctx=ctx)
+    rd, rq = O.encoder(lines, d['bases'], d['qualities'], d['N_qual'], d['dna_bytes_per_row'], d['quality_bytes_per_row'],
+                       d['bits_per_base'], d['bits_per_quality'], variable)
+    assert tuple(dna_array.shape) == rd.shape and tuple(qual_array.shape) == rq.shape
+    assert np.array_equal(dna_array.cpu().numpy(), rd) and np.array_equal(qual_array.cpu().numpy(), rq)
+    assert dna_ptr == dna_array.data_ptr() and qual_ptr == qual_array.data_ptr() and st.current == n
+    assert lib.free(dna_ptr) == 0 and lib.free(qual_ptr) == 0 and not lib._owned

@@ -152,3 +152,62 @@ def test_synth_is_stateless_and_shardable():
     assert len(lines) == 1201 and all(l.startswith(b'@SIM001:42:FCX01:') for l in lines[0:1200:4])
     size, ln, x, y = synth.record_sizes(spec, np.arange(300, dtype=np.uint64))
     assert size.sum() == whole.size and ln.min() >= 36 and ln.max() <= 90
+
+
+def _top_level_args(text, start):
+    """arguments of the call whose '(' is at text[start]: split at top-level commas; returns (list, index after ')')"""
+    depth, cur, out, i = 0, '', [], start
+    while True:
+        ch = text[i]
+        if ch in '([{':
+            depth += 1
+            if depth > 1: cur += ch
+        elif ch in ')]}':
+            depth -= 1
+            if depth == 0:
+                if cur.strip(): out.append(cur.strip())
+                return out, i + 1
+            cur += ch
+        elif ch == ',' and depth == 1:
+            out.append(cur.strip()); cur = ''
+        elif ch == '#':                           # comment to end of line
+            while text[i + 1] != '\n': i += 1
+        else:
+            cur += ch
+        i += 1
+
+
+def test_integration_md_snippets_match_the_binding():
+    """The ctypes stubs INTEGRATION.md shows a maintainer: every `call('uq_*', ...)` passes as many arguments as the
+    entry point takes (uq_amd/_lib.py SIGNATURES == include/uqhip.h), and the structures it declares have the
+    binding's field names in the binding's order.  Keeps the document from drifting away from the boundary."""
+    import re
+    from uq_amd import _lib
+    doc = open(os.path.join(REPO, 'INTEGRATION.md')).read()
+    blocks = re.findall(r'```python\n(.*?)```', doc, flags=re.S)
+    assert blocks
+    seen = set()
+    for code in blocks:
+        tuples = {}
+        for m in re.finditer(r'^(\w+) = \(', code, flags=re.M):
+            tuples[m.group(1)], _ = _top_level_args(code, m.end() - 1)
+        for m in re.finditer(r"call\('(uq_\w+)'\s*,", code):
+            name = m.group(1)
+            args, _ = _top_level_args(code, code.rfind('(', 0, m.start() + 5))
+            args = args[1:]                                        # drop the name
+            n = 0
+            for a in args:
+                n += len(tuples[a[1:]]) if a.startswith('*') else 1
+            assert name in _lib.SIGNATURES, name
+            assert n == len(_lib.SIGNATURES[name]), '%s: INTEGRATION.md passes %d arguments, the ABI takes %d' % (name, n, len(_lib.SIGNATURES[name]))
+            seen.add(name)
+        for m in re.finditer(r'class (\w+)\(C\.Structure\):\s*\n\s*_fields_ = \[', code):
+            fields = re.findall(r"\('(\w+)'", code[m.end():code.index(')]', m.end()) + 1])
+            ref = {'Stats': _lib.Stats, 'PackParams': _lib.PackParams, 'Layout': _lib.QnameLayoutResult}[m.group(1)]
+            assert fields == [f[0] for f in ref._fields_], m.group(1)
+    assert {'uq_pack', 'uq_qname_layout', 'uq_decode_fastq', 'uq_stats_accumulate'} <= seen
+    # every entry point of the header is in the document's table
+    hdr = open(os.path.join(REPO, 'include', 'uqhip.h')).read()
+    for name in re.findall(r'\b(uq_\w+)\s*\(', hdr):
+        if name in _lib.SIGNATURES or name == 'uq_last_error':
+            assert '`%s`' % name in doc or '`%s' % name in doc or name in doc, name + ' missing from INTEGRATION.md'

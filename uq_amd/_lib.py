@@ -89,6 +89,7 @@ SIGNATURES = {
     'uq_argsort_rows': [_vp, _vp, _u64, _u32, _vp],
     'uq_lower_bound_rows': [_vp, _vp, _u64, _u32, _vp, _u64, _vp],
     'uq_gather_rows': [_vp, _vp, _u64, _u32, _vp, _int, _u64, _vp],
+    'uq_check_index_range': [_vp, _vp, _int, _u64, _u64, _P(_u64)],
     'uq_unique_rows': [_vp, _vp, _u64, _u32, _vp, _vp, _vp, _vp, _P(_u64)],
     'uq_key_itemsize': [_u64],
     'uq_narrow': [_vp, _vp, _u64, _int, _vp],

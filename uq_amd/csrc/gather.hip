@@ -159,6 +159,38 @@ int uq_gather_rows_internal(uq_ctx* ctx, const uint8_t* d_table, uint64_t table_
     return 0;
 }
 
+namespace {
+// first position whose index does not address the table (the reference's numpy raises IndexError there, uq.py:953-973)
+__global__ __launch_bounds__(256) void index_range_kernel(const void* __restrict__ idx, int itemsize, uint64_t n, uint64_t limit,
+                                                          unsigned long long* __restrict__ first_bad) {
+    uint64_t bad = UQ_NONE;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        if (load_index(idx, itemsize, i) >= limit) { bad = i; break; }          // a lane's positions increase: its first is its lowest
+    bad = wave_min(bad);
+    if (lane_id() == 0 && bad != UQ_NONE) atomicMin(first_bad, (unsigned long long)bad);
+}
+}  // namespace
+
+extern "C" int uq_check_index_range(uq_ctx* ctx, const void* d_index, int index_itemsize, uint64_t n, uint64_t limit, uint64_t* h_first_bad) {
+    UQ_REQUIRE(ctx && h_first_bad, "uq_check_index_range: null argument");
+    UQ_REQUIRE(index_itemsize == 1 || index_itemsize == 2 || index_itemsize == 4 || index_itemsize == 8,
+               "uq_check_index_range: index itemsize %d not in {1,2,4,8}", index_itemsize);
+    *h_first_bad = UQ_NONE;
+    if (n == 0) return 0;
+    UQ_REQUIRE(d_index, "uq_check_index_range: null index array");
+    void* ws;
+    UQ_TRY(uq_scratch(ctx, 8, &ws));
+    UQ_CHECK_HIP(hipMemsetAsync(ws, 0xFF, 8, ctx->stream));
+    const uint64_t want = (n + 255) / 256;
+    index_range_kernel<<<(uint32_t)(want < UQ_NUM_CU * 8ull ? want : UQ_NUM_CU * 8ull), 256, 0, ctx->stream>>>(d_index, index_itemsize, n, limit,
+                                                                                                               (unsigned long long*)ws);
+    UQ_LAUNCH_CHECK();
+    UQ_CHECK_HIP(hipMemcpyAsync(ctx->h_pinned, ws, 8, hipMemcpyDeviceToHost, ctx->stream));
+    UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    *h_first_bad = ctx->h_pinned[0];
+    return 0;
+}
+
 extern "C" int uq_gather_rows(uq_ctx* ctx, const uint8_t* d_table, uint64_t table_rows, uint32_t cols, const void* d_index,
                               int index_itemsize, uint64_t n_out, uint8_t* d_out) {
     return uq_gather_rows_internal(ctx, d_table, table_rows, cols, d_index, index_itemsize, n_out, d_out);

@@ -5,6 +5,7 @@ here a file moves in 32 MiB chunks: worker threads `readinto` / `pwrite` pinned 
 released inside those calls) while the PCIe copy of the neighbouring chunk is in flight on the
 context's stream.  Nothing is computed here -- bytes only.
 """
+import fcntl
 import os
 from concurrent.futures import ThreadPoolExecutor
 
@@ -118,6 +119,9 @@ class Staging:
         try:
             fd = fileobj.fileno()
             seekable = fileobj.seekable()
+            # pwrite() on an O_APPEND descriptor ignores the offset (Linux): `--decode >> out.fastq` would get its
+            # 32 MiB chunks in completion order.  Appending streams take the sequential path.
+            if fcntl.fcntl(fd, fcntl.F_GETFL) & os.O_APPEND: seekable = False
         except Exception:
             fd, seekable = None, False
         if fd is not None and seekable:

@@ -192,6 +192,14 @@ def gather_rows(ctx, table, table_rows, cols, index, n_out=None, out=None):
     return out
 
 
+def check_index_range(ctx, index, limit):
+    """Lowest position whose value is >= limit, or None (uq_check_index_range): stored keys / mapping columns are
+    checked before they index a table."""
+    bad = C.c_uint64()
+    call('uq_check_index_range', ctx.h, _p(index), index.element_size(), index.numel(), int(limit), C.byref(bad))
+    return None if bad.value == UQ_NONE else int(bad.value)
+
+
 def unique_rows(ctx, table, rows, cols, want_key=True, want_sorted_key=True, want_unique=True):
     """Returns (perm i32[rows], key or None, sorted_key or None, unique rows or None, nunique)."""
     t = ctx.torch

@@ -133,7 +133,13 @@ class Session:
         ops, ctx = self.ops, self.ctx
         if os.path.getsize(path) == 0: error('ERROR: empty input')
         self.path, self._host = path, None
-        self.d_buf = self.io.file_to_device(path)                                # pinned, chunked, overlapped with the reads (row f2)
+        self.load_device(self.io.file_to_device(path))                           # pinned, chunked, overlapped with the reads (row f2)
+
+    def load_device(self, d_buf):
+        """The same for FASTQ bytes that are already in HBM (a uint8 device tensor): record index + pass-1 statistics."""
+        ops, ctx = self.ops, self.ctx
+        self.d_buf = d_buf
+        if not hasattr(self, '_host'): self.path, self._host = None, None
         nlines = ops.count_lines(ctx, self.d_buf)
         if nlines % 4 != 0:
             error('ERROR: The FASTQ file provided contains' + str(nlines) + 'rows, which is not divisible by 4!')
@@ -159,7 +165,7 @@ class Session:
     def host(self):
         """Host copy of the FASTQ bytes: only the sequential QNAME fallback needs it."""
         if self._host is None:
-            self._host = np.fromfile(self.path, dtype=np.uint8)
+            self._host = np.fromfile(self.path, dtype=np.uint8) if self.path else self.ctx.to_numpy(self.d_buf)
         return self._host
 
     # small seams the sharded session (uq_amd/dist_encode.py) overrides
@@ -251,7 +257,23 @@ class Session:
         say('    - we will use', d['dna_bytes_per_row'], 'bytes per unique DNA sequence.\n')
         say('QUAL Analysis:')
         quals_all = sorted(d['qual_distribution'])
+        counts = getattr(getattr(self, 'hs', None), 'counts', None)
+        if counts is not None:                                                  # uq.py:520-526: the per-base breakdown
+            for b in bases_all:
+                say('  [Breakdown for "' + b + '"]')
+                row = counts[ord(b)]
+                for q in np.flatnonzero(row):
+                    pct = int(row[q]) / float(d['base_distribution'][b]) * 100
+                    say('     ', chr(q), '|' + ('#' * int(pct / 2)).ljust(50) + '|', ('%.3f' % pct).rjust(7) + '%', str(int(row[q])).rjust(12))
+                say('')
+        say('  [Total distribution]')
         say('    - the following values were seen as quality scores:', ' '.join(quals_all), '(' + str(len(quals_all)) + ' in total)')
+        say('    - There distribution is:')
+        for q in quals_all:                                                     # uq.py:531-532
+            pct = d['qual_distribution'][q] / total_bases * 100
+            say('     ', q, '|' + ('#' * int(pct / 2)).ljust(50) + '|', ('%.3f' % pct).rjust(7) + '%', str(d['qual_distribution'][q]).rjust(12))
+        nnew = len([c for c in d['N_qual'].values() if c >= len(d['qualities'])])
+        if nnew: say('    - as mentioned above,', nnew, 'unique quality scores will be added to the', len(quals_all), 'above.')
         say('    - this means we will store each quality symbol in', d['bits_per_quality'], 'bits.')
         say('    - we will use', d['quality_bytes_per_row'], 'bytes per unique quality sequence.\n')
         for idx, c in enumerate(self.columns):
@@ -277,8 +299,9 @@ class Session:
         return ((dna, self.total, d['dna_bytes_per_row']), (qual, self.total, d['quality_bytes_per_row']))
 
     def encoder_fixed(self):
-        """uq.py:108-182.  Returns ((dna tensor, rows, cols), (qual tensor, rows, cols)); the tensors are
-        device memory owned by torch (drop the reference to free them, the `lib.free(ptr)` of uq.py:712)."""
+        """uq.py:108-182 on the session's resident buffer.  Returns ((dna tensor, rows, cols), (qual tensor, rows, cols)).
+        The module-level `encoder_fixed(...)` / `encoder_variable(...)` keep the reference's ten-argument signature and
+        its `((array, ptr), (array, ptr), lib)` return."""
         return self._encode(False)
 
     def encoder_variable(self):
@@ -468,6 +491,12 @@ class Session:
             rest = {k: v for k, v in result.items() if k not in ('total_size', 'sorted_on', 'raw_tables')}
             say(str(result['total_size']).rjust(17) + '   ', str(result['sorted_on']).ljust(8), str(tuple(result['raw_tables'])).ljust(27),
                 ' '.join(str(k) + ':' + str(v) for k, v in rest.items()))
+        # uq.py:885-889 (py2 `print x,` soft spaces kept: the line reads the same)
+        line = 'Parameters found to be the best for this data type:\n  '
+        if args.sort is not None and args.sort != (None,): line += '  --sort ' + str(args.sort)
+        if args.raw is not None: line += '  --raw ' + ' '.join(map(str, args.raw))
+        if args.pattern is not None: line += '  --pattern ' + ' '.join(map(str, args.pattern))
+        say(line)
         return all_results
 
     # ------------------------------------------------------------------ container
@@ -528,6 +557,12 @@ class Session:
         if args.output is None: args.output = args.input + '.uQ'
         self.say('Warming up...')
         self.load(args.input)
+        self.encode_loaded()
+
+    def encode_loaded(self, write=True):
+        """Everything after the FASTQ is in HBM (`load` / `load_device`).  write=False: stop before the container is
+        written -- the members stay in `self.members` (header bytes, device payload)."""
+        args = self.args
         self.analyse()
         if args.peek:
             self.say('The config.json would look like:')
@@ -539,6 +574,7 @@ class Session:
         if args.raw is None: args.raw = (None,)
         self.members = {}
         self.run_mix(args.sort, args.raw, False)
+        if not write: return
         self.say('\nWriting final config...')
         self.say('Archiving results and cleaning up temp directory...')
         self.write_container(args.output)
@@ -558,6 +594,12 @@ class Session:
         version = np.lib.format.read_magic(f)
         shape, fortran, dtype = np.lib.format.read_array_header_1_0(f) if version == (1, 0) else np.lib.format.read_array_header_2_0(f)
         hdr = f.tell()
+        # a .uQ file is untrusted input: the payload must be exactly what the header promises (numpy.load raises on a
+        # short member, uq.py:944-945) before any of it is addressed on the device
+        want = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize if len(shape) else np.dtype(dtype).itemsize
+        if len(shape) not in (1, 2) or hdr + want != size:
+            error('ERROR: member %s of this uQ file is damaged (header says %s x %s = %d bytes, the member holds %d)'
+                  % (file_name, tuple(shape), np.dtype(dtype).name, want, size - hdr))
         if len(shape) == 1:
             tt = self.ctx.torch
             isz = np.dtype(dtype).itemsize
@@ -610,6 +652,7 @@ class Session:
             if name in members and name + '.key' in members:
                 t, nrows, cols = self.load_from_tar(members, name, pattern)
                 d_key = self.load_from_tar(members, name + '.key', rows=rows)
+                self.check_index(d_key, nrows, name + '.key')
                 return (ops.gather_rows(ctx, t, nrows, cols, d_key), d_key.numel(), cols)          # uq.py:953, 957
             error('ERROR: No ' + name + ' data was found in this uQ file?!')
 
@@ -622,10 +665,22 @@ class Session:
             d_cols = []
             for i in range(ncols):                                                                # uq.py:973, numeric order (Q6)
                 c = self.load_from_tar(members, 'QNAME_%d' % (i + 1))
+                if i == 0: self.check_index(d_key, c.numel(), 'QNAME.key')
                 d_cols.append(ops.gather_rows(ctx, c.view(u8), c.numel(), c.element_size(), d_key).view(c.dtype))
         else:
             d_cols = [self.load_from_tar(members, 'QNAME_%d.raw' % (i + 1), rows=rows) for i in range(ncols)]
+        for i, c in enumerate(config['QNAME_columns']):                                           # uq.py:1016 `column['map'][row[i]]`
+            if c['format'] == 'mapping': self.check_index(d_cols[i], len(c['map']), 'QNAME column %d' % (i + 1))
+        if len({DNA[1], QUAL[1]} | {c.numel() for c in d_cols}) != 1:
+            error('ERROR: the tables of this uQ file do not hold the same number of reads')
         return DNA, QUAL, d_cols
+
+    def check_index(self, d_index, limit, what):
+        """A stored key / mapping code must address its table: numpy raises IndexError in the reference (uq.py:953-973,
+        1016); here the device check runs before the gather / the text kernels use the value."""
+        bad = self.ops.check_index_range(self.ctx, d_index, limit)
+        if bad is not None:
+            error('ERROR: %s of this uQ file is damaged: entry %d points beyond its table of %d rows' % (what, bad, limit))
 
     @staticmethod
     def device_text_possible(config):
@@ -662,6 +717,63 @@ class Session:
             for r in range(n):
                 l = int(L[r])
                 w.write(names[r].encode('latin-1') + b'\n' + S[r, :l].tobytes() + b'\n+\n' + Q[r, :l].tobytes() + b'\n')
+
+
+# ---------------------------------------------------------------------- the packers with the reference's own signature
+class DeviceLib:
+    """What the reference's third return value (`lib`, the cffi handle of libc) is used for: `lib.free(ptr)`
+    (uq.py:712-713).  Here `ptr` is a device address; free() drops the torch tensor that owns it."""
+
+    def __init__(self):
+        self._owned = {}
+
+    def _own(self, tensor):
+        self._owned[tensor.data_ptr()] = tensor
+        return tensor.data_ptr()
+
+    def free(self, ptr):
+        self._owned.pop(int(ptr), None)
+        return 0
+
+
+def _encoder(variable, total_reads, bases, qualities, N_qual, dna_bytes_per_row, quality_bytes_per_row, status, file_path,
+             bits_per_base, bits_per_quality, ctx=None):
+    from . import ops
+    from .device import Context
+    from .hostio import Staging
+    ctx = ctx or Context(0)
+    d_buf = Staging(ctx).file_to_device(file_path)
+    nlines = ops.count_lines(ctx, d_buf)
+    if nlines // 4 != total_reads: error('ERROR: %s holds %d reads, not %d' % (file_path, nlines // 4, total_reads))
+    d_ls = ops.index_lines(ctx, d_buf, nlines)
+    st = ops.stats_new(ctx)
+    ops.stats_accumulate(ctx, st, d_buf, d_ls, 0, total_reads)                # dna_max and the tile sizing (the reference
+    hs = ops.stats_fetch(ctx, st)                                             # closes over the global `dna_max`, uq.py:128)
+    p = ops.make_pack_params(bases, qualities, N_qual, bits_per_base, bits_per_quality, variable, dna_bytes_per_row,
+                             quality_bytes_per_row, hs.len_max, hs.max_record_bytes, avg_record_bytes=d_buf.numel() // max(total_reads, 1))
+    dna, qual, bad = ops.pack(ctx, d_buf, d_ls, 0, total_reads, p)
+    b = ops.bad_index(bad)
+    if b is not None: error('ERROR: read %d holds a symbol that is in neither alphabet nor N_qual' % b)
+    if status is not None: status.current = total_reads                      # uq.py:176
+    lib = DeviceLib()
+    return ((dna.view(total_reads, dna_bytes_per_row), lib._own(dna)),
+            (qual.view(total_reads, quality_bytes_per_row), lib._own(qual)), lib)
+
+
+def encoder_fixed(total_reads, bases, qualities, N_qual, dna_bytes_per_row, quality_bytes_per_row, status, file_path,
+                  bits_per_base, bits_per_quality, ctx=None):
+    """uq.py:108-182 with its argument list and its return value `((dna_array, dna_ptr), (qual_array, qual_ptr), lib)`:
+    the arrays are uint8[total_reads][bytes_per_row] DEVICE tensors (the reference's numpy views of malloc'd memory,
+    uq.py:178-181), the pointers their device addresses, and `lib.free(ptr)` releases them (uq.py:712-713)."""
+    return _encoder(False, total_reads, bases, qualities, N_qual, dna_bytes_per_row, quality_bytes_per_row, status, file_path,
+                    bits_per_base, bits_per_quality, ctx)
+
+
+def encoder_variable(total_reads, bases, qualities, N_qual, dna_bytes_per_row, quality_bytes_per_row, status, file_path,
+                     bits_per_base, bits_per_quality, ctx=None):
+    """uq.py:188-254, same contract as `encoder_fixed` (rows carry the length sentinel)."""
+    return _encoder(True, total_reads, bases, qualities, N_qual, dna_bytes_per_row, quality_bytes_per_row, status, file_path,
+                    bits_per_base, bits_per_quality, ctx)
 
 
 def main(argv=None):
