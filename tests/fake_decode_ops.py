@@ -39,6 +39,13 @@ class FakeOps:
         return torch.from_numpy(np.ascontiguousarray(t[idx]).reshape(-1))
 
     @staticmethod
+    def check_index_range(ctx, index, limit):
+        idx = index.numpy().astype(np.int64)
+        if index.dtype != torch.uint8: idx &= (1 << (8 * index.element_size())) - 1
+        bad = np.flatnonzero(idx >= limit)
+        return int(bad[0]) if len(bad) else None
+
+    @staticmethod
     def unpattern(ctx, payload, rows, cols, pattern):
         k = int(pattern[0])
         shape = (rows, cols) if k % 2 == 0 else (cols, rows)

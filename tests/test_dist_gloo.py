@@ -4,6 +4,7 @@ here (test infrastructure); on the GPU the same code runs with dist.HipRows."""
 import json
 import os
 import socket
+import time
 
 import numpy as np
 import pytest
@@ -37,6 +38,10 @@ class NumpyRows:
         return torch.tensor([bisect.bisect_left(keys, k) for k in v(p)], dtype=torch.int64)
 
 
+class _Failed:
+    def __init__(self, text): self.text = text
+
+
 def _free_port():
     s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
 
@@ -46,6 +51,10 @@ def _worker(rank, world, port, fn, q):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         q.put((rank, fn(rank, world)))
+    except BaseException as e:                   # a rank that fails says so: the parent must not wait for its result
+        import traceback
+        q.put((rank, _Failed(''.join(traceback.format_exception(type(e), e, e.__traceback__)))))
+        os._exit(1)                              # peers stuck in a collective with this rank get 'connection closed'
     finally:
         dist.destroy_process_group()
 
@@ -56,9 +65,24 @@ def _run(world, fn):
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, fn, q)) for r in range(world)]
     for p in procs: p.start()
-    out = dict(q.get() for _ in range(world))
-    for p in procs: p.join(60)
-    assert all(p.exitcode == 0 for p in procs)
+    out = {}
+    deadline = time.time() + 120
+    while len(out) < world and time.time() < deadline:
+        if not q.empty():
+            r, v = q.get(); out[r] = v
+        elif any(p.exitcode not in (None, 0) for p in procs) and q.empty():
+            time.sleep(0.5)                      # a rank died: collect what is queued, then stop waiting
+            while not q.empty():
+                r, v = q.get(); out[r] = v
+            break
+        else:
+            time.sleep(0.02)
+    for p in procs: p.join(10)
+    for p in procs:
+        if p.is_alive(): p.kill()
+    failed = [v.text for v in out.values() if isinstance(v, _Failed)]
+    assert not failed, failed[0]
+    assert len(out) == world and all(p.exitcode == 0 for p in procs), 'ranks %s did not finish' % [r for r in range(world) if r not in out]
     return [out[r] for r in range(world)]
 
 

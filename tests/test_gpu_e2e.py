@@ -342,3 +342,81 @@ def test_decode_many_qname_columns(ctx, tmp_path):
         assert len(cfg['QNAME_columns']) >= 10
         assert sorted(_records(_run_decode(ctx, path))) == sorted(_records(fq))
         if flags: assert _run_decode(ctx, path) == fq
+
+
+def _rewrite_tar(src, dst, edit):
+    """copy the container `src` to `dst` with member payloads changed by edit(name, bytes) -> bytes"""
+    with tarfile.open(src) as t, tarfile.open(dst, 'w') as o:
+        for m in t.getmembers():
+            data = edit(m.name, t.extractfile(m).read())
+            ti = tarfile.TarInfo(m.name); ti.size = len(data)
+            o.addfile(ti, io.BytesIO(data))
+
+
+def _npy_set(data, index, value):
+    """the .npy member `data` with element `index` of its flat payload set to `value`"""
+    f = io.BytesIO(data)
+    np.lib.format.read_magic(f)
+    shape, fortran, dtype = np.lib.format.read_array_header_1_0(f)
+    hdr = f.tell()
+    a = np.frombuffer(data[hdr:], dtype=dtype).copy()
+    a[index] = value
+    return data[:hdr] + a.tobytes()
+
+
+def test_decoder_refuses_damaged_containers(ctx, tmp_path):
+    """A .uQ file is untrusted input.  A key that points beyond its table, a mapping code beyond its string table and a
+    truncated member each end in a UqError (the reference's numpy raises IndexError / ValueError on them, uq.py:944-973,
+    1016) -- not in an out-of-bounds device read, and not in plausible but wrong FASTQ."""
+    import random
+    rnd = random.Random(5)
+    seqs = [''.join(rnd.choice('ACGT') for _ in range(30)) for _ in range(5)]
+    recs = []
+    for i in range(400):
+        recs.append('@run %s:%d\n%s\n+\n%s\n' % (rnd.choice(['ab', 'c', 'Zed']), i, rnd.choice(seqs), ''.join(rnd.choice('#5AI') for _ in range(30))))
+    fq = ''.join(recs).encode()
+    cfg, members, names, path = _run_encode(ctx, tmp_path, fq, ['--raw', 'QUAL', 'QNAME'])      # DNA keyed: 5 distinct rows, u1 key
+    assert 'DNA.key' in members and cfg['QNAME_columns'][0]['format'] == 'mapping' and len(cfg['QNAME_columns'][0]['map']) == 3
+    assert _run_decode(ctx, path) == fq
+
+    def decode(p):
+        args = uq.build_parser().parse_args(['-i', str(p), '--decode', '--quiet'])
+        uq.validate_args(args)
+        buf = io.BytesIO()
+        uq.Session(args, ctx=ctx).decode(out=buf)
+        return buf.getvalue()
+
+    bad = tmp_path / 'bad.uQ'
+    _rewrite_tar(path, bad, lambda n, d: _npy_set(d, 123, 5) if n == 'DNA.key' else d)            # == nunique
+    with pytest.raises(uq.UqError, match='DNA.key.*entry 123'):
+        decode(bad)
+    _rewrite_tar(path, bad, lambda n, d: _npy_set(d, 77, 3) if n == 'QNAME_1.raw' else d)        # == len(map)
+    with pytest.raises(uq.UqError, match='QNAME column 1.*entry 77'):
+        decode(bad)
+    _rewrite_tar(path, bad, lambda n, d: d[:-100] if n == 'QUAL.raw' else d)                      # truncated member
+    with pytest.raises(uq.UqError, match='QUAL.raw.*damaged'):
+        decode(bad)
+    _rewrite_tar(path, bad, lambda n, d: d[:-1] if n == 'QNAME_2.raw' else d)
+    with pytest.raises(uq.UqError, match='QNAME_2.raw.*damaged'):
+        decode(bad)
+    _rewrite_tar(path, bad, lambda n, d: d)                                                       # the copy itself decodes
+    assert decode(bad) == fq
+
+
+def test_decode_into_appending_file(ctx, tmp_path):
+    """`uq --decode >> out.fastq`: pwrite() ignores its offset on O_APPEND descriptors, so the parallel chunk writer must not
+    be used there (uq_amd/hostio.py)."""
+    from uq_amd import hostio
+    fq = synth.fastq(20261003 + 62, 4000, 100)
+    cfg, members, names, path = _run_encode(ctx, tmp_path, fq, ['--raw', 'DNA', 'QUAL', 'QNAME'])
+    out = tmp_path / 'appended.fastq'
+    out.write_bytes(b'@head\nA\n+\nI\n')
+    old = hostio.CHUNK
+    args = uq.build_parser().parse_args(['-i', path, '--decode', '--quiet'])
+    uq.validate_args(args)
+    s = uq.Session(args, ctx=ctx)
+    s.io.chunk = 64 << 10                       # many chunks in flight: completion order != file order on the parallel path
+    s.io.nbuf = 8
+    with open(out, 'ab') as fh:
+        s.decode(out=fh)
+    assert out.read_bytes() == b'@head\nA\n+\nI\n' + fq
