@@ -14,6 +14,11 @@ class FakeCtx:
     torch = torch
     device = 'cpu'
 
+    @staticmethod
+    def to_numpy(tensor, dtype=None, shape=None):
+        a = tensor.numpy()
+        return a.view(dtype) if dtype is not None else a
+
 
 class FakeIO:
     def file_to_device(self, path, offset=0, size=None, out=None):
@@ -59,3 +64,24 @@ class FakeOps:
             members['QNAME_%d.raw' % (i + 1)] = _npy(np.frombuffer(c.numpy().tobytes(), dtype=np.dtype(cc['dtype'])))
         text = O.decode(dict(config, pattern=['0.1', '0.1']), members).encode('latin-1')
         return torch.frombuffer(bytearray(text), dtype=torch.uint8), None
+
+
+class FakeLoadOps:
+    """numpy stand-ins for what `ShardedSession.load` calls (newline census, record index, statistics)."""
+
+    @staticmethod
+    def count_lines(ctx, buf):
+        return int((buf.numpy() == 10).sum())
+
+    @staticmethod
+    def index_lines(ctx, buf, nlines):
+        pos = np.flatnonzero(buf.numpy() == 10)[:nlines] + 1
+        return torch.from_numpy(np.concatenate([[0], pos]).astype(np.int64))
+
+    @staticmethod
+    def stats_new(ctx):
+        return torch.zeros(8, dtype=torch.uint8)
+
+    @staticmethod
+    def stats_accumulate(ctx, st, buf, ls, first, n):
+        pass

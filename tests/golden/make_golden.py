@@ -15,7 +15,8 @@ afterwards:
      cffi's 0..255 range check on uint8 stores) stands in for the missing package.  The shim
      does no arithmetic: every packed byte is computed by the reference's own loops.
 Outputs: for each case `<name>.fastq` (input), `<name>.uQ` (the tar the reference wrote) and
-`<name>.json` (argv + provenance).  `--stable` cases add the documented Q17 patch
+`<name>.json` (argv + provenance + what the reference's own decoder made of the file) and, when that decoder
+finished, its output `<name>.refdecode.fastq`.  `--stable` cases add the documented Q17 patch
 (argsort kind='stable') so that tie order is comparable.
 """
 import hashlib
@@ -131,14 +132,46 @@ def make_case(name, fastq_bytes, flags, stable=False, decode=True, outdir=HERE):
                 'reference_sha256': hashlib.sha256(open(REFERENCE, 'rb').read()).hexdigest(),
                 'generator': 'tests/golden/make_golden.py'}
         if decode:
+            # the reference's own decoder on the file the reference wrote: its stdout is kept as <name>.refdecode.fastq
+            # (data: the decoder's output) so that lines 2 and 4 of every record pin our decoder to it
             rc, text = run_reference(['-i', out, '--decode'], work, stable)
-            meta['reference_decode_roundtrip'] = (rc == 0 and text.encode('latin-1') == fastq_bytes)
+            got = text.encode('latin-1')
+            meta['reference_decode_roundtrip'] = (rc == 0 and got == fastq_bytes)
+            meta['reference_decode'] = describe_decode(rc, got, fastq_bytes, flags)
+            ref_out = os.path.join(outdir, name + '.refdecode.fastq')
+            if meta['reference_decode']['seq_qual_lines'] != 'unavailable':
+                with open(ref_out, 'wb') as f: f.write(got)
+            elif os.path.exists(ref_out):
+                os.remove(ref_out)
         with open(os.path.join(outdir, name + '.fastq'), 'wb') as f: f.write(fastq_bytes)
         shutil.copyfile(out, os.path.join(outdir, name + '.uQ'))
         with open(os.path.join(outdir, name + '.json'), 'w') as f: json.dump(meta, f, indent=1, sort_keys=True)
         print('wrote', name, os.path.getsize(out), 'bytes', meta.get('reference_decode_roundtrip'))
     finally:
         shutil.rmtree(work, ignore_errors=True)
+
+
+def describe_decode(rc, got, fastq_bytes, flags):
+    """Why `reference_decode_roundtrip` is what it is: which lines of the reference decoder's output equal the input."""
+    want = fastq_bytes.split(b'\n')[:-1]
+    have = got.split(b'\n')[:-1]
+    if rc != 0 or len(have) != len(want) or len(have) % 4:
+        tail = got.decode('latin-1', 'replace').strip().splitlines()[-1:] or ['']
+        return {'seq_qual_lines': 'unavailable', 'qname_lines': 'unavailable',
+                'why': 'the reference decoder stopped (rc %d): %s' % (rc, tail[0][:200])}
+    sorted_run = '--sort' in flags and flags[flags.index('--sort') + 1] != 'None'
+    pick = lambda lines, k: lines[k::4]
+    def same(k):
+        a, b = pick(have, k), pick(want, k)
+        return a == b if not sorted_run else sorted(a) == sorted(b)
+    recs = lambda lines: sorted(zip(pick(lines, 1), pick(lines, 3)))
+    d = {'seq_qual_lines': 'equal to the input' + (' as a multiset of (SEQ, QUAL) pairs (the file is sorted)' if sorted_run else '')
+         if (same(1) and same(3) and same(2) and recs(have) == recs(want)) else 'DIFFERENT from the input',
+         'qname_lines': 'equal to the input' if same(0) else 'different from the input'}
+    if d['qname_lines'] != 'equal to the input':
+        d['why'] = ('QNAME fields come back permuted: the reference decoder orders the QNAME columns by tar member order = '
+                    'os.listdir order (uq.py:911, 964-972; SURVEY.md App. B Q6).  SEQ and QUAL lines are unaffected.')
+    return d
 
 
 def cases():
@@ -168,10 +201,19 @@ def cases():
     yield 'nosort_keyed', dup, ['--sort', 'None', '--pattern', '1.1', '1.2'], False
     # 10. mixed: sort DNA raw, QUAL keyed
     yield 'sort_dna_raw_qual_keyed_stable', dup, ['--sort', 'DNA', '--raw', 'DNA', '--pattern', '3.1', '0.2'], True
+    # 11. the UNPATCHED reference (numpy's default, unstable argsort) on the sorted mixes: compared by the Q17 rule
+    #     (sorted-on table / unique tables / sorted-on key exact, the rest a multiset inside every tie group)
+    yield 'sort_qual_raw', dup, ['--sort', 'QUAL', '--raw', 'DNA', 'QUAL', 'QNAME', '--pattern', '2.2', '2.2'], False
+    yield 'sort_qname_raw', dup, ['--sort', 'QNAME', '--raw', 'QNAME', '--pattern', '0.2', '1.1'], False
+    yield 'sort_qname_keyed', dup, ['--sort', 'QNAME', '--pattern', '2.1', '3.2'], False
+    yield 'sort_dna_raw_all', dup, ['--sort', 'DNA', '--raw', 'DNA', 'QUAL', 'QNAME'], False
 
 
 if __name__ == '__main__':
-    only = set(sys.argv[1:])
+    only = set(a for a in sys.argv[1:] if not a.startswith('--'))
+    outdir = HERE
+    for a in sys.argv[1:]:
+        if a.startswith('--outdir='): outdir = a.split('=', 1)[1]
     for name, fq, flags, stable in cases():
         if only and name not in only: continue
-        make_case(name, fq, flags, stable)
+        make_case(name, fq, flags, stable, outdir=outdir)

@@ -259,3 +259,43 @@ def test_sharded_decoder_ranges_and_offsets(tmp_path, world, flags):
     out = str(tmp_path / 'back.fastq')
     assert all(_run(world, functools.partial(_decode_job, enc=enc, out=out)))
     assert open(out, 'rb').read().decode('latin-1') == O.decode(cfg, members)
+
+
+def _load_job(rank, world, path, slack):
+    """ShardedSession.load over `world` ranks with the device layer replaced by numpy: returns what this rank raised."""
+    import fake_decode_ops as F
+    from uq_amd import dist_encode, uq
+    dist_encode.SLACK = slack
+    args = uq.validate_args(uq.build_parser().parse_args(['-i', path, '--quiet']))
+    s = dist_encode.ShardedSession(args, ctx=F.FakeCtx())
+    s.io, s.ops = F.FakeIO(), F.FakeLoadOps()
+    try:
+        s.load(path)
+    except uq.UqError as e:
+        return 'UqError: ' + str(e)
+    return 'ok %d reads from %d, %d in file' % (s.total, s.read_offset, s.total_reads)
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_load_errors_are_collective(tmp_path, world):
+    """A failure only ONE rank can see must come out of EVERY rank as the same UqError, promptly -- not as one rank
+    leaving while its peers wait in the next collective (dist_encode.py:83)."""
+    import functools
+    from uq_amd import synth
+    fq = synth.fastq(20261003 + 44, 64, 40)
+    p = tmp_path / 'x.fastq'
+    # (1) intact file: every rank loads its share
+    p.write_bytes(fq)
+    res = _run(world, functools.partial(_load_job, path=str(p), slack=4 << 20))
+    assert all(r.startswith('ok') for r in res) and sum(int(r.split()[1]) for r in res) == 64, res
+    # (2) no final newline: `wc -l` counts 255 lines (uq.py:85-87) -- the single-GPU CLI's message, from every rank
+    p.write_bytes(fq[:-1])
+    res = _run(world, functools.partial(_load_job, path=str(p), slack=4 << 20))
+    assert len(set(res)) == 1 and 'contains255rows, which is not divisible by 4' in res[0], res
+    # (3) an unterminated FIFTH line after complete records: the tail is ignored exactly as `wc -l` / 4 ignores it
+    p.write_bytes(fq + b'@trailing garbage')
+    res = _run(world, functools.partial(_load_job, path=str(p), slack=4 << 20))
+    assert all(r.startswith('ok') for r in res) and sum(int(r.split()[1]) for r in res) == 64, res
+    # (4) a record longer than the slack straddles a shard boundary: only the rank in front of it can tell
+    res = _run(world, functools.partial(_load_job, path=str(p), slack=16))
+    assert len(set(res)) == 1 and 'straddles a shard boundary' in res[0], res

@@ -151,3 +151,60 @@ def test_bench_two_ranks_rehearsal():
     r = json.loads(lines[0])
     assert r['n_gpus'] == 2 and r['scaling'] == 'weak' and r['value'] > 0 and r['config']['reads_per_gpu'] == 200000
     assert r['roofline']['bound'] == 'hbm' and 'cpu_baseline' not in r          # the CPU baseline is timed at N = 1 only
+
+
+def _run_sharded_expect_error(world, inp, out, flags, timeout=120):
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), UQ_DIST_BACKEND='gloo', PYTHONPATH=REPO)
+        procs.append(subprocess.Popen([sys.executable, '-m', 'uq_amd.dist_encode', '-i', str(inp), '-o', str(out), '--quiet'] + flags,
+                                      env=env, cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs: q.kill()
+            raise AssertionError('a rank was left waiting in a collective')
+        logs.append(o.decode(errors='replace'))
+    assert all(p.returncode == 1 for p in procs), '\n'.join(logs)        # every rank leaves with the CLI's error code
+    assert not os.path.exists(str(out)) and not os.path.exists(str(out) + '.part')
+    return logs[0]
+
+
+def test_sharded_encoder_errors_reach_every_rank(tmp_path):
+    """Malformed input seen by one rank only: all ranks exit with code 1 well inside the timeout and rank 0 prints what
+    the single-GPU CLI prints for the same file."""
+    from uq_amd import uq
+    fq = synth.fastq(20261003 + 45, 600, (30, 61))
+    recs = fq.split(b'\n')
+    inp, out = tmp_path / 'in.fastq', tmp_path / 'out.uQ'
+
+    def single(data):
+        inp.write_bytes(data)
+        args = uq.validate_args(uq.build_parser().parse_args(['-i', str(inp), '-o', str(tmp_path / 's.uQ'), '--quiet']))
+        from uq_amd.device import Context
+        c = Context(0)
+        try:
+            with pytest.raises(uq.UqError) as e:
+                uq.Session(args, ctx=c).encode()
+        finally:
+            c.close()
+        return str(e.value)
+
+    # no final newline
+    want = single(fq[:-1])
+    assert 'not divisible by 4' in want
+    assert want in _run_sharded_expect_error(2, inp, out, [])
+    # third line of a record in the SECOND half does not start with '+'
+    bad = list(recs); bad[4 * 450 + 2] = b'-'
+    want = single(b'\n'.join(bad))
+    assert 'the third line does not start with +' in want
+    assert want in _run_sharded_expect_error(3, inp, out, ['--sort', 'DNA'])
+    # SEQ / QUAL lengths differ in the last record
+    bad = list(recs); bad[4 * 599 + 3] = bad[4 * 599 + 3][:-2]
+    want = single(b'\n'.join(bad))
+    assert 'does not match the length of the quality scores' in want
+    assert want in _run_sharded_expect_error(2, inp, out, [])

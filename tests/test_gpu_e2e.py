@@ -84,8 +84,8 @@ def test_cli_matches_reference_output(ctx, tmp_path, name):
     else:
         # reference ran numpy's unstable argsort (Q17): the sorted-on table, every unique table and the
         # sorted-on key are order-free; the others agree as multisets inside each tie group = after decoding
-        for k in ('DNA', 'DNA.key', 'QUAL', 'QNAME_1', 'QNAME_2', 'QNAME_3', 'QNAME_4'):
-            if k in ref_members: assert members[k] == ref_members[k], k
+        from test_oracle_golden import assert_equal_up_to_tie_order
+        assert_equal_up_to_tie_order(cfg, members, ref_cfg, ref_members)          # exact members + multiset per tie group
         assert sorted(_records(O.decode(ref_cfg, ref_members).encode('latin-1'))) == sorted(_records(_run_decode(ctx, path)))
     # QNAME members come out in numeric order (Q6)
     q = [n for n in names if n.startswith('QNAME_')]
@@ -109,6 +109,15 @@ def test_decoder_reads_reference_written_files(ctx, name):
     assert text.decode('latin-1') == O.decode(ref_cfg, ref_members)              # same order as the reference's decoder semantics
     if ref_cfg['sort'] == [None]: assert text == fq
     else: assert sorted(_records(text)) == sorted(_records(fq))
+    # ... and against what the reference's OWN decoder printed for this file (tests/golden/<name>.refdecode.fastq):
+    # SEQ, '+' and QUAL lines position by position; the QNAME line too unless the json records the reference's Q6 defect
+    meta = json.load(open(os.path.join(GOLD, name + '.json')))
+    rd = meta['reference_decode']
+    if rd['seq_qual_lines'] == 'unavailable': return
+    ref_lines = open(os.path.join(GOLD, name + '.refdecode.fastq'), 'rb').read().split(b'\n')[:-1]
+    lines = text.split(b'\n')[:-1]
+    assert len(lines) == len(ref_lines) and all(lines[k::4] == ref_lines[k::4] for k in (1, 2, 3))
+    if rd['qname_lines'] == 'equal to the input': assert lines[0::4] == ref_lines[0::4]
 
 
 MIXES = [(s, r, p) for s in (None, 'DNA', 'QUAL', 'QNAME')

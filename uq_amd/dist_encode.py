@@ -48,6 +48,29 @@ class ShardedSession(Session):
         self.dist, self.rank, self.world = uqdist._world()
         if self.rank != 0: args.quiet = True
 
+    # ------------------------------------------------------------------ errors are agreed on
+    def agree(self, message=None):
+        """Collective: every rank calls this after a step that can fail on ONE rank only (I/O, a record straddling the
+        slack, an uncoded symbol); `message` = this rank's error text or None.  If any rank failed, EVERY rank raises the
+        same UqError -- the text of the lowest failing rank -- instead of leaving its peers in the next collective."""
+        sh = uqdist.Shard(self.be, 0, 0, self.group)
+        flags = sh.gather_ints(0 if message is None else 1)
+        if any(flags):
+            msgs = sh.gather_bytes((message or '').encode('utf-8', 'replace'))
+            error(msgs[flags.index(1)].decode('utf-8', 'replace'))
+
+    def guarded(self, fn, what):
+        """Run a rank-local step; whatever it raises is agreed on (see `agree`).  Returns fn()'s value."""
+        res, msg = None, None
+        try:
+            res = fn()
+        except UqError as e:
+            msg = str(e)
+        except (OSError, RuntimeError) as e:         # I/O, HIP / ABI errors (UqHipError is a RuntimeError)
+            msg = 'ERROR: rank %d failed while %s: %s' % (self.rank, what, e)
+        self.agree(msg)
+        return res
+
     # ------------------------------------------------------------------ load
     def load(self, path):
         ops, ctx, t = self.ops, self.ctx, self.ctx.torch
@@ -57,12 +80,21 @@ class ShardedSession(Session):
         lo, hi = size * self.rank // self.world, size * (self.rank + 1) // self.world
         a = max(lo - 1, 0)                         # a newline at lo - 1 makes `lo` a line start
         b = min(size, hi + SLACK)
-        chunk = self.io.file_to_device(path, a, b - a)
+        chunk = self.guarded(lambda: self.io.file_to_device(path, a, b - a), 'reading ' + path)
         # line starts inside [lo, hi): one per newline in [lo - 1, hi - 1), plus the start of the file
         span = max(0, (hi - 1) - a)
         mine = (ops.count_lines(ctx, chunk[:span]) if span else 0) + (1 if self.rank == 0 else 0)
         sh = uqdist.Shard(self.be, 0, 0, self.group)
         per_rank = sh.gather_ints(mine)
+        # A file that does not end in '\n' has one line start more than it has lines (`wc -l` counts newlines, uq.py:85):
+        # the unterminated tail is nobody's line -- the rank that owns its start drops it, as a GLOBAL decision (the last
+        # rank sees the last byte; every rank applies the same correction), so that the count below is the single-GPU
+        # CLI's and the reference's, and so is the message.
+        ends_nl = sh.gather_ints(int(chunk[-1]) == 10 if (self.rank == self.world - 1 and chunk.numel()) else 0)[self.world - 1]
+        if not ends_nl:
+            owner = max(r for r in range(self.world) if per_rank[r] > 0)
+            per_rank[owner] -= 1
+            if owner == self.rank: mine -= 1
         total_lines = sum(per_rank)
         if total_lines % 4 != 0:
             error('ERROR: The FASTQ file provided contains' + str(total_lines) + 'rows, which is not divisible by 4!')
@@ -79,8 +111,8 @@ class ShardedSession(Session):
         nl = ops.count_lines(ctx, chunk)
         ls = ops.index_lines(ctx, chunk, nl)                       # ls[k] = chunk offset after the k-th newline, ls[0] = 0
         k0 = j0 + (0 if self.rank == 0 else 1)
-        if n and k0 + 4 * n > nl:
-            error('ERROR: a record of more than %d bytes straddles a shard boundary' % SLACK)
+        self.agree('ERROR: a record of more than %d bytes straddles a shard boundary (rank %d)' % (SLACK, self.rank)
+                   if (n and k0 + 4 * n > nl) else None)
         if n:
             ends = ctx.to_numpy(ls[k0:k0 + 4 * n + 1:4 * n], np.uint64)
             start, end = int(ends[0]), int(ends[1])
@@ -246,8 +278,9 @@ class ShardedSession(Session):
     def _encode(self, variable):
         if self.total == 0:                                        # a rank without reads still owns (empty) tables
             e = self.ctx.empty(0)
+            self.agree(None)
             return ((e, 0, self.d['dna_bytes_per_row']), (e, 0, self.d['quality_bytes_per_row']))
-        return super()._encode(variable)
+        return self.guarded(lambda: Session._encode(self, variable), 'packing')     # an uncoded symbol is one rank's finding
 
     # ------------------------------------------------------------------ container
     def write_container(self, path):
@@ -275,22 +308,29 @@ class ShardedSession(Session):
         end += -end % tarfile.RECORDSIZE
         tmp = path + '.part'
         mtime = self.shard.reduce([int(time.time())], 'min')[0]
-        if self.rank == 0:
-            fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
-            os.ftruncate(fd, end)                                  # sparse zeros: tar padding and end blocks are already there
+        def create():
+            if self.rank != 0: return None
+            f = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+            os.ftruncate(f, end)                                   # sparse zeros: tar padding and end blocks are already there
             for name, header, hpos, _, size in layout:
                 ti = tarfile.TarInfo(name); ti.size = size; ti.mtime = mtime
-                os.pwrite(fd, ti.tobuf(tarfile.DEFAULT_FORMAT, tarfile.ENCODING, 'surrogateescape') + header, hpos)
-        self.shard.reduce([0], 'sum')                              # barrier: the file exists at its final size
-        if self.rank != 0:
-            fd = os.open(tmp, os.O_WRONLY)
+                os.pwrite(f, ti.tobuf(tarfile.DEFAULT_FORMAT, tarfile.ENCODING, 'surrogateescape') + header, hpos)
+            return f
+        fd = self.guarded(create, 'creating ' + tmp)               # also the barrier: the file exists at its final size
+
+        def put():
+            f = fd if self.rank == 0 else os.open(tmp, os.O_WRONLY)
+            try:
+                for name, _, _, ppos, _ in layout[1:]:
+                    for off, piece in self.members[name][2]:
+                        self.io.device_to_fd(piece, f, ppos + off)
+            finally:
+                os.close(f)
         try:
-            for name, _, _, ppos, _ in layout[1:]:
-                for off, piece in self.members[name][2]:
-                    self.io.device_to_fd(piece, fd, ppos + off)
-        finally:
-            os.close(fd)
-        self.shard.reduce([0], 'sum')                              # barrier: all pieces are in place
+            self.guarded(put, 'writing ' + tmp)                    # also the barrier: all pieces are in place
+        except UqError:
+            if self.rank == 0 and os.path.exists(tmp): os.remove(tmp)
+            raise
         if self.rank == 0:
             os.replace(tmp, path)
 
@@ -300,29 +340,42 @@ class ShardedSession(Session):
         """uq.py:926-1058 over the ranks: rank r decodes reads [n r / W, n (r + 1) / W) of the stored order -- key slices
         and raw row slices come from the file, the tables the keys index are loaded by every rank -- and writes its
         text in place; the offsets are an all-gather of the text sizes.  The result is the single-GPU decoder's output."""
-        members, config = self.open_container()
-        if not self.device_text_possible(config):
-            error('ERROR: this QNAME layout decodes on one GPU only (python -m uq_amd.uq --decode)')
-        if 'DNA.raw' in members: n = self.member_rows(members, 'DNA.raw', (config['pattern'] or ['0.1', '0.1'])[0])
-        else: n = self.member_rows(members, 'DNA.key')
-        lo, hi = n * self.rank // self.world, n * (self.rank + 1) // self.world
-        DNA, QUAL, d_cols = self.load_tables(members, config, rows=(lo, hi))
-        text = self.decode_text(config, DNA, QUAL, d_cols) if hi > lo else self.ctx.torch.empty(0, dtype=self.ctx.torch.uint8, device=self.ctx.device)
+        def my_text():
+            # everything here is rank-local (a damaged key entry or a row without sentinel shows up on the rank that owns
+            # that slice only): `guarded` turns it into the same UqError on every rank
+            members, config = self.open_container()
+            if not self.device_text_possible(config):
+                error('ERROR: this QNAME layout decodes on one GPU only (python -m uq_amd.uq --decode)')
+            if 'DNA.raw' in members: n = self.member_rows(members, 'DNA.raw', (config['pattern'] or ['0.1', '0.1'])[0])
+            else: n = self.member_rows(members, 'DNA.key')
+            lo, hi = n * self.rank // self.world, n * (self.rank + 1) // self.world
+            DNA, QUAL, d_cols = self.load_tables(members, config, rows=(lo, hi))
+            if hi > lo: return self.decode_text(config, DNA, QUAL, d_cols), lo, n
+            return self.ctx.torch.empty(0, dtype=self.ctx.torch.uint8, device=self.ctx.device), lo, n
+        text, lo, n = self.guarded(my_text, 'decoding ' + str(self.args.input))
         shard = uqdist.Shard(self.be, lo, n, self.group)
         sizes = shard.gather_ints(int(text.numel()))
         offset, total = sum(sizes[:self.rank]), sum(sizes)
         tmp = out_path + '.part'
-        if self.rank == 0:
-            fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
-            os.ftruncate(fd, total)
-        shard.reduce([0], 'sum')                                   # barrier: the file exists at its final size
-        if self.rank != 0:
-            fd = os.open(tmp, os.O_WRONLY)
+
+        def create():
+            if self.rank != 0: return None
+            f = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+            os.ftruncate(f, total)
+            return f
+        fd = self.guarded(create, 'creating ' + tmp)               # also the barrier: the file exists at its final size
+
+        def put():
+            f = fd if self.rank == 0 else os.open(tmp, os.O_WRONLY)
+            try:
+                if text.numel(): self.io.device_to_fd(text, f, offset)
+            finally:
+                os.close(f)
         try:
-            if text.numel(): self.io.device_to_fd(text, fd, offset)
-        finally:
-            os.close(fd)
-        shard.reduce([0], 'sum')                                   # barrier: all pieces are in place
+            self.guarded(put, 'writing ' + tmp)                    # also the barrier: all pieces are in place
+        except UqError:
+            if self.rank == 0 and os.path.exists(tmp): os.remove(tmp)
+            raise
         if self.rank == 0:
             os.replace(tmp, out_path)
 
