@@ -125,6 +125,29 @@ int uq_pack_stats(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_star
                   uint64_t nreads, const uq_pack_params* h_guess, uint8_t* d_dna, uint8_t* d_qual, uint64_t* d_bad,
                   uq_stats* d_stats, int* h_fused);
 
+/* ---- index + a1 + a3 / a4 in ONE pass over the stream: newline census, record index, pass-1 statistics and pack.
+ * Replaces, in a single read of the FASTQ, `wc -l` and the line iteration (uq.py:85, 132-137), the pass-1 loop
+ * (uq.py:366-388, 415-425) and encoder_fixed / encoder_variable (uq.py:108-254); same outputs as uq_count_lines +
+ * uq_index_lines + uq_stats_accumulate + uq_pack, byte for byte, when the flags below say so.
+ * h_guess: the pack parameters to speculate with (a sample of this file, the previous file; max_record_bytes and
+ * avg_record_bytes size the tiles).  max_reads: capacity of d_dna / d_qual in rows; d_line_start holds 4 * max_reads + 1
+ * entries.  d_stats: initialised by uq_stats_init, or NULL to skip the statistics.  On return (synchronous):
+ *   launched  0: this geometry has no one-pass kernel (anything but 2-bit A/C/G/T with one contiguous quality range, the
+ *                Q9 carry case, records longer than ~1 KB): NOTHING ran, use the multi-pass entry points;
+ *   nlines    newlines in the buffer (= uq_count_lines);
+ *   index_ok  d_line_start[0 .. nlines] is the record index (= uq_index_lines); 0: more lines than the capacity, a tile with
+ *                more than 1500 lines, or the launch gave itself up (a workgroup waited too long for its predecessors);
+ *   stats_ok  d_stats is complete (= uq_stats_accumulate over all nlines / 4 reads); 0 when a record could not be seen
+ *                whole (longer than the guess allowed) or a read is longer than h_guess->dna_max: run uq_stats_accumulate;
+ *   tables_ok every read was packed with the guess and met no symbol or length outside it: IF the decisions derived from
+ *                the statistics equal the guess, d_dna / d_qual rows [0, nlines / 4) are uq_pack's; otherwise run uq_pack. */
+typedef struct uq_encode_result {
+    uint64_t nlines;
+    int32_t launched, index_ok, stats_ok, tables_ok;
+} uq_encode_result;
+int uq_encode_stream(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, const uq_pack_params* h_guess, uint64_t max_reads,
+                     uint64_t* d_line_start, uint8_t* d_dna, uint8_t* d_qual, uq_stats* d_stats, uq_encode_result* h_out);
+
 /* ---- a9 / a11: the eight --pattern byte layouts.  Replaces numpy.rot90 + ascontiguousarray /
  * asfortranarray + the payload write of numpy.save (uq.py:263-270) and, inverse, numpy.load +
  * rot90(-k) (uq.py:943-945).  pattern_id = 2*k + (order == '.2'), k = rotations (so '0.1'=0,

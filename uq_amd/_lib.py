@@ -28,6 +28,10 @@ class PackParams(C.Structure):
                 ('max_record_bytes', C.c_int32), ('dna_max', C.c_int32), ('avg_record_bytes', C.c_int32)]
 
 
+class EncodeResult(C.Structure):
+    _fields_ = [('nlines', C.c_uint64), ('launched', C.c_int32), ('index_ok', C.c_int32), ('stats_ok', C.c_int32), ('tables_ok', C.c_int32)]
+
+
 class UnpackParams(C.Structure):
     _fields_ = [('base_char', C.c_uint8 * 256), ('qual_char', C.c_uint8 * 256), ('qual_n_base', C.c_uint8 * 256),
                 ('bits_per_base', C.c_int32), ('bits_per_quality', C.c_int32), ('variable', C.c_int32),
@@ -84,6 +88,7 @@ SIGNATURES = {
     'uq_first_occurrence': [_vp, _vp, _vp, _u64, _u64, _u64, _vp],
     'uq_pack': [_vp, _vp, _vp, _u64, _u64, _P(PackParams), _vp, _vp, _vp],
     'uq_pack_stats': [_vp, _vp, _vp, _u64, _u64, _P(PackParams), _vp, _vp, _vp, _vp, _P(_int)],
+    'uq_encode_stream': [_vp, _vp, _u64, _P(PackParams), _u64, _vp, _vp, _vp, _vp, _P(EncodeResult)],
     'uq_pattern': [_vp, _vp, _u64, _u32, _int, _vp],
     'uq_unpattern': [_vp, _vp, _u64, _u32, _int, _vp],
     'uq_argsort_rows': [_vp, _vp, _u64, _u32, _vp],

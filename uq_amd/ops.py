@@ -133,6 +133,35 @@ def pack_stats(ctx, buf, line_start, first_read, nreads, guess):
     return (dna, qual, bad, st) if fused.value else None
 
 
+class Encoded:
+    """What uq_encode_stream left behind: nlines, line_start (or None), d_stats (or None), (dna, qual) (or None)."""
+    __slots__ = ('nlines', 'line_start', 'stats', 'tables', 'guess')
+
+
+def encode_stream(ctx, buf, guess, max_reads, with_stats=True):
+    """One pass over the FASTQ in HBM (uq_encode_stream): census + record index + pass-1 statistics + pack with the GUESSED
+    parameters.  Returns None when this geometry has no one-pass kernel (nothing ran), else an `Encoded` whose parts are
+    None where the pass could not vouch for them (the caller then runs the multi-pass entry point for that part)."""
+    from ._lib import EncodeResult
+    t = ctx.torch
+    max_reads = int(max_reads)
+    ls = t.empty(4 * max_reads + 1, dtype=t.int64, device=ctx.device)
+    dna = t.empty(max_reads * guess.dna_bytes_per_row, dtype=t.uint8, device=ctx.device)
+    qual = t.empty(max_reads * guess.quality_bytes_per_row, dtype=t.uint8, device=ctx.device)
+    st = stats_new(ctx) if with_stats else None
+    res = EncodeResult()
+    call('uq_encode_stream', ctx.h, _p(buf), buf.numel(), C.byref(guess), max_reads, _p(ls), _p(dna), _p(qual), _p(st), C.byref(res))
+    if not res.launched:
+        return None
+    e = Encoded()
+    e.nlines, e.guess = int(res.nlines), guess
+    e.line_start = ls[:e.nlines + 1] if res.index_ok else None
+    e.stats = st if (with_stats and res.stats_ok) else None
+    n = e.nlines // 4
+    e.tables = (dna[:n * guess.dna_bytes_per_row], qual[:n * guess.quality_bytes_per_row]) if res.tables_ok else None
+    return e
+
+
 def same_pack_params(a, b):
     """Do two uq_pack_params describe the same encoding (everything but the tile-sizing hint)?"""
     if (a.bits_per_base, a.bits_per_quality, a.variable, a.dna_bytes_per_row, a.quality_bytes_per_row, a.dna_max) != \
