@@ -7,11 +7,13 @@
 Workload (config.workload): 10 M x 150 bp synthetic FASTQ ("synth-v1", seed 20261005) PER GPU, resident
 in HBM before the timed region, `--sort None --raw DNA QUAL QNAME --pattern 0.1 0.1`: weak scaling,
 reads are sharded record-parallel, rank r owns reads [r*10M, (r+1)*10M).
-One step = one pass of the hot path over the shard:
+One step = one pass of the hot path over the shard, everything from the raw bytes to the packed tables:
     newline census -> record index -> pass-1 statistics (256x256 histogram, lengths, checks)
     -> [N > 1: all-reduce of the statistics over RCCL, the path's only exchange without --sort]
     -> alphabet / N-trick / bit-width decisions on the host (uq.py:448-545)
     -> DNA 2-bit + QUAL 6-bit pack into the raw tables (pattern 0.1 = the tables as packed).
+    (--one-pass: decisions guessed from the shard's first 65536 reads -> uq_encode_stream = census + index + statistics +
+     pack in ONE read of the stream -> decisions from the whole shard's statistics; tables kept iff they equal the guess.)
 The QNAME passes (on the device in the CLI, tools/bench_e2e.py times them) are not part of this
 step.  `value` = FASTQ bytes of all ranks / time, MAX over ranks.
 Besides the contract fields the JSON line carries `roofline` (pack kernel, HIP-event timed inside the
@@ -90,8 +92,9 @@ def main():
     ap.add_argument('--cpu-sample', type=int, default=100_000, help='reads timed on the host for cpu_baseline (0 = skip)')
     ap.add_argument('--force-dist', action='store_true', help='initialise the process group and run the collectives even with one rank')
     ap.add_argument('--one-pass', action='store_true',
-                    help='pack speculatively (previous step\'s decisions) during the statistics pass and verify afterwards: one pass over the '
-                         'stream less, +5 %% on configs[1], but the fused kernel is latency-bound (DESIGN.md 4); not the default')
+                    help='uq_encode_stream: census + record index + statistics + speculative pack (decisions guessed from the shard\'s first '
+                         '65536 reads, verified against the whole shard\'s statistics) in ONE read of the stream.  Fewer bytes, but on MI355X the '
+                         'fused kernel is currently slower than the four separate ones (DESIGN.md 4): not the default')
     ap.add_argument('--workload', default='cfg2', choices=['cfg2', 'cfg5-notricks', 'cfg5-ntrick'],
                     help='cfg2 = BASELINE configs[1] (the bench line the driver reads); cfg5-* = configs[4]: variable length 36-301 bp '
                          'with 1%% N, 3-bit ACGNT path (--notricks) or 2-bit N-trick path -- parity/measurement extras')
@@ -147,40 +150,48 @@ def main():
             return uqdist.allreduce_stats(ctx, st)
         return ops.stats_fetch(ctx, st)
 
-    def step(timed):
-        nlines = ops.count_lines(ctx, d_buf)
-        nreads = nlines // 4
-        ls = ops.index_lines(ctx, d_buf, nlines)              # record index
-        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-        # One-pass form: pack with the previous step's decisions WHILE counting the pass-1 statistics (uq_pack_stats);
-        # the real decisions are then derived from those statistics and the tables kept only if they agree.
-        guess = state.get('params') if args.one_pass else None
-        spec = None
-        if guess is not None:
-            e0.record()
-            spec = ops.pack_stats(ctx, d_buf, ls, 0, nreads, guess)
-            e1.record()
-        if spec is not None:
-            st = spec[3]
-        else:
-            st = ops.stats_new(ctx)
-            ops.stats_accumulate(ctx, st, d_buf, ls, 0, nreads)
-        hs = fetch(st)
-        if hs.incomplete:                                     # the speculative pass could not count everything
-            spec = None
-            st = ops.stats_new(ctx)
-            ops.stats_accumulate(ctx, st, d_buf, ls, 0, nreads)
-            hs = fetch(st)
-        if hs.bad_plus is not None or hs.bad_len is not None:
-            raise RuntimeError('malformed FASTQ record')
+    def decide_and_params(hs, nreads):
         d = host_decide(hs, notricks=notricks)
         p = ops.make_pack_params(d['bases'], d['qualities'], d['N_qual'], d['bits_per_base'], d['bits_per_quality'],
                                  d['variable_read_lengths'], d['dna_bytes_per_row'], d['quality_bytes_per_row'],
                                  d['dna_max'], hs.max_record_bytes, avg_record_bytes=fastq_bytes // max(nreads, 1))
-        if spec is not None and ops.same_pack_params(p, guess):
-            dna, qual, bad = spec[:3]
-            kernel = 'pack_tile_kernel<STATS> (pack + pass-1 statistics in one pass)'
+        return d, p
+
+    def step(timed):
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        enc = None
+        if args.one_pass:
+            # ONE read of the stream (uq_encode_stream): census + record index + pass-1 statistics + pack with decisions guessed
+            # from the head of this shard (its first 65536 reads, statistics pass of their own -- part of the step), verified
+            # below against the statistics of the whole shard
+            g = ops.head_guess(ctx, d_buf, notricks=notricks)
+            if g is not None:
+                guess, rpb = g
+                e0.record()
+                enc = ops.encode_stream(ctx, d_buf, guess, int(fastq_bytes * rpb * 1.02) + 1024)
+                e1.record()
+        if enc is not None and enc.line_start is not None:
+            nlines, ls = enc.nlines, enc.line_start
         else:
+            nlines = enc.nlines if enc is not None else ops.count_lines(ctx, d_buf)
+            ls = ops.index_lines(ctx, d_buf, nlines)              # record index
+            enc = None
+        nreads = nlines // 4
+        if enc is not None and enc.stats is not None:
+            st = enc.stats
+        else:
+            st = ops.stats_new(ctx)
+            ops.stats_accumulate(ctx, st, d_buf, ls, 0, nreads)
+        hs = fetch(st)                                            # N > 1: the all-reduce of the statistics
+        if hs.bad_plus is not None or hs.bad_len is not None:
+            raise RuntimeError('malformed FASTQ record')
+        d, p = decide_and_params(hs, nreads)
+        if enc is not None and enc.tables is not None and enc.stats is not None and ops.same_pack_params(p, enc.guess):
+            dna, qual = enc.tables
+            bad = None
+            kernel = 'encode_tile_kernel (census + record index + pass-1 statistics + pack in one pass over the stream)'
+        else:
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
             dna, qual, bad = ops.pack(ctx, d_buf, ls, 0, nreads, p)
             e1.record()
@@ -210,18 +221,20 @@ def main():
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         total_bytes, total_reads = int(tot[0].item()), int(tot[1].item())
 
-    if ops.bad_index(state['bad']) is not None:
+    if state['bad'] is not None and ops.bad_index(state['bad']) is not None:
         raise RuntimeError('pack reported an uncoded symbol at read %d' % ops.bad_index(state['bad']))
     d = state['d']
     nreads = state['nreads']
     kernel = pack_events[-1][2]
-    one_pass = 'STATS' in kernel
+    one_pass = kernel.startswith('encode_tile_kernel')
     pack_ms = float(np.mean([a.elapsed_time(b) for a, b, k in pack_events if k == kernel]))
-    algo_bytes = fastq_bytes + nreads * (d['dna_bytes_per_row'] + d['quality_bytes_per_row'])
+    # SURVEY.md 8d bytes per read: the record read once + both rows written (+ the 32 B of line offsets the one-pass kernel
+    # also writes: it is the record index too)
+    algo_bytes = fastq_bytes + nreads * (d['dna_bytes_per_row'] + d['quality_bytes_per_row'] + (32 if one_pass else 0))
     achieved = algo_bytes / 1e9 / (pack_ms / 1e3)
 
     traffic = None
-    tpath = os.path.join(HERE, 'profiles', 'pack_stats_traffic.json' if one_pass else 'pack_traffic.json')
+    tpath = os.path.join(HERE, 'profiles', 'encode_traffic.json' if one_pass else 'pack_traffic.json')
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
@@ -230,8 +243,8 @@ def main():
         except Exception:
             traffic = None
 
-    mode = (' [one-pass: stats and pack share one pass over the stream, packed with the previous step\'s decisions and kept only '
-            'because this step\'s statistics gave the same decisions]' if one_pass else ' [two passes]')
+    mode = (' [ONE pass over the stream: decisions guessed from the shard\'s first 65536 reads, tables kept only because the whole '
+            'shard\'s statistics -- counted in the same pass -- gave the same decisions]' if one_pass else ' [four passes]')
     result = {
         'metric': 'FASTQ encode MB/s (150bp synthetic; bit-exact tables vs reference)',
         'value': round(total_bytes / 1e6 / (dt / args.steps), 1), 'unit': 'MB/s',

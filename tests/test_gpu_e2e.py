@@ -289,24 +289,33 @@ def test_cli_fuzz_against_oracle(ctx, tmp_path, seed):
 
 
 def test_cli_one_pass_speculation(ctx, tmp_path):
-    """--one-pass: the second encode of a process packs during the statistics pass with the first one's decisions; a file
-    whose decisions differ falls back to the separate pack.  The output never depends on the path taken."""
-    uq.Session.last_params = None
+    """--one-pass: the encoder reads the stream once (uq_encode_stream) and packs speculatively with decisions guessed from
+    the head of the file itself; a wrong guess falls back to the separate pack.  The default never speculates.  The output
+    never depends on the path taken."""
     a = synth.fastq(20261003 + 50, 3000, 60)
-    b = synth.fastq(20261003 + 51, 2500, 60)                                   # same alphabets and length: the guess holds
-    c = synth.fastq(20261003 + 52, 2000, (30, 61), n_rate=2)                   # variable length, N: the guess fails
-    paths = []
-    for i, fq in enumerate((a, b, c, b)):
-        inp = tmp_path / ('in%d.fastq' % i); inp.write_bytes(fq)
-        out = tmp_path / ('out%d.uQ' % i)
-        args = uq.validate_args(uq.build_parser().parse_args(['-i', str(inp), '-o', str(out), '--quiet', '--one-pass', '--raw', 'DNA', 'QUAL', 'QNAME']))
-        s = uq.Session(args, ctx=ctx)
-        s.encode()
-        paths.append(s.pack_path)
-        cfg, members = O.read_tar(str(out))
-        ocfg, omembers, _ = O.encode(fq, raw=['DNA', 'QUAL', 'QNAME'])
-        assert all(members[k] == omembers[k] for k in omembers)
-    assert paths == ['two-pass', 'one-pass', 'two-pass', 'two-pass']
+    b = synth.fastq(20261003 + 51, 2500, 60)                                   # same alphabets and length as a: a's decisions hold
+    c = synth.fastq(20261003 + 52, 2000, (30, 61), n_rate=2)                   # variable length, N: they do not
+    # d: the head (first 65536 reads) is ACGT only, an N turns up later: the head's guess fails, the fallback packs
+    d = synth.fastq(20261003 + 53, 70_000, 40)
+    k = d.rfind(b'\n', 0, len(d) - 200)
+    k = d.rfind(b'\n', 0, d.rfind(b'\n+\n', 0, k))                             # start of a SEQ line near the end
+    d = d[:k + 1] + b'N' + d[k + 2:]
+    want = {}
+    for mode, expect in ((['--one-pass'], ['one-pass', 'one-pass', 'one-pass', 'one-pass', 'two-pass']),
+                         ([], ['two-pass'] * 5), (['--multi-pass'], ['two-pass'] * 5)):
+        uq.Session.last_params = None
+        paths = []
+        for i, fq in enumerate((a, b, c, b, d)):
+            inp = tmp_path / ('in%d.fastq' % i); inp.write_bytes(fq)
+            out = tmp_path / ('out%d.uQ' % i)
+            args = uq.validate_args(uq.build_parser().parse_args(['-i', str(inp), '-o', str(out), '--quiet', '--raw', 'DNA', 'QUAL', 'QNAME'] + mode))
+            s = uq.Session(args, ctx=ctx)
+            s.encode()
+            paths.append(s.pack_path)
+            cfg, members = O.read_tar(str(out))
+            if i not in want: want[i] = O.encode(fq, raw=['DNA', 'QUAL', 'QNAME'])[1]
+            assert all(members[k] == want[i][k] for k in want[i]), (mode, i)
+        assert paths == expect, (mode, paths)
     uq.Session.last_params = None
 
 

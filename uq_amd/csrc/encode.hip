@@ -28,6 +28,7 @@
 #include "common.h"
 #include "swar.h"
 #include "histo.h"
+#include <stdlib.h>
 
 namespace {
 constexpr int EN_THREADS = 256;
@@ -49,6 +50,7 @@ struct EncGeom {
     uint32_t rmax;                 // reads per batch: what the row images hold
     uint32_t img_d, img_q;         // LDS bytes of the two row images (16-byte multiples, room for the skew)
     uint32_t q_addlo, q_addhi, n_char, n_code;      // lookup-free conversion, as pack.hip
+    uint32_t debug;                // timing experiments (UQ_ENC_DEBUG): bit 0 = no look-back (results are wrong)
 };
 
 struct EncCtl {
@@ -82,45 +84,96 @@ __device__ __noinline__ void store_image(uint8_t* gdst, const uint8_t* img, uint
     }
 }
 
-// Wave 0: the number of newlines in front of tile t, from the status words of the tiles in front of it.
-// Status word: flag << 62 | value; flag 1 = value is the tile's own count, 2 = value is the count up to and including it.
-__device__ __forceinline__ uint64_t lookback(unsigned long long* __restrict__ status, EncCtl* __restrict__ ctl, uint64_t t, uint32_t count,
-                                             uint32_t lane, bool& dead) {
-    uint64_t excl = 0;
-    int64_t pos = (int64_t)t - 1;
+// The number of newlines in front of tile t: decoupled look-back on TWO levels.  One level (every tile sums the counts of
+// the tiles in front of it back to the nearest tile that already knows its own answer) moves 64 tiles per memory round
+// trip: 207 000 tiles of a 3.4 GB shard at ~1.2 us a hop is slower than the rest of the kernel (measured: +1.2 ms).  So
+// tiles are taken in groups of 64:
+//   A[t]   tile t's own count            flag 1 << 62 | count          written once, by the tile
+//   GS[g]  group g's running sum         arrived << 40 | sum           every tile adds 1 << 40 | count; complete at 64 arrivals
+//   GP[g]  count up to and including g   flag 1 << 62 | value          written by the group's last arriver after ITS look-back
+// A tile adds up (1) the counts of the tiles in front of it inside its group (one wave-load of A) and (2) the groups in
+// front of its group, newest first, until one has its GP (one wave-load each of GP and GS covers 64 groups = 4096 tiles).
+// Every word is one self-contained 8-byte granule read and written with relaxed agent-scope atomics; every spin is bounded.
+constexpr uint32_t EN_GROUP = 64;
+constexpr uint32_t EN_GWIN = 16;                          // groups asked about per round trip (a resident grid spans 12)
+constexpr unsigned long long EN_SUM40 = (1ull << 40) - 1;
+constexpr uint32_t EN_GSTRIDE = 16;                       // u64 words per group record: GS and GP of a group share a 128-byte line of
+                                                          // their own -- 768 tiles arriving at counters that sit in ONE line serialise
+                                                          // at that line's memory channel (measured: 37 us per round of the grid)
+struct LookBack { unsigned long long *A, *GR; };         // GR[g * EN_GSTRIDE + 0] = GS[g], + 1 = GP[g]
+
+__device__ __forceinline__ bool lb_spin(uint32_t& spins, EncCtl* ctl) {
+    ++spins;
+    if (spins > EN_SPIN_MAX || ((spins & 255u) == 0 && __hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) return true;
+    __builtin_amdgcn_s_sleep(1);
+    return false;
+}
+
+// thread 0, as soon as the tile's count is known: publish it, join the group.  Returns GS[g] as it was before.
+__device__ __forceinline__ unsigned long long lb_arrive(const LookBack& lb, uint64_t t, uint32_t count) {
+    __hip_atomic_store(&lb.A[t], (1ull << 62) | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __hip_atomic_fetch_add(&lb.GR[(t / EN_GROUP) * EN_GSTRIDE], (1ull << 40) | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// wave 0; `old` = lb_arrive's return value in lane 0
+__device__ __forceinline__ uint64_t lookback(const LookBack& lb, EncCtl* __restrict__ ctl, uint64_t t, uint64_t ntiles, uint32_t count,
+                                             unsigned long long old, uint32_t lane, bool& dead) {
+    const uint64_t g = t / EN_GROUP;
+    const uint32_t j = (uint32_t)(t % EN_GROUP);
+    const uint64_t left = ntiles - g * EN_GROUP;
+    const uint32_t n_g = left < EN_GROUP ? (uint32_t)left : EN_GROUP;
     uint32_t spins = 0;
     dead = false;
-    while (pos >= 0) {
+    uint64_t own = 0, exg = 0;
+    int64_t pos = (int64_t)g - 1;
+    bool need_own = j != 0, need_groups = pos >= 0;
+    // all three wave-loads of a round are in flight together; in the steady state one round answers both questions
+    while (need_own || need_groups) {
         const int64_t idx = pos - (int64_t)lane;
-        const unsigned long long s = idx >= 0 ? __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 62);
-        const uint32_t flag = (uint32_t)(s >> 62);
-        const unsigned long long bp = __ballot(flag == 2), bi = __ballot(flag == 0);
-        const uint32_t fp = bp ? (uint32_t)__ffsll((long long)bp) - 1u : 64u, fi = bi ? (uint32_t)__ffsll((long long)bi) - 1u : 64u;
-        if (fi < fp) {                              // a tile this side of the nearest inclusive count has published nothing yet
-            ++spins;
-            if (spins > EN_SPIN_MAX || ((spins & 255u) == 0 && __hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-                dead = true;
-                break;
-            }
-            __builtin_amdgcn_s_sleep(2);
-            continue;
+        unsigned long long a = 1ull << 62, gp = 1ull << 62, gs = 0;
+        if (need_own && lane < j) a = __hip_atomic_load(&lb.A[g * EN_GROUP + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (need_groups && idx >= 0 && lane < EN_GWIN) {
+            gp = __hip_atomic_load(&lb.GR[idx * EN_GSTRIDE + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            gs = __hip_atomic_load(&lb.GR[idx * EN_GSTRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        const uint32_t last = fp < 64 ? fp : 63;
-        excl += wave_sum<uint64_t>(lane <= last ? (uint64_t)(s & EN_VALUE) : 0ull);
-        if (fp < 64) break;
-        pos -= 64;
+        bool progress = false;
+        if (need_own && !__ballot((a >> 62) == 0)) {                       // (1) the tiles in front, inside the group
+            own = wave_sum<uint64_t>(lane < j ? (uint64_t)(a & EN_VALUE) : 0ull);
+            need_own = false; progress = true;
+        }
+        if (need_groups) {                                                 // (2) the groups in front, 64 per round trip
+            uint32_t flag = 2;
+            uint64_t value = 0;
+            if (lane >= EN_GWIN) flag = 3;                                     // not asked
+            else if (idx >= 0) {
+                if (gp >> 62) value = gp & EN_VALUE;
+                else if ((uint32_t)(gs >> 40) == EN_GROUP) { flag = 1; value = gs & EN_SUM40; }   // groups in front of another are full ones
+                else flag = 0;
+            }
+            const unsigned long long bp = __ballot(flag == 2), bi = __ballot(flag == 0);
+            const uint32_t fp = bp ? (uint32_t)__ffsll((long long)bp) - 1u : 64u, fi = bi ? (uint32_t)__ffsll((long long)bi) - 1u : 64u;
+            if (fi >= fp || fi == 64) {                                    // no incomplete group this side of the nearest GP
+                exg += wave_sum<uint64_t>(lane <= (fp < 64 ? fp : EN_GWIN - 1) && lane < EN_GWIN ? value : 0ull);
+                if (fp < 64) need_groups = false; else { pos -= EN_GWIN; need_groups = pos >= 0; }
+                progress = true;
+            }
+        }
+        if (!progress && lb_spin(spins, ctl)) { dead = true; break; }
     }
+    old = __shfl(old, 0, 64);
+    const bool last = (uint32_t)(old >> 40) == n_g - 1;                    // this tile completes its group
+    const uint64_t total_g = (old & EN_SUM40) + count;
     if (lane == 0) {
         if (dead) __hip_atomic_store(&ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else __hip_atomic_store(&status[t], (2ull << 62) | (excl + count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else if (last) __hip_atomic_store(&lb.GR[g * EN_GSTRIDE + 1], (1ull << 62) | (exg + total_g), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    return excl;
+    return exg + own;
 }
 
 // LDS carve (dynamic): [16 B guard][stage: tile + halo + 32][DNA image][QUAL image][E: line starts][misc 64 B][count tables]
 template <int BQ, bool NTRICK, bool STATS>
 __global__ __launch_bounds__(EN_THREADS, STATS ? 3 : 4) void encode_tile_kernel(const uint4* __restrict__ abuf, EncGeom g,
-                                                                               unsigned long long* __restrict__ status, EncCtl* __restrict__ ctl,
+                                                                               LookBack lb, EncCtl* __restrict__ ctl,
                                                                                uint64_t* __restrict__ line_start, uint8_t* __restrict__ dna,
                                                                                uint8_t* __restrict__ qual, uq_stats* __restrict__ st, uint32_t win) {
     constexpr int BD = 2;
@@ -173,7 +226,8 @@ __global__ __launch_bounds__(EN_THREADS, STATS ? 3 : 4) void encode_tile_kernel(
 #pragma unroll
         for (uint32_t i = 0; i < EN_THREADS / 64; ++i) { const uint32_t x = misc[i]; if (i < w) base += x; count += x; }
         const uint32_t nhalo = misc[4];
-        if (tid == 0) __hip_atomic_store(&status[t], (1ull << 62) | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long arrived = 0;
+        if (tid == 0) arrived = lb_arrive(lb, t, count);                       // published as early as possible
         // ---- line starts (stage offsets of the bytes after the newlines, stream order) and the bytes themselves -> LDS
         const uint32_t shift = t == 0 ? 1u : 0u;                               // tile 0: entry 0 = the start of the stream
         const uint32_t ex[EN_NV + 1] = {base + (i01 & 0xFFFFu) - c0, base + T0 + (i01 >> 16) - c1, base + T0 + T1 + (i23 & 0xFFFFu) - c2,
@@ -193,13 +247,16 @@ __global__ __launch_bounds__(EN_THREADS, STATS ? 3 : 4) void encode_tile_kernel(
 #pragma unroll
         for (int u = 0; u < EN_NV; ++u) ((uint4*)stage)[vl0 + u * 64] = v[u];
         if (w == EN_THREADS / 64 - 1) ((uint4*)stage)[EN_TV + lane] = v[EN_NV];
-        issue(t + S);                                                          // the next tile's bytes are in flight from here on
-        // ---- how many newlines lie in front of this tile
+        if (w != 0) issue(t + S);                                              // the next tile's bytes are in flight from here on
+        // ---- how many newlines lie in front of this tile.  Wave 0 asks BEFORE it issues any other vector memory operation of
+        //      this iteration: an atomic load waits (vmcnt) for every older load of its wave, and behind the next tile's 16 KiB
+        //      each poll took an HBM round trip under load instead of a trip to the L2 / fabric (measured: +1.2 ms per launch)
         if (w == 0) {
-            bool dead;
-            const uint64_t excl = lookback(status, ctl, t, count, lane, dead);
+            bool dead = false;
+            const uint64_t excl = (g.debug & 1) ? t * 192 : lookback(lb, ctl, t, g.ntiles, count, arrived, lane, dead);
             if (lane == 0) { misc[5] = (uint32_t)excl; misc[6] = (uint32_t)(excl >> 32); misc[7] = dead ? 1u : 0u; }
         }
+        if (w == 0) issue(t + S);
         __syncthreads();                                                       // B2
         if (misc[7]) break;                                                    // the launch is given up (workgroup-uniform)
         const uint64_t Gp = ((uint64_t)misc[6] << 32) | misc[5];
@@ -314,7 +371,7 @@ __global__ __launch_bounds__(EN_THREADS, STATS ? 3 : 4) void encode_tile_kernel(
     }
 }
 
-typedef void (*EncKernel)(const uint4*, EncGeom, unsigned long long*, EncCtl*, uint64_t*, uint8_t*, uint8_t*, uq_stats*, uint32_t);
+typedef void (*EncKernel)(const uint4*, EncGeom, LookBack, EncCtl*, uint64_t*, uint8_t*, uint8_t*, uq_stats*, uint32_t);
 
 template <bool STATS>
 EncKernel pick_enc(int bq, bool ntrick) {
@@ -374,6 +431,7 @@ extern "C" int uq_encode_stream(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbyt
     if (P > g.G) P = g.G;
     if (P < 1) P = 1;
     g.P = P; g.magicP = magic_u32(P);
+    if (const char* dbg = getenv("UQ_ENC_DEBUG")) g.debug = (uint32_t)atoi(dbg);
     const size_t lds = fixed + g.img_d + g.img_q;
     UQ_REQUIRE(lds <= 160 * 1024, "uq_encode_stream: tile needs %zu bytes of LDS", lds);
 
@@ -390,13 +448,15 @@ extern "C" int uq_encode_stream(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbyt
     const uint64_t blocks = g.ntiles < (uint64_t)UQ_NUM_CU * per_cu ? g.ntiles : (uint64_t)UQ_NUM_CU * per_cu;
 
     void* ws;
-    const size_t ws_bytes = 256 + g.ntiles * 8;
+    const uint64_t ngroups = (g.ntiles + EN_GROUP - 1) / EN_GROUP;
+    const size_t ws_bytes = 256 + (((g.ntiles + 15) & ~uint64_t(15)) + ngroups * EN_GSTRIDE) * 8;
     UQ_TRY(uq_scratch(ctx, ws_bytes, &ws));
     EncCtl* d_ctl = (EncCtl*)ws;
-    unsigned long long* d_status = (unsigned long long*)((uint8_t*)ws + 256);
+    LookBack lb;
+    lb.A = (unsigned long long*)((uint8_t*)ws + 256); lb.GR = lb.A + ((g.ntiles + 15) & ~uint64_t(15));
     UQ_CHECK_HIP(hipMemsetAsync(ws, 0, ws_bytes, ctx->stream));
     const uint32_t qbase = qmin >= 64 ? 59u : (qmin < 33 ? 0u : 33u);
-    k<<<(uint32_t)blocks, EN_THREADS, lds, ctx->stream>>>((const uint4*)(d_buf - g.mis), g, d_status, d_ctl, d_line_start, d_dna, d_qual, d_stats,
+    k<<<(uint32_t)blocks, EN_THREADS, lds, ctx->stream>>>((const uint4*)(d_buf - g.mis), g, lb, d_ctl, d_line_start, d_dna, d_qual, d_stats,
                                                          (64u << 8) | qbase);
     UQ_LAUNCH_CHECK();
     UQ_CHECK_HIP(hipMemcpyAsync(ctx->h_pinned, d_ctl, sizeof(EncCtl), hipMemcpyDeviceToHost, ctx->stream));

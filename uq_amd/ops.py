@@ -162,6 +162,69 @@ def encode_stream(ctx, buf, guess, max_reads, with_stats=True):
     return e
 
 
+HEAD_BYTES = 24 << 20          # the slice of the file the one-pass encoder's guess is taken from
+HEAD_READS = 65536
+
+
+def head_guess(ctx, buf, notricks=False, pad=False):
+    """uq_pack_params guessed from the head of the file itself: the multi-pass statistics (uq.py:366-425) of its first
+    HEAD_READS reads -> the decisions of uq.py:448-545 on that sample.  Returns (params, reads per byte estimate) or None when
+    the head holds no complete record.  A guess is only ever used speculatively: the caller verifies it against the
+    statistics of the WHOLE file (uq_encode_stream counts them in the same pass)."""
+    from . import analysis
+    head = buf[:HEAD_BYTES]
+    nl = count_lines(ctx, head)
+    n = min(nl // 4, HEAD_READS)
+    if n == 0:
+        return None
+    ls = index_lines(ctx, head, nl)
+    st = stats_new(ctx)
+    stats_accumulate(ctx, st, head, ls, 0, n)
+    hs = stats_fetch(ctx, st)
+    if hs.bad_plus is not None or hs.bad_len is not None:
+        return None
+    d = analysis.decide_from_counts(hs.counts, hs.len_min, hs.len_max, notricks=notricks, pad=pad)
+    if d['N_qual'] and max(d['N_qual'].values()) >= len(d['qualities']): return None       # Q9 new-code files: exact kernel only
+    span = int(ls[4 * n].item())
+    p = make_pack_params(d['bases'], d['qualities'], d['N_qual'], d['bits_per_base'], d['bits_per_quality'], d['variable_read_lengths'],
+                         d['dna_bytes_per_row'], d['quality_bytes_per_row'], d['dna_max'], hs.max_record_bytes, avg_record_bytes=span // n)
+    return p, n / span
+
+
+def encode_one_pass(ctx, buf, guess=None, notricks=False, pad=False, reads_per_byte=None):
+    """Census + record index + pass-1 statistics (+ speculative tables) with ONE read of the stream where the input allows
+    it, else through the multi-pass entry points -- the same results either way.
+    Returns (nlines, line_start, d_stats, spec, path): d_stats = device uq_stats of all nlines // 4 reads (None when nlines
+    is no multiple of 4: the caller reports that first), spec = (guess, dna, qual) when the pass packed every read with
+    `guess` and met nothing outside it (the caller keeps the tables iff the real decisions equal the guess), else None."""
+    e = None
+    if guess is None:
+        g = head_guess(ctx, buf, notricks, pad)
+        if g is not None: guess, reads_per_byte = g
+    if guess is not None:
+        rpb = reads_per_byte or (1.0 / max(guess.avg_record_bytes, 1))
+        e = encode_stream(ctx, buf, guess, int(buf.numel() * rpb * 1.02) + 1024)
+        if e is not None and e.line_start is None and e.nlines % 4 == 0 and e.nlines:
+            e = encode_stream(ctx, buf, guess, e.nlines // 4) or e          # the row estimate was short: the census is exact now
+    if e is not None and e.line_start is not None:
+        nlines, ls, path = e.nlines, e.line_start, 'one-pass'
+    else:
+        nlines = e.nlines if e is not None else count_lines(ctx, buf)
+        ls = index_lines(ctx, buf, nlines)
+        e, path = None, 'multi-pass'
+    n = nlines // 4
+    d_stats = None
+    if nlines % 4 == 0 and n:
+        if e is not None and e.stats is not None:
+            d_stats = e.stats
+        else:
+            path = 'multi-pass' if e is None else 'one-pass index, multi-pass statistics'
+            d_stats = stats_new(ctx)
+            stats_accumulate(ctx, d_stats, buf, ls, 0, n)
+    spec = (guess,) + e.tables if (e is not None and e.tables is not None and e.stats is not None) else None
+    return nlines, ls, d_stats, spec, path
+
+
 def same_pack_params(a, b):
     """Do two uq_pack_params describe the same encoding (everything but the tile-sizing hint)?"""
     if (a.bits_per_base, a.bits_per_quality, a.variable, a.dna_bytes_per_row, a.quality_bytes_per_row, a.dna_max) != \

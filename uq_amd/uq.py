@@ -58,7 +58,9 @@ def build_parser():
     p.add_argument('--quiet', action='store_true', default=False, help='suppress the analysis report (extension)')
     p.add_argument('--host-qname', action='store_true', default=False, help='run the QNAME passes sequentially on the host (extension)')
     p.add_argument('--one-pass', action='store_true', default=False,
-                   help='pack speculatively during the statistics pass with the decisions of the previous encode of this process, verify afterwards (extension)')
+                   help='census, record index, statistics and a speculative pack (decisions guessed from the head of the file, verified afterwards) '
+                        'in ONE read of the stream (extension)')
+    p.add_argument('--multi-pass', action='store_true', default=False, help='the default: census, record index, statistics and pack as separate passes (extension)')
     p.add_argument('--two-pass-decode', action='store_true', default=False,
                    help='decode through the fixed-pitch text arrays (uq_unpack + uq_emit_fastq) instead of the fused kernel (extension)')
     return p
@@ -136,28 +138,28 @@ class Session:
         self.load_device(self.io.file_to_device(path))                           # pinned, chunked, overlapped with the reads (row f2)
 
     def load_device(self, d_buf):
-        """The same for FASTQ bytes that are already in HBM (a uint8 device tensor): record index + pass-1 statistics."""
-        ops, ctx = self.ops, self.ctx
+        """The same for FASTQ bytes that are already in HBM (a uint8 device tensor): record index + pass-1 statistics, as
+        separate passes over the stream (census -> index -> statistics).  --one-pass does all of it in ONE read of the stream
+        together with a speculative pack (uq_encode_stream; the guess comes from the head of this file); analyse() /
+        _encode() keep those tables only if the decisions derived from the whole file's statistics equal the guess, and any
+        input the one-pass kernel declines takes the separate passes: same results.  (On MI355X the one-pass kernel is
+        currently the slower of the two -- DESIGN.md 4 -- hence opt-in.)"""
+        ops, ctx, args = self.ops, self.ctx, self.args
         self.d_buf = d_buf
         if not hasattr(self, '_host'): self.path, self._host = None, None
-        nlines = ops.count_lines(ctx, self.d_buf)
+        self._spec, self.load_path = None, 'multi-pass'
+        one_pass = getattr(args, 'one_pass', False) and not getattr(args, 'multi_pass', False)
+        if one_pass:
+            nlines, self.d_ls, self.d_stats, spec, self.load_path = ops.encode_one_pass(ctx, self.d_buf, None, args.notricks, args.pad)
+            if spec is not None: self._spec = spec + (None,)
+        else:
+            nlines = ops.count_lines(ctx, self.d_buf)
         if nlines % 4 != 0:
             error('ERROR: The FASTQ file provided contains' + str(nlines) + 'rows, which is not divisible by 4!')
         if nlines == 0: error('ERROR: empty input')
         self.total = nlines // 4
-        self.d_ls = ops.index_lines(ctx, self.d_buf, nlines)                     # record index
-        # pass-1 statistics.  With --one-pass, and when this process has encoded before, pack speculatively with those
-        # decisions in the same pass over the stream (uq_pack_stats); analyse() / _encode() keep the tables only if the
-        # real decisions agree.  (One HBM pass less, but the fused kernel is latency-bound: not the default.)
-        self._spec = None
-        guess = Session.last_params
-        if guess is not None and getattr(self.args, 'one_pass', False) and \
-                self.total * (guess.dna_bytes_per_row + guess.quality_bytes_per_row) <= 2 * self.d_buf.numel():   # a guess of another scale is no guess
-            res = ops.pack_stats(ctx, self.d_buf, self.d_ls, 0, self.total, guess)
-            if res is not None:
-                self._spec = (guess,) + res[:3]
-                self.d_stats = res[3]
-        if self._spec is None:
+        if not one_pass:
+            self.d_ls = ops.index_lines(ctx, self.d_buf, nlines)                 # record index
             self.d_stats = ops.stats_new(ctx)
             ops.stats_accumulate(ctx, self.d_stats, self.d_buf, self.d_ls, 0, self.total)
 
@@ -294,7 +296,7 @@ class Session:
             del spec
             dna, qual, bad = ops.pack(ctx, self.d_buf, self.d_ls, 0, self.total, p)
         Session.last_params = p
-        b = ops.bad_index(bad)
+        b = ops.bad_index(bad) if bad is not None else None      # the one-pass kernel withdraws its tables instead
         if b is not None: error('ERROR: read %d holds a symbol with no code (internal inconsistency)' % b)
         return ((dna, self.total, d['dna_bytes_per_row']), (qual, self.total, d['quality_bytes_per_row']))
 
