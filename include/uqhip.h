@@ -248,12 +248,17 @@ int uq_qname_free(uq_qname* q);
  *   canonical non-negative integers: 0x80 | value, big-endian).  Reductions per column: first_nonint (UQ_NONE if
  *   every field is [+-]digits), vmin / vmax over the integer fields, any_long bit0 = a field that does not fit
  *   the 8-byte key (long and not a canonical integer, or holding NUL / non-ASCII), bit1 = long canonical integer
- *   seen.  flags: bit0 separators missing / out of order / extra, bit1 whitespace inside a field (Python's int()
+ *   seen, bit2 = an integer field that is not the canonical decimal of its value ('+7', '007', '-0').  flags: bit0 separators missing / out of order / extra, bit1 whitespace inside a field (Python's int()
  *   strips it), bit2 more than 18 digits, bit3 QNAME shorter than prefix + suffix -- any flag: use uq_qname_analyse.
  * uq_prefix_distinct (uq.py:609-625, the `len(map) > entries_read / 10` checkpoints): from a STABLE argsort
  *   (d_perm) and the group ids in sorted order (d_sorted_key; both from uq_unique_rows), the number of distinct
  *   rows among rows [0, T] for each threshold T.  d_perm holds, per sorted position, the file-order index of that
  *   row as uint32 (perm_itemsize 4: the local argsort) or uint64 (8: file-wide indices after a distributed sort).
+ * uq_int_prefix_distinct: the same counts for a column of INTEGER fields whose text is the canonical decimal of its value
+ *   (then distinct strings = distinct values) without sorting it: first[v] = lowest read holding value v in [vmin, vmin +
+ *   range) via atomic minima (a private LDS table per workgroup for small ranges), then h_counts[k] = #{v: first[v] <= T_k}.
+ *   d_val = uq_qname_tokenise's value array; indices are file-wide (read_index_base + i).  any_long bit 2 from
+ *   uq_qname_tokenise (a non-canonical integer such as '+7', '007', '-0' was seen) rules this shortcut out.
  * uq_encode_int (uq.py:724-733): d_out[i] = (unsigned itemsize)(d_val[i] - sub). */
 typedef struct uq_qname_layout_result {
     uint32_t min_lcp, min_lcs;
@@ -277,6 +282,8 @@ int uq_qname_tokenise(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_
                       uint64_t* const* h_d_strs, uq_qname_cols_result* h_out);
 int uq_prefix_distinct(uq_ctx* ctx, const void* d_perm, int perm_itemsize, const uint32_t* d_sorted_key, uint64_t n,
                        const uint64_t* h_thresholds, int nthresholds, uint64_t* h_counts);
+int uq_int_prefix_distinct(uq_ctx* ctx, const int64_t* d_val, uint64_t n, int64_t vmin, uint64_t range, uint64_t read_index_base,
+                           const uint64_t* h_thresholds, int nthresholds, uint64_t* h_counts);
 int uq_encode_int(uq_ctx* ctx, const int64_t* d_val, uint64_t n, int64_t sub, int itemsize, void* d_out);
 
 /* ---- f3: FASTQ text assembled on the device.  Replaces the decoder's exec-compiled convert_qname

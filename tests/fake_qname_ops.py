@@ -103,6 +103,8 @@ def qname_tokenise(ctx, buf, ls, n, plen, slen, separators):
             isint = len(body) > 0 and all(48 <= b <= 57 for b in body)
             if isint and len(body) > 18:
                 r.flags |= 4
+            if isint and len(body) <= 18 and (f[:1] == b'+' or (len(body) > 1 and body[:1] == b'0') or (f[:1] == b'-' and int(body) == 0)):
+                r.any_long[c] |= 4
             key = f[:8].ljust(8, b'\0')
             if len(f) > 8:
                 if isint and body is f and not (len(f) > 1 and f[:1] == b'0') and len(body) <= 18:
@@ -142,6 +144,15 @@ def prefix_distinct(ctx, perm, skey, n, thresholds):
 
 _DT = {1: np.uint8, 2: np.uint16, 4: np.uint32, 8: np.uint64}
 _VIEW = {1: np.uint8, 2: np.int16, 4: np.int32, 8: np.int64}
+
+
+def int_prefix_distinct(ctx, val, n, vmin, value_range, thresholds, index_base=0):
+    v = val.numpy()[:n]
+    first = {}
+    for i, x in enumerate(v.tolist()):
+        if vmin <= x < vmin + value_range and x not in first: first[x] = index_base + i
+    f = np.array(sorted(first.values()), dtype=np.uint64)
+    return [int((f <= T).sum()) for T in thresholds]
 
 
 def narrow(ctx, key, itemsize):

@@ -108,6 +108,7 @@ SIGNATURES = {
     'uq_qname_layout': [_vp, _vp, _vp, _u64, _u64, _vp, _u32, _P(QnameLayoutResult)],
     'uq_qname_tokenise': [_vp, _vp, _vp, _u64, _u32, _u32, _vp, _u32, _P(_vp), _P(_vp), _P(QnameColsResult)],
     'uq_prefix_distinct': [_vp, _vp, _int, _vp, _u64, _P(_u64), _int, _P(_u64)],
+    'uq_int_prefix_distinct': [_vp, _vp, _u64, C.c_int64, _u64, _u64, _P(_u64), _int, _P(_u64)],
     'uq_encode_int': [_vp, _vp, _u64, C.c_int64, _int, _vp],
     'uq_emit_fastq': [_vp, _P(EmitParams), _P(_vp), _P(_vp), _P(_vp), _vp, _vp, _vp, _u64, _vp, _vp, _u64, _P(_u64)],
     'uq_debug_scribble_lds': [_vp, C.c_uint32],

@@ -197,6 +197,7 @@ __global__ __launch_bounds__(QN_THREADS) void qname_tokenise_kernel(const uint8_
             if (ws) flags |= 2u;
             const long long v = neg ? -(long long)mag : (long long)mag;
             uint32_t lng = odd ? 1u : 0u;
+            if (isint && (b0 == '+' || lead0 || (neg && mag == 0))) lng |= 4u;     // '+7', '007', '-0': text is not THE decimal of the value
             if (fl > 8) {
                 if (isint && !sign && !lead0) { key = 0x8000000000000000ull | mag; lng |= 2u; }   // text <-> value is a bijection here
                 else lng |= 1u;
@@ -235,6 +236,52 @@ __global__ __launch_bounds__(QN_THREADS) void prefix_distinct_kernel(const IDX* 
             for (int k = 0; k < nth; ++k)
                 if (f <= th[k]) atomicAdd(&s_cnt[k], 1u);
         }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nth && s_cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
+}
+
+// ---- distinct counts of an INTEGER column without sorting it (uq_int_prefix_distinct).
+// first[v - vmin] = lowest read index (file-wide) holding value v, over reads [0, n): small ranges through a private LDS table
+// per workgroup (a column of four lanes or sixty-four tiles would otherwise be ten million atomics on a handful of
+// addresses), wide ranges straight to the global table (contention falls with the range).
+template <bool PRIVATE>
+__global__ __launch_bounds__(QN_THREADS) void first_seen_kernel(const long long* __restrict__ val, uint64_t n, long long vmin, uint32_t range,
+                                                               uint64_t index_base, unsigned long long* __restrict__ first) {
+    extern __shared__ unsigned long long s_first[];
+    if (PRIVATE) {
+        for (uint32_t i = threadIdx.x; i < range; i += QN_THREADS) s_first[i] = UQ_NONE;
+        __syncthreads();
+    }
+    // a workgroup takes a CONTIGUOUS slice of the reads: the first lane to see a value in a slice usually settles it
+    const uint64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const uint64_t lo = (uint64_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += QN_THREADS) {
+        const unsigned long long slot = (unsigned long long)(val[i] - vmin);
+        if (slot >= range) continue;                         // not in [vmin, vmax]: the caller's bounds were wrong (never with uq_qname_tokenise's)
+        const unsigned long long gi = index_base + i;
+        if (PRIVATE) { if (gi < s_first[slot]) atomicMin(&s_first[slot], gi); }
+        else if (gi < first[slot]) atomicMin(&first[slot], gi);
+    }
+    if (PRIVATE) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < range; i += QN_THREADS)
+            if (s_first[i] != UQ_NONE && s_first[i] < first[i]) atomicMin(&first[i], s_first[i]);
+    }
+}
+
+// counts[k] = number of values whose first occurrence is <= T_k
+__global__ __launch_bounds__(QN_THREADS) void first_seen_count_kernel(const unsigned long long* __restrict__ first, uint32_t range,
+                                                                      const unsigned long long* __restrict__ th, int nth,
+                                                                      unsigned long long* __restrict__ counts) {
+    __shared__ uint32_t s_cnt[64];
+    if (threadIdx.x < 64) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint64_t j = (uint64_t)blockIdx.x * QN_THREADS + threadIdx.x; j < range; j += (uint64_t)gridDim.x * QN_THREADS) {
+        const unsigned long long f = first[j];
+        if (f == UQ_NONE) continue;
+        for (int k = 0; k < nth; ++k)
+            if (f <= th[k]) atomicAdd(&s_cnt[k], 1u);
     }
     __syncthreads();
     if ((int)threadIdx.x < nth && s_cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
@@ -343,6 +390,33 @@ extern "C" int uq_prefix_distinct(uq_ctx* ctx, const void* d_perm, int perm_item
     else
         prefix_distinct_kernel<unsigned long long><<<grid_for(n), QN_THREADS, 0, ctx->stream>>>((const unsigned long long*)d_perm, d_sorted_key, n, d_th,
                                                                                                nthresholds, d_cnt);
+    UQ_LAUNCH_CHECK();
+    UQ_CHECK_HIP(hipMemcpyAsync(h_counts, d_cnt, nthresholds * 8, hipMemcpyDeviceToHost, ctx->stream));
+    UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" int uq_int_prefix_distinct(uq_ctx* ctx, const int64_t* d_val, uint64_t n, int64_t vmin, uint64_t range, uint64_t read_index_base,
+                                      const uint64_t* h_thresholds, int nthresholds, uint64_t* h_counts) {
+    UQ_REQUIRE(ctx && h_thresholds && h_counts && nthresholds >= 1 && nthresholds <= 64, "uq_int_prefix_distinct: bad argument");
+    UQ_REQUIRE(range >= 1 && range <= (uint64_t(1) << 26), "uq_int_prefix_distinct: value range %llu not in 1 .. 2^26", (unsigned long long)range);
+    for (int k = 0; k < nthresholds; ++k) h_counts[k] = 0;
+    if (n == 0) return 0;
+    UQ_REQUIRE(d_val, "uq_int_prefix_distinct: null buffer");
+    void* scr;
+    UQ_TRY(uq_scratch(ctx, 2048 + range * 8, &scr));
+    unsigned long long* d_th = (unsigned long long*)scr;
+    unsigned long long* d_cnt = d_th + 64;
+    unsigned long long* d_first = d_th + 256;
+    UQ_CHECK_HIP(hipMemcpyAsync(d_th, h_thresholds, nthresholds * 8, hipMemcpyHostToDevice, ctx->stream));
+    UQ_CHECK_HIP(hipMemsetAsync(d_cnt, 0, 64 * 8, ctx->stream));
+    UQ_CHECK_HIP(hipMemsetAsync(d_first, 0xFF, range * 8, ctx->stream));
+    UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));       // h_thresholds may be a temporary of the caller
+    const uint32_t grid = grid_for(n);
+    if (range <= 4096) first_seen_kernel<true><<<grid, QN_THREADS, range * 8, ctx->stream>>>((const long long*)d_val, n, vmin, (uint32_t)range, read_index_base, d_first);
+    else first_seen_kernel<false><<<grid, QN_THREADS, 0, ctx->stream>>>((const long long*)d_val, n, vmin, (uint32_t)range, read_index_base, d_first);
+    UQ_LAUNCH_CHECK();
+    first_seen_count_kernel<<<grid_for(range), QN_THREADS, 0, ctx->stream>>>(d_first, (uint32_t)range, d_th, nthresholds, d_cnt);
     UQ_LAUNCH_CHECK();
     UQ_CHECK_HIP(hipMemcpyAsync(h_counts, d_cnt, nthresholds * 8, hipMemcpyDeviceToHost, ctx->stream));
     UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));

@@ -370,6 +370,14 @@ def prefix_distinct(ctx, perm, sorted_key, n, thresholds):
     return list(out)
 
 
+def int_prefix_distinct(ctx, val, n, vmin, value_range, thresholds, index_base=0):
+    """Distinct values among reads [0, T] of the first n entries of an int64 column, per threshold T (uq_int_prefix_distinct)."""
+    th = (C.c_uint64 * len(thresholds))(*thresholds)
+    out = (C.c_uint64 * len(thresholds))()
+    call('uq_int_prefix_distinct', ctx.h, _p(val), int(n), int(vmin), int(value_range), int(index_base), th, len(thresholds), out)
+    return list(out)
+
+
 def encode_int(ctx, val, sub, itemsize):
     t = ctx.torch
     out = t.empty(val.numel(), dtype=getattr(t, _NARROW_DT[itemsize]), device=ctx.device)

@@ -22,6 +22,9 @@ from .qname import QnameError, _LADDER
 REGEX_SPECIAL = frozenset('.^$*+?{}[]\\|()-')
 _STRINGS = 'Encoding QNAMEs as strings has not been implimented yet.'
 _I64_MAX = (1 << 63) - 1
+INT_RANGE_SMALL = 4096          # value ranges counted over the whole column (private LDS tables)
+INT_RANGE_MAX = 1 << 24         # widest range the sort-free count is tried on
+INT_PREFIX = 1 << 21            # reads a wide-range column is judged on before the sort is paid for
 
 
 def _ladder(x):
@@ -156,13 +159,33 @@ def type_and_encode_device(ctx, d_buf, d_ls, nreads, prefix, suffix, separators,
         col = {'name': 'QNAME_%d' % (c + 1), 'format': 'mapping'}
         all_int = first_nonint[c] == UQ_NONE
         vmin, vmax = vmins[c], vmaxs[c]
-        counts, nu, key, uniq = _distinct_counts(ctx, strs[c], n_local, thresholds, shard)
+        counts = None
+        key = uniq = None
+        # An all-integer column whose fields are the canonical decimals of their values has as many distinct strings as
+        # distinct VALUES: first occurrences per value (atomic minima over [vmin, vmax]) give every checkpoint's count
+        # without the sort (uq_int_prefix_distinct).  Small ranges are settled for the whole column; wide ones (flow-cell
+        # coordinates) from a prefix of the reads, where the `len(map) > entries_read / 10` rule fires at once or never.
+        value_range = vmax - vmin + 1 if all_int else 0
+        if (shard is None or shard.world == 1) and all_int and not (res.any_long[c] & 4) and 1 <= value_range <= INT_RANGE_MAX:
+            if value_range <= INT_RANGE_SMALL:
+                counts = ops.int_prefix_distinct(ctx, vals[c], n_local, vmin, value_range, thresholds)
+                nu = counts[-1]
+            else:
+                head = [T for T in thresholds if T < INT_PREFIX]
+                if head:
+                    hc = ops.int_prefix_distinct(ctx, vals[c], min(n_local, head[-1] + 1), vmin, value_range, head)
+                    if any(cnt > T // 10 for T, cnt in zip(head, hc)): counts, nu = hc, None      # demoted inside the prefix: nu is not needed
+                    elif len(head) == len(thresholds): counts, nu = hc, hc[-1]                    # the prefix was the whole column
+        if counts is None:
+            counts, nu, key, uniq = _distinct_counts(ctx, strs[c], n_local, thresholds, shard)
         for T, cnt in zip(thresholds, counts):
             if cnt > T // 10:                               # check_format(): mapping -> integers
                 if not all_int:
                     raise QnameError(_STRINGS)
                 col['format'] = 'integers'
                 break
+        if col['format'] == 'mapping' and uniq is None and not (all_int and vmax - vmin <= _ladder(nu)[0]):
+            counts, nu, key, uniq = _distinct_counts(ctx, strs[c], n_local, thresholds, shard)     # it stays a mapping: the sorted map is needed
         if col['format'] == 'mapping':
             lim, dt = _ladder(nu)
             col['dtype'] = dt
