@@ -10,3 +10,9 @@
 size_t radix_ws_bytes(uint64_t n);
 int radix_sort_pairs(uq_ctx* ctx, uint64_t* keys, uint32_t* vals, uint64_t* keys_alt, uint32_t* vals_alt,
                      uint64_t n, int begin_bit, int end_bit, void* ws, int* in_alt);
+// The same with 32-bit keys: 8 bytes a pair instead of 12, four digit positions instead of eight.
+// h_hist: the digit census of the keys (radix_census32: h_hist[p * 256 + d] = keys whose byte p is d) when the caller has
+// taken it already, else NULL.
+int radix_sort_pairs32(uq_ctx* ctx, uint32_t* keys, uint32_t* vals, uint32_t* keys_alt, uint32_t* vals_alt,
+                       uint64_t n, int begin_bit, int end_bit, void* ws, int* in_alt, const uint32_t* h_hist);
+int radix_census32(uq_ctx* ctx, const uint32_t* keys, uint64_t n, void* ws, uint32_t* h_hist);

@@ -12,31 +12,37 @@
 
 namespace {
 constexpr int RS_THREADS = 256;
-constexpr int RS_ITEMS = 12;
-constexpr int RS_TILE = RS_THREADS * RS_ITEMS;   // 3072 pairs per workgroup (36 KiB of LDS: 4 workgroups per CU; 16 items = 48 KiB = 3 per CU was 8 % slower)
-constexpr int RS_WAVE_KEYS = 64 * RS_ITEMS;      // 768 per wave
+// pairs per thread: 12 with u64 keys = 3072 pairs per workgroup (36 KiB of LDS: 4 workgroups per CU; 16 items = 48 KiB = 3 per CU
+// was 8 % slower); u32 keys are 8 bytes a pair, so 16 items fit the same 36 KiB
+template <typename K> struct RsGeom { static constexpr int ITEMS = sizeof(K) == 4 ? 16 : 12; static constexpr int TILE = RS_THREADS * ITEMS;
+                                      static constexpr int WAVE_KEYS = 64 * ITEMS; static constexpr int DIGITS = sizeof(K); };
 
-__device__ __forceinline__ uint32_t digit_of(uint64_t k, int shift) { return (uint32_t)(k >> shift) & 255u; }
+template <typename K>
+__device__ __forceinline__ uint32_t digit_of(K k, int shift) { return (uint32_t)(k >> shift) & 255u; }
 
-// Census of all eight digit positions at once: ghist[p][d].
-__global__ __launch_bounds__(RS_THREADS) void rs_census_kernel(const uint64_t* __restrict__ keys, uint64_t n,
+// Census of all digit positions at once: ghist[p][d].
+template <typename K>
+__global__ __launch_bounds__(RS_THREADS) void rs_census_kernel(const K* __restrict__ keys, uint64_t n,
                                                                uint32_t* __restrict__ ghist) {
-    __shared__ uint32_t h[8 * 256];
-    for (int i = threadIdx.x; i < 8 * 256; i += RS_THREADS) h[i] = 0;
+    constexpr int ND = RsGeom<K>::DIGITS;
+    __shared__ uint32_t h[ND * 256];
+    for (int i = threadIdx.x; i < ND * 256; i += RS_THREADS) h[i] = 0;
     __syncthreads();
     const uint64_t stride = (uint64_t)gridDim.x * RS_THREADS;
     for (uint64_t i = (uint64_t)blockIdx.x * RS_THREADS + threadIdx.x; i < n; i += stride) {
-        uint64_t k = keys[i];
+        const K k = keys[i];
 #pragma unroll
-        for (int p = 0; p < 8; ++p) atomicAdd(&h[p * 256 + digit_of(k, 8 * p)], 1u);
+        for (int p = 0; p < ND; ++p) atomicAdd(&h[p * 256 + digit_of(k, 8 * p)], 1u);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 8 * 256; i += RS_THREADS)
+    for (int i = threadIdx.x; i < ND * 256; i += RS_THREADS)
         if (h[i]) atomicAdd(&ghist[i], h[i]);
 }
 
-__global__ __launch_bounds__(RS_THREADS) void rs_count_kernel(const uint64_t* __restrict__ keys, uint64_t n, int shift,
+template <typename K>
+__global__ __launch_bounds__(RS_THREADS) void rs_count_kernel(const K* __restrict__ keys, uint64_t n, int shift,
                                                               uint32_t nb, uint32_t* __restrict__ block_hist) {
+    constexpr int RS_ITEMS = RsGeom<K>::ITEMS, RS_TILE = RsGeom<K>::TILE;
     __shared__ uint32_t h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
@@ -50,11 +56,13 @@ __global__ __launch_bounds__(RS_THREADS) void rs_count_kernel(const uint64_t* __
     block_hist[(uint64_t)threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
 }
 
-__global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-                                                                uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+template <typename K>
+__global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const K* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                                K* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                                 uint64_t n, int shift, uint32_t nb,
                                                                 const uint32_t* __restrict__ block_off) {
-    __shared__ uint64_t s_keys[RS_TILE];
+    constexpr int RS_ITEMS = RsGeom<K>::ITEMS, RS_TILE = RsGeom<K>::TILE, RS_WAVE_KEYS = RsGeom<K>::WAVE_KEYS;
+    __shared__ K s_keys[RS_TILE];
     __shared__ uint32_t s_vals[RS_TILE];
     __shared__ uint32_t s_cnt[4 * 256];      // per-wave digit counts, then per-wave exclusive bases
     __shared__ uint32_t s_start[256];        // first tile-local slot of each digit
@@ -68,7 +76,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint64_t* 
     s_goff[tid] = block_off[(uint64_t)tid * nb + blockIdx.x];
     __syncthreads();
 
-    uint64_t key[RS_ITEMS];
+    K key[RS_ITEMS];
     uint32_t val[RS_ITEMS];
     uint32_t rank[RS_ITEMS];
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -124,7 +132,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint64_t* 
     for (int i = 0; i < RS_ITEMS; ++i) {
         const uint32_t p = i * RS_THREADS + tid;
         if (p < ntile) {
-            const uint64_t k = s_keys[p];
+            const K k = s_keys[p];
             const uint32_t d = digit_of(k, shift);
             const uint32_t g = s_goff[d] + (p - s_start[d]);
             keys_out[g] = k;
@@ -135,40 +143,66 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint64_t* 
 }  // namespace
 
 size_t radix_ws_bytes(uint64_t n) {
-    uint64_t nb = (n + RS_TILE - 1) / RS_TILE;
+    uint64_t nb = (n + RsGeom<uint64_t>::TILE - 1) / RsGeom<uint64_t>::TILE;      // the smaller tile: more workgroups
     return (size_t)(256 * nb + 64) * 4 + 8 * 256 * 4 + 256;
 }
 
-int radix_sort_pairs(uq_ctx* ctx, uint64_t* keys, uint32_t* vals, uint64_t* keys_alt, uint32_t* vals_alt,
-                     uint64_t n, int begin_bit, int end_bit, void* ws, int* in_alt) {
+template <typename K>
+static int radix_sort_impl(uq_ctx* ctx, K* keys, uint32_t* vals, K* keys_alt, uint32_t* vals_alt,
+                           uint64_t n, int begin_bit, int end_bit, void* ws, int* in_alt, const uint32_t* h_hist_in) {
+    constexpr int ND = RsGeom<K>::DIGITS, TILE = RsGeom<K>::TILE;
     *in_alt = 0;
     if (n <= 1 || end_bit <= begin_bit) return 0;
     UQ_REQUIRE(n < (uint64_t(1) << 32), "radix sort: more than 2^32-1 pairs");
-    UQ_REQUIRE(begin_bit % 8 == 0 && begin_bit >= 0 && end_bit <= 64, "radix sort: bad bit range");
-    const uint32_t nb = (uint32_t)((n + RS_TILE - 1) / RS_TILE);
+    UQ_REQUIRE(begin_bit % 8 == 0 && begin_bit >= 0 && end_bit <= 8 * ND, "radix sort: bad bit range");
+    const uint32_t nb = (uint32_t)((n + TILE - 1) / TILE);
     uint32_t* ghist = (uint32_t*)ws;
     uint32_t* block_hist = ghist + 8 * 256 + 64;
-    UQ_CHECK_HIP(hipMemsetAsync(ghist, 0, 8 * 256 * 4, ctx->stream));
-    uint32_t cb = nb < 2048 ? nb : 2048;
-    rs_census_kernel<<<cb, RS_THREADS, 0, ctx->stream>>>(keys, n, ghist);
-    UQ_LAUNCH_CHECK();
     static thread_local uint32_t h_hist[8 * 256];
-    UQ_CHECK_HIP(hipMemcpyAsync(h_hist, ghist, sizeof(h_hist), hipMemcpyDeviceToHost, ctx->stream));
-    UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-    uint64_t* kin = keys; uint32_t* vin = vals; uint64_t* kout = keys_alt; uint32_t* vout = vals_alt;
+    if (h_hist_in) memcpy(h_hist, h_hist_in, ND * 256 * 4);          // the caller has taken the census already
+    else {
+        UQ_CHECK_HIP(hipMemsetAsync(ghist, 0, ND * 256 * 4, ctx->stream));
+        uint32_t cb = nb < 2048 ? nb : 2048;
+        rs_census_kernel<K><<<cb, RS_THREADS, 0, ctx->stream>>>(keys, n, ghist);
+        UQ_LAUNCH_CHECK();
+        UQ_CHECK_HIP(hipMemcpyAsync(h_hist, ghist, ND * 256 * 4, hipMemcpyDeviceToHost, ctx->stream));
+        UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    K* kin = keys; uint32_t* vin = vals; K* kout = keys_alt; uint32_t* vout = vals_alt;
     for (int p = begin_bit / 8; p * 8 < end_bit; ++p) {
         bool trivial = false;
         for (int d = 0; d < 256; ++d)
             if (h_hist[p * 256 + d] == n) { trivial = true; break; }
         if (trivial) continue;
-        rs_count_kernel<<<nb, RS_THREADS, 0, ctx->stream>>>(kin, n, 8 * p, nb, block_hist);
+        rs_count_kernel<K><<<nb, RS_THREADS, 0, ctx->stream>>>(kin, n, 8 * p, nb, block_hist);
         UQ_LAUNCH_CHECK();
         UQ_TRY(uq_scan_exclusive_u32(ctx, block_hist, block_hist, (uint64_t)256 * nb, nullptr));
-        rs_scatter_kernel<<<nb, RS_THREADS, 0, ctx->stream>>>(kin, vin, kout, vout, n, 8 * p, nb, block_hist);
+        rs_scatter_kernel<K><<<nb, RS_THREADS, 0, ctx->stream>>>(kin, vin, kout, vout, n, 8 * p, nb, block_hist);
         UQ_LAUNCH_CHECK();
-        uint64_t* tk = kin; kin = kout; kout = tk;
+        K* tk = kin; kin = kout; kout = tk;
         uint32_t* tv = vin; vin = vout; vout = tv;
         *in_alt ^= 1;
     }
+    return 0;
+}
+
+int radix_sort_pairs(uq_ctx* ctx, uint64_t* keys, uint32_t* vals, uint64_t* keys_alt, uint32_t* vals_alt,
+                     uint64_t n, int begin_bit, int end_bit, void* ws, int* in_alt) {
+    return radix_sort_impl<uint64_t>(ctx, keys, vals, keys_alt, vals_alt, n, begin_bit, end_bit, ws, in_alt, nullptr);
+}
+
+int radix_sort_pairs32(uq_ctx* ctx, uint32_t* keys, uint32_t* vals, uint32_t* keys_alt, uint32_t* vals_alt,
+                       uint64_t n, int begin_bit, int end_bit, void* ws, int* in_alt, const uint32_t* h_hist) {
+    return radix_sort_impl<uint32_t>(ctx, keys, vals, keys_alt, vals_alt, n, begin_bit, end_bit, ws, in_alt, h_hist);
+}
+
+int radix_census32(uq_ctx* ctx, const uint32_t* keys, uint64_t n, void* ws, uint32_t* h_hist) {
+    uint32_t* ghist = (uint32_t*)ws;
+    UQ_CHECK_HIP(hipMemsetAsync(ghist, 0, 4 * 256 * 4, ctx->stream));
+    const uint64_t nb = (n + RsGeom<uint32_t>::TILE - 1) / RsGeom<uint32_t>::TILE;
+    rs_census_kernel<uint32_t><<<(uint32_t)(nb < 2048 ? (nb ? nb : 1) : 2048), RS_THREADS, 0, ctx->stream>>>(keys, n, ghist);
+    UQ_LAUNCH_CHECK();
+    UQ_CHECK_HIP(hipMemcpyAsync(h_hist, ghist, 4 * 256 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     return 0;
 }

@@ -29,12 +29,53 @@ __device__ __forceinline__ uint64_t load_chunk_be(const uint8_t* row, uint32_t C
     return v;
 }
 
-__global__ void extract_all_kernel(const uint8_t* __restrict__ table, uint64_t n, uint32_t C, uint64_t* __restrict__ keys,
-                                   uint32_t* __restrict__ vals) {
+// chunk 0 of every row; `andor` (optional): AND and OR over all of them -- the leading bits on which every row agrees carry no order
+__global__ __launch_bounds__(ST) void extract_all_kernel(const uint8_t* __restrict__ table, uint64_t n, uint32_t C, uint64_t* __restrict__ keys,
+                                                         uint32_t* __restrict__ vals, unsigned long long* __restrict__ andor) {
+    uint64_t i = (uint64_t)blockIdx.x * ST + threadIdx.x;
+    unsigned long long a = ~0ull, o = 0ull;
+    if (i < n) {
+        const uint64_t k = load_chunk_be(table + i * C, C, 0);
+        keys[i] = k;
+        vals[i] = (uint32_t)i;
+        a = o = k;
+    }
+    if (andor) {      // per-workgroup partials (780 000 waves x 2 atomics on one word were 19 ms), folded by and_or_fold_kernel
+        __shared__ unsigned long long sa[ST / 64], so[ST / 64];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { a &= __shfl_xor(a, d, 64); o |= __shfl_xor(o, d, 64); }
+        if (lane_id() == 0) { sa[threadIdx.x >> 6] = a; so[threadIdx.x >> 6] = o; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < ST / 64; ++w) { a &= sa[w]; o |= so[w]; }
+            andor[2 * (uint64_t)blockIdx.x] = a; andor[2 * (uint64_t)blockIdx.x + 1] = o;
+        }
+    }
+}
+__global__ __launch_bounds__(ST) void and_or_fold_kernel(const unsigned long long* __restrict__ part, uint64_t nblocks, unsigned long long* __restrict__ out) {
+    __shared__ unsigned long long sa[ST / 64], so[ST / 64];
+    unsigned long long a = ~0ull, o = 0ull;
+    for (uint64_t i = threadIdx.x; i < nblocks; i += ST) { a &= part[2 * i]; o |= part[2 * i + 1]; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { a &= __shfl_xor(a, d, 64); o |= __shfl_xor(o, d, 64); }
+    if (lane_id() == 0) { sa[threadIdx.x >> 6] = a; so[threadIdx.x >> 6] = o; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < ST / 64; ++w) { a &= sa[w]; o |= so[w]; }
+        out[0] = a; out[1] = o;
+    }
+}
+// the 32 bits of chunk 0 behind its z constant leading bits
+__global__ void prefix32_kernel(const uint64_t* __restrict__ keys, uint64_t n, uint32_t z, uint32_t* __restrict__ k32, uint32_t* __restrict__ vals) {
     uint64_t i = (uint64_t)blockIdx.x * ST + threadIdx.x;
     if (i >= n) return;
-    keys[i] = load_chunk_be(table + i * C, C, 0);
+    k32[i] = (uint32_t)((keys[i] << z) >> 32);
     vals[i] = (uint32_t)i;
+}
+__global__ void heads_first32_kernel(const uint32_t* __restrict__ keys, uint64_t n, uint8_t* __restrict__ heads) {
+    uint64_t j = (uint64_t)blockIdx.x * ST + threadIdx.x;
+    if (j >= n) return;
+    heads[j] = (j == 0 || keys[j] != keys[j - 1]) ? 1 : 0;
 }
 
 __global__ void heads_first_kernel(const uint64_t* __restrict__ keys, uint64_t n, uint8_t* __restrict__ heads) {
@@ -155,35 +196,79 @@ int sort_rows_core(uq_ctx* ctx, const uint8_t* table, uint64_t n, uint32_t C, ui
     if (n == 0) return 0;
     hipStream_t s = ctx->stream;
 
-    // ---- round 0
-    extract_all_kernel<<<blocks_for(n), ST, 0, s>>>(table, n, C, keysA, valsA);
+    // ---- round 0: all rows by (a prefix of) chunk 0
+    bool mode32 = C > 8 && n >= (1u << 16);
+    unsigned long long* part = (unsigned long long*)keysB;                      // free until the sort: 16 B per workgroup
+    extract_all_kernel<<<blocks_for(n), ST, 0, s>>>(table, n, C, keysA, valsA, mode32 ? part : nullptr);
     UQ_LAUNCH_CHECK();
-    int alt = 0;
-    UQ_TRY(radix_sort_pairs(ctx, keysA, valsA, keysB, valsB, n, 0, 64, rws, &alt));
-    const uint64_t* K = alt ? keysB : keysA;
-    const uint32_t* V = alt ? valsB : valsA;
-    UQ_CHECK_HIP(hipMemcpyAsync(d_perm, V, n * 4, hipMemcpyDeviceToDevice, s));
-    heads_first_kernel<<<blocks_for(n), ST, 0, s>>>(K, n, heads);
-    UQ_LAUNCH_CHECK();
-
-    // ---- refinement rounds
-    const uint32_t nchunks = (C + 7) / 8;
-    for (uint32_t k = 1; k < nchunks; ++k) {
-        // exact duplicates need no further rounds: stop as soon as no tying pair differs in what is left of the rows
-        UQ_CHECK_HIP(hipMemsetAsync(tot + 2, 0, 8, s));
-        tail_differs_kernel<<<blocks_for(n), ST, 0, s>>>(table, C, 8 * k, d_perm, heads, n, (uint32_t*)(tot + 2));
+    if (mode32) {
+        and_or_fold_kernel<<<1, ST, 0, s>>>(part, blocks_for(n), (unsigned long long*)(tot + 4));
         UQ_LAUNCH_CHECK();
-        UQ_CHECK_HIP(hipMemcpyAsync(ctx->h_pinned + 2, tot + 2, 8, hipMemcpyDeviceToHost, s));
+    }
+    // A 64-bit LSD sort moves 32 B per pair and pass, eight passes.  Rows wider than a chunk go to refinement rounds anyway
+    // when they tie, so round 0 may as well sort on FEWER bits: the 32 bits of chunk 0 behind its constant leading bits
+    // (a 2-bit DNA row of 150 bases starts with four zero bits) as u32 keys -- 20 B per pair and pass, four passes -- and
+    // leave the few rows that collide on them (n^2 / 2^33 pairs for random reads) to the first refinement round together
+    // with the true duplicates.  Tables whose rows crowd on few prefixes (the digit census says so) keep the 64-bit sort.
+    uint32_t z = 0;
+    if (mode32) {
+        UQ_CHECK_HIP(hipMemcpyAsync(ctx->h_pinned + 4, tot + 4, 16, hipMemcpyDeviceToHost, s));
         UQ_CHECK_HIP(hipStreamSynchronize(s));
-        if (ctx->h_pinned[2] == 0) break;
+        const uint64_t same = ~(ctx->h_pinned[4] ^ ctx->h_pinned[5]);           // bits every key agrees on
+        while (z < 64 && ((same >> (63 - z)) & 1)) ++z;
+        mode32 = z <= 32;
+    }
+    int alt = 0;
+    if (mode32) {
+        uint32_t* k32a = (uint32_t*)keysB;                                      // keysB's n * 8 bytes hold both u32 key buffers
+        uint32_t* k32b = k32a + n;
+        prefix32_kernel<<<blocks_for(n), ST, 0, s>>>(keysA, n, z, k32a, valsA);
+        UQ_LAUNCH_CHECK();
+        static thread_local uint32_t h_hist[4 * 256];
+        UQ_TRY(radix_census32(ctx, k32a, n, rws, h_hist));
+        // expected share of rows that tie on the prefix if its bytes were independent: n * prod_p sum_d (h[p][d] / n)^2
+        double coll = (double)n;
+        for (int p = 0; p < 4; ++p) {
+            double c2 = 0;
+            for (int d = 0; d < 256; ++d) { const double q = (double)h_hist[p * 256 + d] / (double)n; c2 += q * q; }
+            coll *= c2;
+        }
+        if (coll > 0.3) mode32 = false;
+        else {
+            UQ_TRY(radix_sort_pairs32(ctx, k32a, valsA, k32b, valsB, n, 0, 32, rws, &alt, h_hist));
+            UQ_CHECK_HIP(hipMemcpyAsync(d_perm, alt ? valsB : valsA, n * 4, hipMemcpyDeviceToDevice, s));
+            heads_first32_kernel<<<blocks_for(n), ST, 0, s>>>(alt ? k32b : k32a, n, heads);
+            UQ_LAUNCH_CHECK();
+        }
+    }
+    if (!mode32) {
+        UQ_TRY(radix_sort_pairs(ctx, keysA, valsA, keysB, valsB, n, 0, 64, rws, &alt));
+        const uint64_t* K = alt ? keysB : keysA;
+        const uint32_t* V = alt ? valsB : valsA;
+        UQ_CHECK_HIP(hipMemcpyAsync(d_perm, V, n * 4, hipMemcpyDeviceToDevice, s));
+        heads_first_kernel<<<blocks_for(n), ST, 0, s>>>(K, n, heads);
+        UQ_LAUNCH_CHECK();
+    }
+
+    // ---- refinement rounds (after a 32-bit round 0 the first one looks at the whole of chunk 0 again)
+    const uint32_t nchunks = (C + 7) / 8;
+    for (uint32_t k = mode32 ? 0 : 1; k < nchunks; ++k) {
+        // exact duplicates need no further rounds: stop as soon as no tying pair differs in what is left of the rows.
+        // That test, the flags of the rows still tying and their two scans are queued together: ONE synchronisation per round.
+        if (mode32 && k == 0) UQ_CHECK_HIP(hipMemsetAsync(tot + 2, 0xFF, 8, s));        // rows that collide on 32 bits: they do differ, no need to look
+        else {
+            UQ_CHECK_HIP(hipMemsetAsync(tot + 2, 0, 8, s));
+            tail_differs_kernel<<<blocks_for(n), ST, 0, s>>>(table, C, 8 * k, d_perm, heads, n, (uint32_t*)(tot + 2));
+            UQ_LAUNCH_CHECK();
+        }
         active_flags_kernel<<<blocks_for(n), ST, 0, s>>>(heads, n, fa, fh);
         UQ_LAUNCH_CHECK();
         UQ_TRY(uq_scan_exclusive_u32(ctx, fa, apos, n, tot));
         UQ_TRY(uq_scan_exclusive_u32(ctx, fh, hpos, n, tot + 1));
-        UQ_CHECK_HIP(hipMemcpyAsync(ctx->h_pinned, tot, 16, hipMemcpyDeviceToHost, s));
+        UQ_CHECK_HIP(hipMemcpyAsync(ctx->h_pinned, tot, 24, hipMemcpyDeviceToHost, s));
         UQ_CHECK_HIP(hipStreamSynchronize(s));
         const uint64_t m = ctx->h_pinned[0], nseg = ctx->h_pinned[1];
-        if (m == 0) break;
+        if ((uint32_t)ctx->h_pinned[2] == 0 || m == 0) break;
         compact_active_kernel<<<blocks_for(n), ST, 0, s>>>(fa, apos, fh, hpos, d_perm, n, table, C, k, pos, aval, sid, keysA, valsA);
         UQ_LAUNCH_CHECK();
         // sort #1: active rows by the value of chunk k
