@@ -56,6 +56,14 @@ int uq_timer_stop(uq_ctx* ctx, float* h_ms);
  *                 d_line_start[nlines] = offset one past the last '\n'.  nlines from uq_count_lines. */
 int uq_count_lines(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint64_t* h_nlines);
 int uq_index_lines(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint64_t nlines, uint64_t* d_line_start);
+/* uq_count_lines in pieces, for a buffer that is still being filled (a file streaming into HBM chunk by chunk, SURVEY.md 8
+ * row f2): _begin once, _chunk for every byte range [first_byte, first_byte + chunk_bytes) as it lands -- ranges are whole
+ * 16 KiB tiles of the 16-byte-aligned address space (any multiple of 16 KiB from an aligned base), the last one ends with the
+ * buffer; every byte is covered exactly once, in any order -- and _end = the line count, exactly what uq_count_lines returns for
+ * the whole buffer (uq_index_lines then reuses the census the same way). */
+int uq_count_lines_begin(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes);
+int uq_count_lines_chunk(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint64_t first_byte, uint64_t chunk_bytes);
+int uq_count_lines_end(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint64_t* h_nlines);
 
 /* ---- a1: pass-1 statistics.  Replaces uq.py:366-375, 382, 388, 415-425.
  * counts[base * 256 + qual] over every (base, quality) pair of reads [0, nreads); DNA length range;

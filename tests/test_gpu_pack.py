@@ -425,3 +425,51 @@ def test_encoder_reference_signature(ctx, tmp_path, variable):
     assert np.array_equal(dna_array.cpu().numpy(), rd) and np.array_equal(qual_array.cpu().numpy(), rq)
     assert dna_ptr == dna_array.data_ptr() and qual_ptr == qual_array.data_ptr() and st.current == n
     assert lib.free(dna_ptr) == 0 and lib.free(qual_ptr) == 0 and not lib._owned
+
+
+@pytest.mark.parametrize('offset', [0, 7])
+def test_chunked_census_equals_whole_buffer(ctx, offset):
+    """the newline census taken chunk by chunk while a file streams into HBM (uq_count_lines_begin /
+    _chunk / _end) gives the line count and -- through uq_index_lines -- the record index of the whole-buffer census,
+    whatever the chunk sizes and their order."""
+    t = ctx.torch
+    src = ops.synth_fastq(ctx, synth.Spec(S + 80, (30, 120), n_rate=1), 0, 40_000)
+    big = t.empty(src.numel() + 64, dtype=t.uint8, device=ctx.device).fill_(10)
+    big[offset:offset + src.numel()] = src
+    buf = big[offset:offset + src.numel()]
+    nl = ops.count_lines(ctx, buf)
+    ls = ops.index_lines(ctx, buf, nl)
+    mis = buf.data_ptr() & 15
+    tile = 16 << 10
+    rng = np.random.default_rng(5)
+    for trial in range(3):
+        # cut points: multiples of 16 KiB in the aligned address space
+        ntiles = (buf.numel() + mis + tile - 1) // tile
+        cuts = sorted(set(rng.integers(1, ntiles, size=[1, 5, 40][trial]).tolist()))
+        edges = [0] + [c * tile - mis for c in cuts] + [buf.numel()]
+        pieces = [(a, b - a) for a, b in zip(edges[:-1], edges[1:]) if b > a]
+        order = rng.permutation(len(pieces)) if trial else range(len(pieces))
+        cc = ops.ChunkedCensus(ctx, buf)
+        for k in order: cc.chunk(*pieces[k])
+        assert cc.end() == nl
+        assert t.equal(ops.index_lines(ctx, buf, nl), ls)
+    # a chunk that is not made of whole tiles is refused
+    from uq_amd._lib import UqHipError
+    cc = ops.ChunkedCensus(ctx, buf)
+    with pytest.raises(UqHipError):
+        cc.chunk(0, 1000)
+
+
+def test_session_load_overlaps_census_with_ingest(ctx, tmp_path):
+    """Session.load: the census is queued behind every chunk's PCIe copy; index and statistics equal the whole-buffer path's."""
+    from uq_amd import uq
+    fq = synth.fastq(S + 81, 20_000, (40, 100), n_rate=1)
+    p = tmp_path / 'in.fastq'; p.write_bytes(fq)
+    args = uq.validate_args(uq.build_parser().parse_args(['-i', str(p), '--quiet']))
+    a = uq.Session(args, ctx=ctx)
+    a.io.chunk, a.io.nbuf = 64 << 10, 4                       # many chunks
+    a.load(str(p))
+    b = uq.Session(args, ctx=ctx)
+    b.load_device(ctx.bytes_to_device(fq))
+    assert a.total == b.total == 20_000 and ctx.torch.equal(a.d_ls, b.d_ls)
+    assert np.array_equal(ops.stats_fetch(ctx, a.d_stats).counts, ops.stats_fetch(ctx, b.d_stats).counts)

@@ -79,6 +79,9 @@ SIGNATURES = {
     'uq_timer_start': [_vp],
     'uq_timer_stop': [_vp, _P(C.c_float)],
     'uq_count_lines': [_vp, _vp, _u64, _P(_u64)],
+    'uq_count_lines_begin': [_vp, _vp, _u64],
+    'uq_count_lines_chunk': [_vp, _vp, _u64, _u64, _u64],
+    'uq_count_lines_end': [_vp, _vp, _u64, _P(_u64)],
     'uq_index_lines': [_vp, _vp, _u64, _u64, _vp],
     'uq_stats_init': [_vp, _vp],
     'uq_stats_accumulate': [_vp, _vp, _vp, _u64, _u64, _vp],

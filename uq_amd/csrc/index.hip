@@ -58,12 +58,13 @@ __global__ __launch_bounds__(IDX_THREADS) void count_newlines_kernel(const uint4
 // to a word (16-bit fields: a wave's sum stays below 2^16).
 __global__ __launch_bounds__(IDX_THREADS) void census_list_kernel(const uint4* __restrict__ abuf, uint32_t mis, uint64_t nbytes, uint64_t nvec,
                                                                    uint32_t* __restrict__ partials, uint16_t* __restrict__ list,
-                                                                   uint32_t* __restrict__ overflow) {
+                                                                   uint32_t* __restrict__ overflow, uint64_t tile0) {
     // one tile per workgroup, like the bitmap form: a persistent, register-prefetching variant (the shape that pays in the
     // pack / statistics kernels) was slower here (0.81 vs 0.65 ms) -- eight small workgroups per CU already keep HBM busy
     __shared__ uint32_t lds[IDX_THREADS / 64];
     const uint32_t lane = lane_id(), w = threadIdx.x >> 6;
-    const uint64_t v0 = ((uint64_t)blockIdx.x * IDX_TILE + (uint64_t)w * IDX_WAVE_BYTES) / 16 + lane;
+    const uint64_t tile = tile0 + blockIdx.x;                 // tile0: the chunked census (uq_count_lines_chunk) walks the buffer in pieces
+    const uint64_t v0 = (tile * IDX_TILE + (uint64_t)w * IDX_WAVE_BYTES) / 16 + lane;
     uint32_t m[IDX_LOADS];
 #pragma unroll
     for (int it = 0; it < IDX_LOADS; ++it) {
@@ -84,10 +85,10 @@ __global__ __launch_bounds__(IDX_THREADS) void census_list_kernel(const uint4* _
     uint32_t base = 0, total = 0;
 #pragma unroll
     for (uint32_t i = 0; i < IDX_THREADS / 64; ++i) { const uint32_t x = lds[i]; if (i < w) base += x; total += x; }
-    if (threadIdx.x == 0) partials[blockIdx.x] = total;
+    if (threadIdx.x == 0) partials[tile] = total;
     const uint32_t ex[IDX_LOADS] = {base + (i01 & 0xFFFFu) - c0, base + T0 + (i01 >> 16) - c1, base + T0 + T1 + (i23 & 0xFFFFu) - c2,
                                     base + T0 + T1 + T2 + (i23 >> 16) - c3};
-    uint16_t* slot = list + (uint64_t)blockIdx.x * IDX_LIST_CAP;
+    uint16_t* slot = list + tile * IDX_LIST_CAP;
     bool over = false;
 #pragma unroll
     for (int it = 0; it < IDX_LOADS; ++it) {
@@ -138,11 +139,7 @@ __global__ __launch_bounds__(IDX_THREADS) void scatter_newlines_kernel(const uin
     }
 }
 
-int run_count(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint64_t* nblocks_out, bool list_form) {
-    const uint32_t mis = (uint32_t)((uintptr_t)d_buf & 15);
-    const uint64_t nvec = (nbytes + mis + 15) / 16;
-    const uint64_t nb = (nvec * 16 + IDX_TILE - 1) / IDX_TILE;
-    UQ_REQUIRE(nb <= 0x7fffffffu, "uq_count_lines: buffer too large for one launch");
+int census_buffers(uq_ctx* ctx, uint64_t nb) {
     if (nb + 1 > ctx->idx_partials_cap) {
         UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
         if (ctx->idx_partials) UQ_CHECK_HIP(hipFree(ctx->idx_partials));
@@ -154,11 +151,20 @@ int run_count(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint64_t* nblo
         UQ_CHECK_HIP(hipMalloc((void**)&ctx->idx_bitmap, nb * IDX_TILE_VECS * sizeof(uint16_t) + 16));
         ctx->idx_partials_cap = nb + 1;
     }
+    return 0;
+}
+
+int run_count(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint64_t* nblocks_out, bool list_form) {
+    const uint32_t mis = (uint32_t)((uintptr_t)d_buf & 15);
+    const uint64_t nvec = (nbytes + mis + 15) / 16;
+    const uint64_t nb = (nvec * 16 + IDX_TILE - 1) / IDX_TILE;
+    UQ_REQUIRE(nb <= 0x7fffffffu, "uq_count_lines: buffer too large for one launch");
+    UQ_TRY(census_buffers(ctx, nb));
     if (list_form) {
         uint32_t* d_over = (uint32_t*)(ctx->idx_bitmap + nb * IDX_TILE_VECS);          // the 16 spare bytes behind the slots
         UQ_CHECK_HIP(hipMemsetAsync(d_over, 0, 4, ctx->stream));
         census_list_kernel<<<(uint32_t)nb, IDX_THREADS, 0, ctx->stream>>>((const uint4*)(d_buf - mis), mis, nbytes, nvec, ctx->idx_partials,
-                                                                         ctx->idx_bitmap, d_over);
+                                                                         ctx->idx_bitmap, d_over, 0);
     } else {
         count_newlines_kernel<<<(uint32_t)nb, IDX_THREADS, 0, ctx->stream>>>((const uint4*)(d_buf - mis), mis, nbytes, nvec, ctx->idx_partials,
                                                                             ctx->idx_bitmap);
@@ -180,6 +186,8 @@ int uq_index_run_census(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint
     return 0;
 }
 
+static int finish_count(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint64_t nb, uint64_t* h_nlines);
+
 extern "C" int uq_count_lines(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint64_t* h_nlines) {
     UQ_REQUIRE(ctx && h_nlines, "uq_count_lines: null argument");
     ctx->idx_buf = nullptr;
@@ -188,7 +196,13 @@ extern "C" int uq_count_lines(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes
     uint64_t nb;
     UQ_TRY(run_count(ctx, d_buf, nbytes, &nb, true));
     // exclusive scan of the per-tile counts right away: its total is the census, and uq_index_lines
-    // reuses the scanned offsets (and the bitmap) for the same buffer
+    // reuses the scanned offsets (and the lists) for the same buffer
+    return finish_count(ctx, d_buf, nbytes, nb, h_nlines);
+}
+
+// ---- the census in pieces: a file arrives in HBM chunk by chunk; every chunk's newlines are counted and
+// listed while the next one is still crossing PCIe, so that only the scan of the per-tile counts is left when the last byte lands.
+static int finish_count(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint64_t nb, uint64_t* h_nlines) {
     void* scr;
     UQ_TRY(uq_scratch(ctx, 256, &scr));
     UQ_TRY(uq_scan_exclusive_u32(ctx, ctx->idx_partials, ctx->idx_partials, nb, (uint64_t*)scr));
@@ -199,6 +213,45 @@ extern "C" int uq_count_lines(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes
     // the lists are only good when every tile's newlines fitted its slot; otherwise uq_index_lines runs the bitmap form
     if ((uint32_t)ctx->h_pinned[1] == 0) { ctx->idx_buf = d_buf; ctx->idx_nbytes = nbytes; ctx->idx_nlines = *h_nlines; }
     return 0;
+}
+
+extern "C" int uq_count_lines_begin(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes) {
+    UQ_REQUIRE(ctx && (d_buf || nbytes == 0), "uq_count_lines_begin: null argument");
+    ctx->idx_buf = nullptr;
+    if (nbytes == 0) return 0;
+    const uint32_t mis = (uint32_t)((uintptr_t)d_buf & 15);
+    const uint64_t nb = (((nbytes + mis + 15) / 16) * 16 + IDX_TILE - 1) / IDX_TILE;
+    UQ_REQUIRE(nb <= 0x7fffffffu, "uq_count_lines_begin: buffer too large");
+    UQ_TRY(census_buffers(ctx, nb));
+    UQ_CHECK_HIP(hipMemsetAsync(ctx->idx_bitmap + nb * IDX_TILE_VECS, 0, 4, ctx->stream));
+    return 0;
+}
+
+extern "C" int uq_count_lines_chunk(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint64_t first_byte, uint64_t chunk_bytes) {
+    UQ_REQUIRE(ctx && d_buf, "uq_count_lines_chunk: null argument");
+    if (chunk_bytes == 0) return 0;
+    const uint32_t mis = (uint32_t)((uintptr_t)d_buf & 15);
+    const uint64_t nvec = (nbytes + mis + 15) / 16;
+    const uint64_t nb = (nvec * 16 + IDX_TILE - 1) / IDX_TILE;
+    UQ_REQUIRE(first_byte + chunk_bytes <= nbytes, "uq_count_lines_chunk: chunk beyond the buffer");
+    // chunks are whole census tiles (16 KiB of the 16-byte-aligned address space), except that the last one ends with the buffer
+    UQ_REQUIRE((first_byte + mis) % IDX_TILE == 0 || first_byte == 0, "uq_count_lines_chunk: a chunk must start on a 16 KiB tile boundary");
+    UQ_REQUIRE((first_byte + chunk_bytes + mis) % IDX_TILE == 0 || first_byte + chunk_bytes == nbytes,
+               "uq_count_lines_chunk: a chunk must end on a 16 KiB tile boundary or with the buffer");
+    const uint64_t t0 = (first_byte + mis) / IDX_TILE, t1 = first_byte + chunk_bytes == nbytes ? nb : (first_byte + chunk_bytes + mis) / IDX_TILE;
+    if (t1 <= t0) return 0;
+    census_list_kernel<<<(uint32_t)(t1 - t0), IDX_THREADS, 0, ctx->stream>>>((const uint4*)(d_buf - mis), mis, nbytes, nvec, ctx->idx_partials,
+                                                                            ctx->idx_bitmap, (uint32_t*)(ctx->idx_bitmap + nb * IDX_TILE_VECS), t0);
+    UQ_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int uq_count_lines_end(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint64_t* h_nlines) {
+    UQ_REQUIRE(ctx && h_nlines, "uq_count_lines_end: null argument");
+    if (nbytes == 0) { *h_nlines = 0; return 0; }
+    const uint32_t mis = (uint32_t)((uintptr_t)d_buf & 15);
+    const uint64_t nb = (((nbytes + mis + 15) / 16) * 16 + IDX_TILE - 1) / IDX_TILE;
+    return finish_count(ctx, d_buf, nbytes, nb, h_nlines);
 }
 
 extern "C" int uq_index_lines(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint64_t nlines, uint64_t* d_line_start) {

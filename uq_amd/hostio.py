@@ -33,8 +33,10 @@ class Staging:
         return self._pin, self._np, self._ev
 
     # ------------------------------------------------------------------ file -> HBM
-    def file_to_device(self, path, offset=0, size=None, out=None):
-        """Bytes [offset, offset + size) of `path` as a uint8 device tensor (or into `out`)."""
+    def file_to_device(self, path, offset=0, size=None, out=None, on_chunk=None):
+        """Bytes [offset, offset + size) of `path` as a uint8 device tensor (or into `out`).  on_chunk(d, lo, n): called right
+        after the copy of bytes [lo, lo + n) has been queued on the stream -- work it queues there runs on that chunk while
+        the next ones are still being read and copied (row f2: the newline census of the encoder)."""
         ctx = self.ctx
         if size is None:
             size = os.path.getsize(path) - offset
@@ -67,6 +69,7 @@ class Staging:
                 lo = j * self.chunk
                 d[lo:lo + n].copy_(pin[k][:n], non_blocking=True)
                 ev[k].record()
+                if on_chunk is not None: on_chunk(d, lo, n)
                 nxt = j + self.nbuf
                 if nxt < nchunks:
                     # the buffer is free for the next read once its copy has left the host

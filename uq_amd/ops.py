@@ -20,6 +20,22 @@ def count_lines(ctx, buf):
     return n.value
 
 
+class ChunkedCensus:
+    """uq_count_lines over a buffer that is still being filled: `chunk(lo, n)` as each piece lands, `end()` = the line count."""
+
+    def __init__(self, ctx, buf):
+        self.ctx, self.buf = ctx, buf
+        call('uq_count_lines_begin', ctx.h, _p(buf), buf.numel())
+
+    def chunk(self, lo, n):
+        call('uq_count_lines_chunk', self.ctx.h, _p(self.buf), self.buf.numel(), int(lo), int(n))
+
+    def end(self):
+        out = C.c_uint64()
+        call('uq_count_lines_end', self.ctx.h, _p(self.buf), self.buf.numel(), C.byref(out))
+        return out.value
+
+
 def index_lines(ctx, buf, nlines):
     """int64 tensor [nlines + 1] of line start offsets (bit pattern of uint64)."""
     t = ctx.torch

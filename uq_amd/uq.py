@@ -135,9 +135,18 @@ class Session:
         ops, ctx = self.ops, self.ctx
         if os.path.getsize(path) == 0: error('ERROR: empty input')
         self.path, self._host = path, None
-        self.load_device(self.io.file_to_device(path))                           # pinned, chunked, overlapped with the reads (row f2)
+        # pinned, chunked, file reads overlapped with the PCIe copies; the newline census of a chunk is queued right behind its
+        # copy (row f2), so that only the scan of the per-tile counts is left when the last byte lands
+        census = {}
 
-    def load_device(self, d_buf):
+        def on_chunk(d, lo, n):
+            if 'c' not in census: census['c'] = ops.ChunkedCensus(ctx, d)
+            census['c'].chunk(lo, n)
+        chunked = not getattr(self.args, 'one_pass', False) and self.io.chunk % (16 << 10) == 0
+        d_buf = self.io.file_to_device(path, on_chunk=on_chunk if chunked else None)
+        self.load_device(d_buf, nlines=census['c'].end() if 'c' in census else None)
+
+    def load_device(self, d_buf, nlines=None):
         """The same for FASTQ bytes that are already in HBM (a uint8 device tensor): record index + pass-1 statistics, as
         separate passes over the stream (census -> index -> statistics).  --one-pass does all of it in ONE read of the stream
         together with a speculative pack (uq_encode_stream; the guess comes from the head of this file); analyse() /
@@ -152,7 +161,7 @@ class Session:
         if one_pass:
             nlines, self.d_ls, self.d_stats, spec, self.load_path = ops.encode_one_pass(ctx, self.d_buf, None, args.notricks, args.pad)
             if spec is not None: self._spec = spec + (None,)
-        else:
+        elif nlines is None:                                                     # else: the census ran chunk by chunk during the load
             nlines = ops.count_lines(ctx, self.d_buf)
         if nlines % 4 != 0:
             error('ERROR: The FASTQ file provided contains' + str(nlines) + 'rows, which is not divisible by 4!')
