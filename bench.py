@@ -90,6 +90,8 @@ def main():
     ap.add_argument('--reads', type=int, default=10_000_000, help='reads per GPU (default: BASELINE configs[1])')
     ap.add_argument('--length', type=int, default=150)
     ap.add_argument('--cpu-sample', type=int, default=100_000, help='reads timed on the host for cpu_baseline (0 = skip)')
+    ap.add_argument('--sort-reads', type=int, default=25_000_000,
+                    help='N > 1 only: reads per GPU of the global --sort leg (BASELINE configs[3]: 200 M over 8 GPUs = 25 M each); 0 = skip')
     ap.add_argument('--force-dist', action='store_true', help='initialise the process group and run the collectives even with one rank')
     ap.add_argument('--one-pass', action='store_true',
                     help='uq_encode_stream: census + record index + statistics + speculative pack (decisions guessed from the shard\'s first '
@@ -236,6 +238,55 @@ def main():
             best = (q1 - q0) if best is None or (q1 - q0) < best else best
             if qres is None: best = None; break
         qname_ms = None if best is None else best * 1e3
+    # ---- N > 1: the north_star's scaling claim is about the global --sort (BASELINE configs[3]: 200 M x 150 bp over 8 GPUs,
+    # `--sort QUAL --raw DNA QUAL QNAME`), whose data-path exchange the weak-scaling step above never touches.  Timed beside it:
+    # sample sort of the QUAL table over the ranks (local sort -> splitters -> all-to-all(v) of rows + file-wide indices by key
+    # range -> stable local sort of the received runs) and the DNA table moved into that order (requests to the owners, rows
+    # back): uq_amd.dist.global_sort_rows + dist_gather_rows, the table movements of that mix (QNAME columns: the same gather
+    # on 8-byte rows, not repeated).  Reported as `sort_leg`; `value` stays the weak-scaling step.
+    sort_leg = None
+    if use_dist and args.sort_reads > 0 and args.workload == 'cfg2':
+        from uq_amd import dist as uqdist
+        be = uqdist.HipRows(ctx)
+        ns = args.sort_reads
+        spec3 = synth.Spec(20261003 + 4, args.length, dup='qual', dup_templates=max(1, ns * world // 16))
+        buf3 = ops.synth_fastq(ctx, spec3, rank * ns, ns)
+        nl3 = ops.count_lines(ctx, buf3)
+        ls3 = ops.index_lines(ctx, buf3, nl3)
+        st3 = ops.stats_new(ctx)
+        ops.stats_accumulate(ctx, st3, buf3, ls3, 0, ns)
+        hs3 = fetch(st3)
+        d3 = host_decide(hs3)
+        p3 = ops.make_pack_params(d3['bases'], d3['qualities'], d3['N_qual'], d3['bits_per_base'], d3['bits_per_quality'], d3['variable_read_lengths'],
+                                  d3['dna_bytes_per_row'], d3['quality_bytes_per_row'], d3['dna_max'], hs3.max_record_bytes)
+        dna3, qual3, _ = ops.pack(ctx, buf3, ls3, 0, ns, p3)
+        del buf3, ls3
+        Cd3, Cq3 = d3['dna_bytes_per_row'], d3['quality_bytes_per_row']
+        starts = [r * ns for r in range(world + 1)]
+
+        def sort_step():
+            gs = uqdist.global_sort_rows(be, qual3, ns, Cq3, rank * ns)
+            dg = uqdist.dist_gather_rows(be, dna3, ns, Cd3, starts, gs['gidx'])
+            return gs, dg
+        sort_step()
+        fence()
+        ts = time.perf_counter()
+        K3 = 3
+        for _ in range(K3): gs, dg = sort_step()
+        fence()
+        dts = time.perf_counter() - ts
+        t3 = torch.tensor([dts], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t3, op=dist.ReduceOp.MAX)
+        dts = float(t3.item()) / K3
+        rows_here = torch.tensor([gs['rows']], dtype=torch.int64, device=red_dev)
+        dist.all_reduce(rows_here, op=dist.ReduceOp.MAX)
+        sort_leg = {'workload': 'BASELINE configs[3] shape: %d x %dbp per GPU, 10 %% of the reads copy one of N/16 QUAL templates; global --sort QUAL: '
+                                'sample sort of the %d-byte QUAL rows over %d rank(s) + the %d-byte DNA rows moved into that order'
+                                % (ns, args.length, Cq3, world, Cd3),
+                    'reads_per_gpu': ns, 'ms': round(dts * 1e3, 3), 'reads_per_s': round(ns * world / dts, 1),
+                    'largest_shard_after_exchange': int(rows_here.item()),
+                    'exchanged_bytes_per_rank': int(ns * (Cq3 + 8 + 8 + Cd3) * (world - 1) / world)}
+        del dna3, qual3, gs, dg
     if state['bad'] is not None and ops.bad_index(state['bad']) is not None:
         raise RuntimeError('pack reported an uncoded symbol at read %d' % ops.bad_index(state['bad']))
     d = state['d']
@@ -282,6 +333,7 @@ def main():
                      'algorithmic_bytes_per_launch': int(algo_bytes), 'avg_launch_ms': round(pack_ms, 4)},
     }
 
+    if sort_leg is not None: result['sort_leg'] = sort_leg
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         ns = min(args.cpu_sample, nreads)
         end = int(state['ls'][4 * ns].item())

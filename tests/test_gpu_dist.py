@@ -144,13 +144,16 @@ def test_bench_two_ranks_rehearsal():
     env = dict(os.environ, UQ_DIST_BACKEND='gloo', PYTHONPATH=REPO)
     out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
                           '--master-port', str(_free_port()), os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
-                          '--reads', '200000'], env=env, cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+                          '--reads', '200000', '--sort-reads', '150000'], env=env, cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert out.returncode == 0, out.stderr.decode(errors='replace')[-2000:]
     lines = [l for l in out.stdout.decode().splitlines() if l.startswith('{')]
     assert len(lines) == 1
     r = json.loads(lines[0])
     assert r['n_gpus'] == 2 and r['scaling'] == 'weak' and r['value'] > 0 and r['config']['reads_per_gpu'] == 200000
     assert r['roofline']['bound'] == 'hbm' and 'cpu_baseline' not in r          # the CPU baseline is timed at N = 1 only
+    # the global --sort leg (BASELINE configs[3] shape): sample sort + all-to-all(v) of the QUAL rows, DNA rows moved along
+    sl = r['sort_leg']
+    assert sl['reads_per_gpu'] == 150000 and sl['ms'] > 0 and 150000 <= sl['largest_shard_after_exchange'] <= 200000
 
 
 def _run_sharded_expect_error(world, inp, out, flags, timeout=120):

@@ -170,33 +170,33 @@ class HipRows:
         return ops.lower_bound_rows(self.ctx, sorted_table, rows, cols, probes, nprobes)
 
 
-def exchange_v(parts, dist, torch, device, dtype, group=None):
-    """all-to-all(v): parts[d] (1-D tensor) goes to rank d; returns the list received from every source.
-    Built from batched point-to-point sends/receives (what NCCL/RCCL's all-to-all is made of, and it also
-    runs on gloo), after an all-gather of the counts."""
+def exchange_split(send, splits, dist, torch, device, dtype, group=None):
+    """all-to-all(v) of ONE contiguous 1-D tensor: elements [sum(splits[:d]), sum(splits[:d + 1])) go to rank d.  Returns
+    (received tensor, list of received counts per source).  Two collectives -- the counts, then the payload, both
+    `all_to_all_single` (on the nccl backend RCCL's all-to-all: every xGMI link carries its own peer's slice at once) -- and
+    ONE host round trip (the receive sizes: the output buffer has to be allocated)."""
     world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
     out_device = device
     if dist.get_backend(group) == 'gloo' and torch.device(device).type != 'cpu':
-        # gloo rehearsal on a GPU box (several ranks sharing one card): stage through the host
-        parts = [p.cpu() for p in parts]
+        send = send.cpu()                            # gloo rehearsal on a GPU box (several ranks sharing one card): staged through the host
         device = 'cpu'
-    counts = torch.tensor([int(p.numel()) for p in parts], dtype=torch.int64, device=device)
-    allc = [torch.empty_like(counts) for _ in range(world)]
-    dist.all_gather(allc, counts, group=group)
-    recv = [torch.empty(int(allc[s][rank].item()), dtype=dtype, device=device) for s in range(world)]
-    ops_ = []
-    for peer in range(world):
-        if peer == rank:
-            recv[rank].copy_(parts[rank])
-            continue
-        if parts[peer].numel(): ops_.append(dist.P2POp(dist.isend, parts[peer].contiguous(), peer, group))
-        if recv[peer].numel(): ops_.append(dist.P2POp(dist.irecv, recv[peer], peer, group))
-    if ops_:
-        for req in dist.batch_isend_irecv(ops_): req.wait()
+    splits = [int(x) for x in splits]
+    sc = torch.tensor(splits, dtype=torch.int64, device=device)
+    rc = torch.empty_like(sc)
+    dist.all_to_all_single(rc, sc, group=group)
+    rcounts = [int(x) for x in rc.tolist()]
+    recv = torch.empty(sum(rcounts), dtype=dtype, device=device)
+    dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=rcounts, input_split_sizes=splits, group=group)
     if out_device != device:
-        recv = [r.to(out_device) for r in recv]
-    return recv
+        recv = recv.to(out_device)
+    return recv, rcounts
+
+
+def exchange_v(parts, dist, torch, device, dtype, group=None):
+    """all-to-all(v): parts[d] (1-D tensor) goes to rank d; returns the list received from every source."""
+    send = torch.cat([p.reshape(-1) for p in parts]) if len(parts) > 1 else parts[0].reshape(-1)
+    recv, rcounts = exchange_split(send, [int(p.numel()) for p in parts], dist, torch, device, dtype, group)
+    return list(recv.split(rcounts))
 
 
 def choose_splitters(samples, cols, world):
@@ -238,13 +238,10 @@ def global_sort_rows(be, table, rows, cols, read_offset, group=None, samples_per
     # 2. cut the sorted shard at the splitters: rows < splitter_k stay below cut k (lower bound: equal rows go up together)
     cuts = be.lower_bound_rows(local_sorted, rows, cols, d_split, world - 1).cpu().tolist() if rows else [0] * (world - 1)
     bounds = [0] + [int(c) for c in cuts] + [rows]
-    row_parts = [local_sorted[bounds[d] * cols:bounds[d + 1] * cols] for d in range(world)]
-    idx_parts = [gidx[bounds[d]:bounds[d + 1]] for d in range(world)]
-    # 3. all-to-all(v) of rows and their global indices
-    recv_rows = exchange_v(row_parts, dist, torch, be.device, torch.uint8, group)
-    recv_idx = exchange_v(idx_parts, dist, torch, be.device, torch.int64, group)
-    merged = torch.cat(recv_rows)
-    midx = torch.cat(recv_idx)
+    nsend = [bounds[d + 1] - bounds[d] for d in range(world)]
+    # 3. all-to-all(v) of rows and their global indices: the sorted shard IS the send buffer, cut at the splitters
+    merged, _ = exchange_split(local_sorted, [k * cols for k in nsend], dist, torch, be.device, torch.uint8, group)
+    midx, _ = exchange_split(gidx, nsend, dist, torch, be.device, torch.int64, group)
     m = int(midx.numel())
     # 4. stable local sort of the received runs (source-rank order = file order inside ties)
     if m:
@@ -253,10 +250,10 @@ def global_sort_rows(be, table, rows, cols, read_offset, group=None, samples_per
         oidx = be.gather_rows(midx.view(torch.uint8), m, 8, perm2).view(torch.int64)
     else:
         out, oidx = merged, midx
-    counts = torch.tensor([m], dtype=torch.int64, device='cpu' if dist.get_backend(group) == 'gloo' else be.device)
-    allm = [torch.empty_like(counts) for _ in range(world)]
-    dist.all_gather(allm, counts, group=group)
-    offset = sum(int(allm[r].item()) for r in range(rank))
+    counts = torch.zeros(world, dtype=torch.int64, device='cpu' if dist.get_backend(group) == 'gloo' else be.device)
+    counts[rank] = m
+    dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+    offset = sum(counts.tolist()[:rank])
     return dict(table=out, rows=m, gidx=oidx, offset=offset)
 
 
@@ -288,8 +285,9 @@ def dist_scatter_rows(be, values, cols, shard_starts, gidx, group=None):
         return be.gather_rows(values, n, cols, inv) if n else values
     order, sorted_idx, bounds = _route_by_owner(be, shard_starts, gidx, world)
     sorted_vals = be.gather_rows(values, n, cols, order) if n else values
-    ridx = torch.cat(exchange_v([sorted_idx[bounds[d]:bounds[d + 1]] for d in range(world)], dist, torch, be.device, torch.int64, group))
-    rval = torch.cat(exchange_v([sorted_vals[bounds[d] * cols:bounds[d + 1] * cols] for d in range(world)], dist, torch, be.device, torch.uint8, group))
+    nsend = [bounds[d + 1] - bounds[d] for d in range(world)]
+    ridx, _ = exchange_split(sorted_idx, nsend, dist, torch, be.device, torch.int64, group)
+    rval, _ = exchange_split(sorted_vals, [k * cols for k in nsend], dist, torch, be.device, torch.uint8, group)
     if int(ridx.numel()) != mine:
         raise RuntimeError('dist_scatter_rows: received %d rows for a shard of %d' % (int(ridx.numel()), mine))
     inv = torch.empty(mine, dtype=torch.int32, device=be.device)
@@ -313,12 +311,11 @@ def dist_gather_rows(be, table, rows, cols, shard_starts, gidx, group=None):
     probes = torch.arange(1, world, dtype=torch.uint8, device=be.device)
     cuts = be.lower_bound_rows(sorted_owner, n, 1, probes, world - 1).cpu().tolist() if n else [0] * (world - 1)
     bounds = [0] + [int(c) for c in cuts] + [n]
-    req = exchange_v([sorted_idx[bounds[d]:bounds[d + 1]] for d in range(world)], dist, torch, be.device, torch.int64, group)
-    replies = []
-    for s in range(world):
-        want = (req[s] - int(shard_starts[rank])).to(torch.int32)
-        replies.append(be.gather_rows(table, rows, cols, want) if want.numel() else torch.empty(0, dtype=torch.uint8, device=be.device))
-    got = torch.cat(exchange_v(replies, dist, torch, be.device, torch.uint8, group))
+    req, nreq = exchange_split(sorted_idx, [bounds[d + 1] - bounds[d] for d in range(world)], dist, torch, be.device, torch.int64, group)
+    # one gather serves all the requesters: the reply buffer is the requests' order, i.e. already grouped by destination
+    want = (req - int(shard_starts[rank])).to(torch.int32)
+    reply = be.gather_rows(table, rows, cols, want) if want.numel() else torch.empty(0, dtype=torch.uint8, device=be.device)
+    got, _ = exchange_split(reply, [k * cols for k in nreq], dist, torch, be.device, torch.uint8, group)
     # rows came back in `order`; undo it: out[order[j]] = got[j]
     inv = torch.empty(n, dtype=torch.int32, device=be.device)
     inv[order.to(torch.int64) & 0xFFFFFFFF] = torch.arange(n, dtype=torch.int32, device=be.device)
