@@ -50,7 +50,7 @@ struct EncGeom {
     uint32_t rmax;                 // reads per batch: what the row images hold
     uint32_t img_d, img_q;         // LDS bytes of the two row images (16-byte multiples, room for the skew)
     uint32_t q_addlo, q_addhi, n_char, n_code;      // lookup-free conversion, as pack.hip
-    uint32_t debug;                // timing experiments (UQ_ENC_DEBUG): bit 0 = no look-back (results are wrong)
+    uint32_t debug;                // timing experiments (UQ_ENC_DEBUG; results are wrong): bit 0 = no look-back, bit 1 = no publish either
 };
 
 struct EncCtl {
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(EN_THREADS, STATS ? 3 : 4) void encode_tile_kernel(
         for (uint32_t i = 0; i < EN_THREADS / 64; ++i) { const uint32_t x = misc[i]; if (i < w) base += x; count += x; }
         const uint32_t nhalo = misc[4];
         unsigned long long arrived = 0;
-        if (tid == 0) arrived = lb_arrive(lb, t, count);                       // published as early as possible
+        if (tid == 0 && !(g.debug & 2)) arrived = lb_arrive(lb, t, count);      // published as early as possible
         // ---- line starts (stage offsets of the bytes after the newlines, stream order) and the bytes themselves -> LDS
         const uint32_t shift = t == 0 ? 1u : 0u;                               // tile 0: entry 0 = the start of the stream
         const uint32_t ex[EN_NV + 1] = {base + (i01 & 0xFFFFu) - c0, base + T0 + (i01 >> 16) - c1, base + T0 + T1 + (i23 & 0xFFFFu) - c2,
