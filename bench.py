@@ -304,7 +304,11 @@ def main():
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            if args.workload == 'cfg2' and tj.get('reads') == nreads and tj.get('length') == args.length:
+            # counters are taken in separate rocprofv3 --pmc passes (tools/pmc_traffic.sh), not in this run: the figure is only
+            # quoted while the kernel's source is byte for byte the one it was measured on
+            import hashlib
+            same_kernel = hashlib.sha256(open(os.path.join(HERE, tj['kernel_source']), 'rb').read()).hexdigest() == tj['kernel_source_sha256']
+            if args.workload == 'cfg2' and tj.get('reads') == nreads and tj.get('length') == args.length and same_kernel:
                 traffic = tj.get('hbm_bytes_per_launch')
         except Exception:
             traffic = None
