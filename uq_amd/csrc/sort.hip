@@ -133,6 +133,58 @@ __global__ void compact_active_kernel(const uint32_t* __restrict__ a, const uint
     vals[u] = u;
 }
 
+// ---- the same compaction without arrays of n flags and their scans: per block of CB sorted positions the number of rows
+// that still tie and of tie segments that start there (counts[2 b], [2 b + 1]); after a scan of those few counters the
+// second kernel recomputes the flags of its block, ranks them inside the block and writes the compacted lists.
+constexpr int CB = 1024;                     // positions per workgroup of 256: four per lane
+__device__ __forceinline__ void active_of(const uint8_t* __restrict__ heads, uint64_t n, uint64_t j, bool& act, bool& seg) {
+    act = seg = false;
+    if (j >= n) return;
+    const bool hd = heads[j] != 0;
+    const bool next_head = (j + 1 == n) || heads[j + 1] != 0;
+    act = !(hd && next_head);
+    seg = act && hd;
+}
+__global__ __launch_bounds__(ST) void active_count_kernel(const uint8_t* __restrict__ heads, uint64_t n, uint32_t* __restrict__ counts) {
+    __shared__ uint32_t sa[ST / 64], sh[ST / 64];
+    const uint64_t j0 = (uint64_t)blockIdx.x * CB + (uint64_t)threadIdx.x * 4;
+    uint32_t a = 0, h = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { bool act, seg; active_of(heads, n, j0 + i, act, seg); a += act; h += seg; }
+    a = wave_sum(a); h = wave_sum(h);
+    if (lane_id() == 0) { sa[threadIdx.x >> 6] = a; sh[threadIdx.x >> 6] = h; }
+    __syncthreads();
+    if (threadIdx.x == 0) { counts[2 * (uint64_t)blockIdx.x] = sa[0] + sa[1] + sa[2] + sa[3]; counts[2 * (uint64_t)blockIdx.x + 1] = sh[0] + sh[1] + sh[2] + sh[3]; }
+}
+// offs = exclusive scan of counts (pairs interleaved: scanned as u64 = {actives, segments}, both below 2^32)
+__global__ __launch_bounds__(ST) void compact_active2_kernel(const uint8_t* __restrict__ heads, const unsigned long long* __restrict__ offs,
+                                                             const uint32_t* __restrict__ perm, uint64_t n, const uint8_t* __restrict__ table,
+                                                             uint32_t C, uint32_t k, uint32_t* __restrict__ pos, uint32_t* __restrict__ aval,
+                                                             uint32_t* __restrict__ sid, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    __shared__ unsigned long long lds[ST / 64 + 1];
+    const uint64_t j0 = (uint64_t)blockIdx.x * CB + (uint64_t)threadIdx.x * 4;
+    bool act[4], seg[4];
+    unsigned long long mine = 0;             // low word: actives, high word: segment heads
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { active_of(heads, n, j0 + i, act[i], seg[i]); mine += (unsigned long long)act[i] + ((unsigned long long)seg[i] << 32); }
+    unsigned long long total;
+    unsigned long long ex = block_exclusive_sum<unsigned long long, ST / 64>(mine, lds, total) + offs[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (act[i]) {
+            const uint32_t u = (uint32_t)ex;
+            const uint32_t segs_before = (uint32_t)(ex >> 32);
+            const uint32_t row = perm[j0 + i];
+            pos[u] = (uint32_t)(j0 + i);
+            aval[u] = row;
+            sid[u] = segs_before + (seg[i] ? 1u : 0u) - 1u;
+            keys[u] = load_chunk_be(table + (uint64_t)row * C, C, k);
+            vals[u] = u;
+        }
+        ex += (unsigned long long)act[i] + ((unsigned long long)seg[i] << 32);
+    }
+}
+
 // d[t] = chunk value differs from the previous active element (in chunk order)
 __global__ void diff_flags_kernel(const uint64_t* __restrict__ keys, uint64_t m, uint32_t* __restrict__ d) {
     uint64_t t = (uint64_t)blockIdx.x * ST + threadIdx.x;
@@ -261,15 +313,16 @@ int sort_rows_core(uq_ctx* ctx, const uint8_t* table, uint64_t n, uint32_t C, ui
             tail_differs_kernel<<<blocks_for(n), ST, 0, s>>>(table, C, 8 * k, d_perm, heads, n, (uint32_t*)(tot + 2));
             UQ_LAUNCH_CHECK();
         }
-        active_flags_kernel<<<blocks_for(n), ST, 0, s>>>(heads, n, fa, fh);
+        const uint64_t ncb = (n + CB - 1) / CB;
+        uint32_t* bcnt = apos;                                                  // 2 counters per block of CB positions, then their scan
+        active_count_kernel<<<(uint32_t)ncb, ST, 0, s>>>(heads, n, bcnt);
         UQ_LAUNCH_CHECK();
-        UQ_TRY(uq_scan_exclusive_u32(ctx, fa, apos, n, tot));
-        UQ_TRY(uq_scan_exclusive_u32(ctx, fh, hpos, n, tot + 1));
+        UQ_TRY(uq_scan_exclusive_u64(ctx, (const uint64_t*)bcnt, (uint64_t*)bcnt, ncb, tot));      // {actives, segments} packed in one u64
         UQ_CHECK_HIP(hipMemcpyAsync(ctx->h_pinned, tot, 24, hipMemcpyDeviceToHost, s));
         UQ_CHECK_HIP(hipStreamSynchronize(s));
-        const uint64_t m = ctx->h_pinned[0], nseg = ctx->h_pinned[1];
+        const uint64_t m = ctx->h_pinned[0] & 0xFFFFFFFFull, nseg = ctx->h_pinned[0] >> 32;
         if ((uint32_t)ctx->h_pinned[2] == 0 || m == 0) break;
-        compact_active_kernel<<<blocks_for(n), ST, 0, s>>>(fa, apos, fh, hpos, d_perm, n, table, C, k, pos, aval, sid, keysA, valsA);
+        compact_active2_kernel<<<(uint32_t)ncb, ST, 0, s>>>(heads, (const unsigned long long*)bcnt, d_perm, n, table, C, k, pos, aval, sid, keysA, valsA);
         UQ_LAUNCH_CHECK();
         // sort #1: active rows by the value of chunk k
         UQ_TRY(radix_sort_pairs(ctx, keysA, valsA, keysB, valsB, m, 0, 64, rws, &alt));
@@ -299,6 +352,41 @@ __global__ void heads_to_u32_kernel(const uint8_t* __restrict__ heads, uint64_t 
     uint64_t j = (uint64_t)blockIdx.x * ST + threadIdx.x;
     if (j < n) f[j] = heads[j];
 }
+// the same without the n-sized flag array and its scan: heads per block of CB positions, then ranks inside the block
+__global__ __launch_bounds__(ST) void heads_count_kernel(const uint8_t* __restrict__ heads, uint64_t n, uint32_t* __restrict__ counts) {
+    __shared__ uint32_t sc[ST / 64];
+    const uint64_t j0 = (uint64_t)blockIdx.x * CB + (uint64_t)threadIdx.x * 4;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c += (j0 + i < n && heads[j0 + i]) ? 1u : 0u;
+    c = wave_sum(c);
+    if (lane_id() == 0) sc[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = sc[0] + sc[1] + sc[2] + sc[3];
+}
+__global__ __launch_bounds__(ST) void keys_from_groups2_kernel(const uint8_t* __restrict__ heads, const uint32_t* __restrict__ boffs,
+                                                               const uint32_t* __restrict__ perm, uint64_t n, uint32_t* __restrict__ key,
+                                                               uint32_t* __restrict__ sorted_key, uint32_t* __restrict__ uidx) {
+    __shared__ uint32_t lds[ST / 64 + 1];
+    const uint64_t j0 = (uint64_t)blockIdx.x * CB + (uint64_t)threadIdx.x * 4;
+    bool hd[4];
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { hd[i] = j0 + i < n && heads[j0 + i]; c += hd[i]; }
+    uint32_t total;
+    uint32_t g = block_exclusive_sum<uint32_t, ST / 64>(c, lds, total) + boffs[blockIdx.x];       // heads in front of position j0
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint64_t j = j0 + i;
+        if (j >= n) break;
+        g += hd[i];                              // inclusive count of heads
+        const uint32_t row = perm[j];
+        if (key) key[row] = g - 1;
+        if (sorted_key) sorted_key[j] = g - 1;
+        if (uidx && hd[i]) uidx[g - 1] = row;
+    }
+}
+
 __global__ void keys_from_groups_kernel(const uint8_t* __restrict__ heads, const uint32_t* __restrict__ gscan, const uint32_t* __restrict__ perm,
                                         uint64_t n, uint32_t* __restrict__ key, uint32_t* __restrict__ sorted_key, uint32_t* __restrict__ uidx) {
     uint64_t j = (uint64_t)blockIdx.x * ST + threadIdx.x;
@@ -379,10 +467,11 @@ extern "C" int uq_unique_rows(uq_ctx* ctx, const uint8_t* d_table, uint64_t rows
     uint32_t* uidx = gscan + rows;
     uint64_t* tot = (uint64_t*)(uidx + rows);
     tot = (uint64_t*)(((uintptr_t)tot + 7) & ~uintptr_t(7));
-    heads_to_u32_kernel<<<blocks_for(rows), ST, 0, ctx->stream>>>(c.heads, rows, f);
+    const uint64_t ncb = (rows + CB - 1) / CB;
+    heads_count_kernel<<<(uint32_t)ncb, ST, 0, ctx->stream>>>(c.heads, rows, f);
     UQ_LAUNCH_CHECK();
-    UQ_TRY(uq_scan_exclusive_u32(ctx, f, gscan, rows, tot));
-    keys_from_groups_kernel<<<blocks_for(rows), ST, 0, ctx->stream>>>(c.heads, gscan, d_perm, rows, d_key, d_sorted_key, d_unique ? uidx : nullptr);
+    UQ_TRY(uq_scan_exclusive_u32(ctx, f, gscan, ncb, tot));
+    keys_from_groups2_kernel<<<(uint32_t)ncb, ST, 0, ctx->stream>>>(c.heads, gscan, d_perm, rows, d_key, d_sorted_key, d_unique ? uidx : nullptr);
     UQ_LAUNCH_CHECK();
     UQ_CHECK_HIP(hipMemcpyAsync(ctx->h_pinned, tot, 8, hipMemcpyDeviceToHost, ctx->stream));
     UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
