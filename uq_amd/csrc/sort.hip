@@ -159,7 +159,7 @@ __global__ __launch_bounds__(ST) void active_count_kernel(const uint8_t* __restr
 // offs = exclusive scan of counts (pairs interleaved: scanned as u64 = {actives, segments}, both below 2^32)
 __global__ __launch_bounds__(ST) void compact_active2_kernel(const uint8_t* __restrict__ heads, const unsigned long long* __restrict__ offs,
                                                              const uint32_t* __restrict__ perm, uint64_t n, const uint8_t* __restrict__ table,
-                                                             uint32_t C, uint32_t k, uint32_t* __restrict__ pos, uint32_t* __restrict__ aval,
+                                                             uint32_t C, uint32_t k, uint32_t fold_z, uint32_t* __restrict__ pos, uint32_t* __restrict__ aval,
                                                              uint32_t* __restrict__ sid, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
     __shared__ unsigned long long lds[ST / 64 + 1];
     const uint64_t j0 = (uint64_t)blockIdx.x * CB + (uint64_t)threadIdx.x * 4;
@@ -177,8 +177,12 @@ __global__ __launch_bounds__(ST) void compact_active2_kernel(const uint8_t* __re
             const uint32_t row = perm[j0 + i];
             pos[u] = (uint32_t)(j0 + i);
             aval[u] = row;
-            sid[u] = segs_before + (seg[i] ? 1u : 0u) - 1u;
-            keys[u] = load_chunk_be(table + (uint64_t)row * C, C, k);
+            const uint32_t sg = segs_before + (seg[i] ? 1u : 0u) - 1u;
+            sid[u] = sg;
+            const uint64_t chunk = load_chunk_be(table + (uint64_t)row * C, C, k);
+            // fold_z (after a 32-bit round 0): the rows of a segment agree on the 32 bits behind chunk 0's z leading ones, so what
+            // is left of the chunk fits the low word and (segment, rest) is ONE sort key -- no separate sort by chunk value
+            keys[u] = fold_z == 0xFFFFFFFFu ? chunk : ((uint64_t)sg << 32) | (uint32_t)(chunk << fold_z);
             vals[u] = u;
         }
         ex += (unsigned long long)act[i] + ((unsigned long long)seg[i] << 32);
@@ -322,8 +326,18 @@ int sort_rows_core(uq_ctx* ctx, const uint8_t* table, uint64_t n, uint32_t C, ui
         UQ_CHECK_HIP(hipStreamSynchronize(s));
         const uint64_t m = ctx->h_pinned[0] & 0xFFFFFFFFull, nseg = ctx->h_pinned[0] >> 32;
         if ((uint32_t)ctx->h_pinned[2] == 0 || m == 0) break;
-        compact_active2_kernel<<<(uint32_t)ncb, ST, 0, s>>>(heads, (const unsigned long long*)bcnt, d_perm, n, table, C, k, pos, aval, sid, keysA, valsA);
+        const bool fold = mode32 && k == 0;
+        compact_active2_kernel<<<(uint32_t)ncb, ST, 0, s>>>(heads, (const unsigned long long*)bcnt, d_perm, n, table, C, k, fold ? z : 0xFFFFFFFFu, pos, aval, sid,
+                                                           keysA, valsA);
         UQ_LAUNCH_CHECK();
+        const int sbits0 = bits_for(nseg > 0 ? nseg - 1 : 0);
+        if (fold) {
+            int alt2 = 0;
+            UQ_TRY(radix_sort_pairs(ctx, keysA, valsA, keysB, valsB, m, 0, 32 + (sbits0 ? sbits0 : 1), rws, &alt2));
+            writeback_kernel<<<blocks_for(m), ST, 0, s>>>(alt2 ? keysB : keysA, alt2 ? valsB : valsA, pos, aval, m, d_perm, heads);
+            UQ_LAUNCH_CHECK();
+            continue;
+        }
         // sort #1: active rows by the value of chunk k
         UQ_TRY(radix_sort_pairs(ctx, keysA, valsA, keysB, valsB, m, 0, 64, rws, &alt));
         const uint64_t* K1 = alt ? keysB : keysA;
