@@ -38,20 +38,30 @@ def main():
     subprocess.run([sys.executable, '-c', gen], check=True)
     try:
         flags = a.flags.split()
+        def work_s(err):
+            for line in err.decode(errors='replace').splitlines():
+                if line.startswith('{"uq_timing"'): return json.loads(line)['work_s']
         t0 = time.perf_counter()
-        subprocess.run([sys.executable, '-m', 'uq_amd.uq', '-i', path, '-o', path + '.one.uQ', '--quiet'] + flags, check=True, cwd=REPO)
+        r1 = subprocess.run([sys.executable, '-m', 'uq_amd.uq', '-i', path, '-o', path + '.one.uQ', '--quiet'] + flags, check=True, cwd=REPO,
+                            env=dict(os.environ, UQ_TIMING='1'), stderr=subprocess.PIPE)
         t_one = time.perf_counter() - t0
+        w_one = work_s(r1.stderr)
         s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
         t0 = time.perf_counter()
         procs = [subprocess.Popen([sys.executable, '-m', 'uq_amd.dist_encode', '-i', path, '-o', path + '.dist.uQ', '--quiet'] + flags, cwd=REPO,
                                   env=dict(os.environ, RANK=str(r), WORLD_SIZE=str(a.world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1',
-                                           MASTER_PORT=str(port), UQ_DIST_BACKEND=a.backend)) for r in range(a.world)]
+                                           MASTER_PORT=str(port), UQ_DIST_BACKEND=a.backend, UQ_TIMING='1'), stderr=subprocess.PIPE if r == 0 else None)
+                 for r in range(a.world)]
+        err0 = procs[0].communicate()[1]
         rc = [p.wait() for p in procs]
         t_dist = time.perf_counter() - t0
+        w_dist = work_s(err0)
         same = rc == [0] * a.world and members_sha(path + '.one.uQ') == members_sha(path + '.dist.uQ')
         print(json.dumps({'op': 'sharded_encode', 'reads': a.reads, 'flags': a.flags, 'world': a.world, 'backend': a.backend,
                           'fastq_MB': round(os.path.getsize(path) / 1e6, 1), 'single_gpu_cli_s': round(t_one, 2),
-                          'sharded_cli_s': round(t_dist, 2), 'members_identical': bool(same)}), flush=True)
+                          'sharded_cli_s': round(t_dist, 2), 'single_gpu_work_s': w_one, 'sharded_work_s': w_dist,
+                          'note': '*_cli_s = whole process (interpreter + torch import + device / process-group start-up); *_work_s = the encode itself, '
+                                  'timed inside the process once that is up', 'members_identical': bool(same)}), flush=True)
     finally:
         for p in (path, path + '.one.uQ', path + '.dist.uQ', path + '.dist.uQ.part'):
             if os.path.exists(p): os.remove(p)

@@ -407,6 +407,7 @@ def main(argv=None):
     else:
         dist.init_process_group(backend, rank=rank, world_size=world)
     code = 0
+    t_ready = time.perf_counter()                                  # interpreter, torch and the process group are up
     try:
         args.device = device
         validate_args(args)
@@ -419,6 +420,8 @@ def main(argv=None):
         if rank == 0: print(e)
         code = 1
     finally:
+        if os.environ.get('UQ_TIMING') and rank == 0:
+            print(json.dumps({'uq_timing': 'dist_encode', 'world': world, 'work_s': round(time.perf_counter() - t_ready, 3)}), file=sys.stderr, flush=True)
         dist.destroy_process_group()
     return code
 

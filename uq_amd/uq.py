@@ -792,10 +792,14 @@ def main(argv=None):
     try:
         validate_args(args)
         s = Session(args)
+        t_ready = time.perf_counter()                                # interpreter, torch and the device context are up
         if args.decode:
             s.decode()
         else:
             s.encode()
+        if os.environ.get('UQ_TIMING'):
+            s.ctx.sync()
+            print(json.dumps({'uq_timing': 'uq', 'work_s': round(time.perf_counter() - t_ready, 3)}), file=sys.stderr, flush=True)
     except UqError as e:
         print(e)
         return 1
