@@ -222,7 +222,8 @@ __global__ __launch_bounds__(EM_THREADS, 4) void emit_tile_kernel(EmitGeom g, Ti
     __shared__ EmitGeom sg;
     const uint32_t tid = threadIdx.x, lane = lane_id();
     for (uint32_t i = tid; i < sizeof(EmitGeom) / 4; i += EM_THREADS) ((uint32_t*)&sg)[i] = ((const uint32_t*)&g)[i];
-    if constexpr (PACKED) { l_tab[tid] = lut.base_char[tid]; l_tab[256 + tid] = lut.qual_char[tid]; l_tab[512 + tid] = lut.qual_n_base[tid]; }
+    if constexpr (PACKED)
+        for (uint32_t i = tid; i < 256; i += EM_THREADS) { l_tab[i] = lut.base_char[i]; l_tab[256 + i] = lut.qual_char[i]; l_tab[512 + i] = lut.qual_n_base[i]; }
     __syncthreads();
     const uint32_t R = tg.R, P = tg.P, cap = tg.cap;
     const uint64_t ntiles = (n + R - 1) / R;
@@ -538,7 +539,8 @@ __global__ __launch_bounds__(EM_THREADS) void direct_tiles_kernel(EmitGeom g, Ti
     __shared__ uint8_t l_tab[PACKED ? 768 : 4];
     const uint8_t* l_base = l_tab; const uint8_t* l_qual = l_tab + 256; const uint8_t* l_qn = l_tab + 512;
     const uint32_t tid = threadIdx.x, lane = lane_id();
-    if constexpr (PACKED) { l_tab[tid] = lut.base_char[tid]; l_tab[256 + tid] = lut.qual_char[tid]; l_tab[512 + tid] = lut.qual_n_base[tid]; }
+    if constexpr (PACKED)
+        for (uint32_t i = tid; i < 256; i += EM_THREADS) { l_tab[i] = lut.base_char[i]; l_tab[256 + i] = lut.qual_char[i]; l_tab[512 + i] = lut.qual_n_base[i]; }
     __syncthreads();
     const uint64_t R = tg.R, ntiles = (n + R - 1) / R;
     for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
