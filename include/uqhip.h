@@ -81,6 +81,14 @@ typedef struct uq_stats {
 int uq_stats_init(uq_ctx* ctx, uq_stats* d_stats);
 int uq_stats_accumulate(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start,
                         uint64_t first_read, uint64_t nreads, uq_stats* d_stats);
+/* uq_count_lines AND uq_stats_accumulate in ONE read of the stream ("a census that counts"): the statistics of a tile's records
+ * need the line number modulo 4, which the census is only just taking -- so every 16 KiB tile takes the phase from its own content
+ * (the one residue for which every 4th line starts with '@' and the lines two on with '+'), counts the records that start in it,
+ * and a small kernel checks every tile's assumption against the scanned counts afterwards.  *h_nlines = the census (always);
+ * *h_stats_ok = 1: d_stats (initialised by uq_stats_init) holds what uq_stats_accumulate over all nlines / 4 reads would have
+ * left there; 0 (a tile without a unique phase, a record longer than ~1 KB, a malformed record, nlines % 4 != 0): d_stats is
+ * unspecified -- re-initialise it and run uq_stats_accumulate on the index.  uq_index_lines reuses the census either way. */
+int uq_count_lines_stats(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uq_stats* d_stats, uint64_t* h_nlines, int* h_stats_ok);
 /* Multi-GPU: a uq_stats as ONE summable buffer of 65536 + 6 * world int64 words.  uq_stats_export writes the
  * counts and, in this rank's six slots, bad_plus / bad_len (made file-wide by adding read_offset; sign bit flipped so that
  * signed order == unsigned order), len_min, len_max, max_record_bytes and the `reserved` flag; the other ranks' slots are 0.

@@ -473,3 +473,63 @@ def test_session_load_overlaps_census_with_ingest(ctx, tmp_path):
     b.load_device(ctx.bytes_to_device(fq))
     assert a.total == b.total == 20_000 and ctx.torch.equal(a.d_ls, b.d_ls)
     assert np.array_equal(ops.stats_fetch(ctx, a.d_stats).counts, ops.stats_fetch(ctx, b.d_stats).counts)
+
+
+def _census_stats_check(ctx, d_buf, expect_ok=True):
+    t = ctx.torch
+    nl = ops.count_lines(ctx, d_buf)
+    ls = ops.index_lines(ctx, d_buf, nl)
+    st = ops.stats_new(ctx)
+    if nl >= 4: ops.stats_accumulate(ctx, st, d_buf, ls, 0, nl // 4)
+    hs = ops.stats_fetch(ctx, st)
+    nl2, st2 = ops.count_lines_stats(ctx, d_buf)
+    assert nl2 == nl
+    assert t.equal(ops.index_lines(ctx, d_buf, nl2), ls), 'the census of uq_count_lines_stats does not serve uq_index_lines'
+    if expect_ok is not None: assert (st2 is not None) == expect_ok
+    if st2 is not None:
+        h2 = ops.stats_fetch(ctx, st2)
+        assert np.array_equal(h2.counts, hs.counts), 'pair counts differ'
+        assert (h2.len_min, h2.len_max, h2.max_record_bytes, h2.bad_plus, h2.bad_len) == (hs.len_min, hs.len_max, hs.max_record_bytes, None, None)
+    return st2 is not None
+
+
+@pytest.mark.parametrize('n,length,kw', [(60_000, 150, {}), (40_000, (36, 301), dict(n_rate=1)), (30_000, 100, dict(n_rate=2)),
+                                         (2_000, (1, 40), {}), (50_000, 36, {}), (7, 150, {}), (1, 400, {})],
+                         ids=['fixed150', 'var36-301', 'fixed100-N', 'tiny-reads', 'short36', 'seven', 'one'])
+def test_census_that_counts_equals_two_passes(ctx, n, length, kw):
+    """uq_count_lines_stats: line count, the census uq_index_lines expands, and the statistics equal the separate passes'."""
+    d_buf = ops.synth_fastq(ctx, synth.Spec(S + 90, length, **kw), 0, n)
+    _census_stats_check(ctx, d_buf, True)
+
+
+def test_census_that_counts_knows_what_it_cannot_vouch_for(ctx):
+    """Qualities starting with '@' or '+', lower-case / IUPAC bases, Phred+64 (exact through the slower tiers); then inputs where
+    a tile cannot settle the phase or see a record whole: the statistics are withdrawn (None), the census stays exact."""
+    t = ctx.torch
+    rng = np.random.default_rng(9)
+
+    def fq(n, bases, quals, L, name=b'@q:%d:%d'):
+        B, Q = np.frombuffer(bases, np.uint8), np.frombuffer(quals, np.uint8)
+        return b''.join(name % (i % 3, i) + b'\n' + bytes(rng.choice(B, L)) + b'\n+\n' + bytes(rng.choice(Q, L)) + b'\n' for i in range(n))
+
+    dev = lambda b: ctx.bytes_to_device(b)
+    assert _census_stats_check(ctx, dev(fq(20_000, b'ACGT', b'@+ABCDEFGHI', 90)))            # QUAL lines that begin like '@' / '+' lines
+    assert _census_stats_check(ctx, dev(fq(20_000, b'acgtnRYKM', bytes(range(64, 105)), 70)))
+    assert _census_stats_check(ctx, dev(fq(3_000, b'ACGT', b'!#5I', 900)), None) is not None   # 1.8 kB records: beyond the halo sooner or later
+    # SEQ lines that all start with '@' and QUAL lines with '+': two phases fit -> withdrawn
+    amb = b''.join(b'@r%d\n@ACGT\n+\n+III\n' % i for i in range(5000))
+    _census_stats_check(ctx, dev(amb), False)
+    # a malformed record (third line without '+'), lengths that differ, no final newline, a line count that is no multiple of 4
+    good = fq(10_000, b'ACGT', b'#5AI', 60)
+    _census_stats_check(ctx, dev(good.replace(b'\n+\n', b'\n-\n', 7000).replace(b'\n-\n', b'\n+\n', 6999)), False)
+    lines = good.split(b'\n'); lines[4 * 5000 + 3] = lines[4 * 5000 + 3][:-2]
+    _census_stats_check(ctx, dev(b'\n'.join(lines)), False)
+    _census_stats_check(ctx, dev(good[:-1]), False)
+    _census_stats_check(ctx, dev(good + b'@x\nAC\n'), False)
+    _census_stats_check(ctx, dev(good + b'@trailing garbage'), True)
+    # misaligned buffers
+    src = ops.synth_fastq(ctx, synth.Spec(S + 91, (30, 90), n_rate=1), 0, 20_000)
+    for off in (3, 8, 13):
+        big = t.empty(src.numel() + 64, dtype=t.uint8, device=ctx.device).fill_(10)
+        big[off:off + src.numel()] = src
+        _census_stats_check(ctx, big[off:off + src.numel()], True)

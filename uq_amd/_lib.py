@@ -79,6 +79,7 @@ SIGNATURES = {
     'uq_timer_start': [_vp],
     'uq_timer_stop': [_vp, _P(C.c_float)],
     'uq_count_lines': [_vp, _vp, _u64, _P(_u64)],
+    'uq_count_lines_stats': [_vp, _vp, _u64, _vp, _P(_u64), _P(_int)],
     'uq_count_lines_begin': [_vp, _vp, _u64],
     'uq_count_lines_chunk': [_vp, _vp, _u64, _u64, _u64],
     'uq_count_lines_end': [_vp, _vp, _u64, _P(_u64)],

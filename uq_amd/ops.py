@@ -20,6 +20,15 @@ def count_lines(ctx, buf):
     return n.value
 
 
+def count_lines_stats(ctx, buf):
+    """Newline census + pass-1 statistics in one read of the stream (uq_count_lines_stats).  Returns (nlines, d_stats): d_stats is
+    None when the pass cannot vouch for the statistics (the caller then runs stats_accumulate on the index)."""
+    st = stats_new(ctx)
+    n = C.c_uint64(); ok = C.c_int(0)
+    call('uq_count_lines_stats', ctx.h, _p(buf), buf.numel(), _p(st), C.byref(n), C.byref(ok))
+    return n.value, (st if ok.value else None)
+
+
 class ChunkedCensus:
     """uq_count_lines over a buffer that is still being filled: `chunk(lo, n)` as each piece lands, `end()` = the line count."""
 
