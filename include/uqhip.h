@@ -136,7 +136,9 @@ int uq_pack(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start, uin
  * *h_fused = 0: this geometry has no fused kernel (anything but 2-bit A/C/G/T with one contiguous quality range, the
  * Q9 carry case, records beyond one tile) and NOTHING was launched: run uq_stats_accumulate + uq_pack.
  * d_stats->reserved != 0 after the call: the counts are incomplete (a read longer than h_guess->dna_max, a record
- * longer than h_guess->max_record_bytes, SEQ / QUAL lengths differ): re-initialise and run uq_stats_accumulate. */
+ * longer than h_guess->max_record_bytes, SEQ / QUAL lengths differ, a symbol outside the guessed alphabets -- the kernel counts
+ * on the codes the conversion produces): re-initialise and run uq_stats_accumulate.  No fused kernel either for more than 64
+ * quality symbols (a count bin per byte). */
 int uq_pack_stats(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start, uint64_t first_read,
                   uint64_t nreads, const uq_pack_params* h_guess, uint8_t* d_dna, uint8_t* d_qual, uint64_t* d_bad,
                   uq_stats* d_stats, int* h_fused);

@@ -289,9 +289,10 @@ def test_cli_fuzz_against_oracle(ctx, tmp_path, seed):
 
 
 def test_cli_one_pass_speculation(ctx, tmp_path):
-    """--one-pass: the encoder reads the stream once (uq_encode_stream) and packs speculatively with decisions guessed from
-    the head of the file itself; a wrong guess falls back to the separate pack.  The default never speculates.  The output
-    never depends on the path taken."""
+    """The encoder packs speculatively with decisions guessed from the head of the file itself -- by default in the kernel that
+    also counts the statistics (uq_pack_stats: two reads of the stream), with --one-pass in the kernel that does everything
+    (uq_encode_stream: one read); a wrong guess falls back to the separate pack; --multi-pass never speculates.  `pack_path` says
+    whether the speculative tables were kept.  The output never depends on the path taken."""
     a = synth.fastq(20261003 + 50, 3000, 60)
     b = synth.fastq(20261003 + 51, 2500, 60)                                   # same alphabets and length as a: a's decisions hold
     c = synth.fastq(20261003 + 52, 2000, (30, 61), n_rate=2)                   # variable length, N: they do not
@@ -301,8 +302,8 @@ def test_cli_one_pass_speculation(ctx, tmp_path):
     k = d.rfind(b'\n', 0, d.rfind(b'\n+\n', 0, k))                             # start of a SEQ line near the end
     d = d[:k + 1] + b'N' + d[k + 2:]
     want = {}
-    for mode, expect in ((['--one-pass'], ['one-pass', 'one-pass', 'one-pass', 'one-pass', 'two-pass']),
-                         ([], ['two-pass'] * 5), (['--multi-pass'], ['two-pass'] * 5)):
+    for mode, expect in (([], ['one-pass', 'one-pass', 'one-pass', 'one-pass', 'two-pass']),
+                         (['--one-pass'], ['one-pass', 'one-pass', 'one-pass', 'one-pass', 'two-pass']), (['--multi-pass'], ['two-pass'] * 5)):
         uq.Session.last_params = None
         paths = []
         for i, fq in enumerate((a, b, c, b, d)):

@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libuqhip.so')
+LIB_PATH = os.environ.get('UQ_LIB_PATH') or os.path.join(HERE, 'libuqhip.so')       # UQ_LIB_PATH: A/B builds of the kernels (tuning)
 UQ_NONE = (1 << 64) - 1
 ABI_VERSION = 1
 

@@ -85,7 +85,14 @@ __device__ __noinline__ void store_tile(uint8_t* gdst, const uint8_t* lsrc, uint
 }
 
 constexpr int PK_NV = 5;   // 16-byte loads per lane per tile: a tile spans at most PK_NV * 256 * 16 = 20 KiB
-constexpr int PK_NV_STATS = 4;   // the fused pack + statistics kernel keeps 16 KiB of LDS for the count tables: smaller tiles, same occupancy
+constexpr int PK_NV_STATS = 4;   // the fused pack + statistics kernel keeps a few KiB of LDS for its count table: 16 KiB tiles, same occupancy
+// Its counts are taken on the CODES the lookup-free conversion has just produced (bin = base code << 6 | quality code: two
+// instructions per four pairs instead of re-deriving bins from the characters), into a PKS_COPIES-fold replicated LDS table;
+// code 0 fill pairs of a read's partial top group and the N-trick positions (counted as their substitute there) are taken off
+// again at the flush, the N-trick base's own pairs go to a 128-entry table by quality character.  A symbol outside the guessed
+// alphabets is not counted at all: the statistics are flagged incomplete (the guess is wrong then anyway).
+constexpr int PKS_COPIES = 4;
+constexpr uint32_t PKS_WORDS = 256 * PKS_COPIES + 128;
 
 // LDS carve (dynamic): [16 B guard][stage][out_d | out_q][meta u32 x (4R+4)][luts 3 x 512 B]
 // Workgroups are persistent: each walks tiles b, b + S, b + 2S, ... with a software pipeline -- the
@@ -96,7 +103,7 @@ constexpr int PK_NV_STATS = 4;   // the fused pack + statistics kernel keeps 16 
 // (uq_pack_stats).  `st->reserved` is raised when the counts are incomplete (a record longer than the guess
 // allowed for, or malformed): the caller then runs the plain statistics pass.
 template <int BD, int BQ, bool NTRICK, bool FAST, bool STATS>
-__global__ __launch_bounds__(PK_THREADS, STATS ? 4 : 5) void pack_tile_kernel(const uint8_t* __restrict__ buf,
+__global__ __launch_bounds__(PK_THREADS, (STATS && NTRICK) ? 4 : 5) void pack_tile_kernel(const uint8_t* __restrict__ buf,
                                                                const uint64_t* __restrict__ ls, uint64_t first,
                                                                uint64_t n, PackLut lut, PackGeom g,
                                                                uint8_t* __restrict__ dna, uint8_t* __restrict__ qual,
@@ -115,10 +122,12 @@ __global__ __launch_bounds__(PK_THREADS, STATS ? 4 : 5) void pack_tile_kernel(co
     l_dna[tid] = lut.dna_code[tid];
     l_qual[tid] = lut.qual_code[tid];
     if (NTRICK) l_nq[tid] = lut.n_qual[tid];
-    Histo hz;
     RecordAcc acc;
     bool incomplete = false;
-    if (STATS) hz.init((uint32_t*)(l_nq + 256), st, win);        // tables zeroed; the first tile's barrier orders it
+    uint32_t* cnt_tab = (uint32_t*)(l_nq + 256);                 // [256 bins][PKS_COPIES], then [128] N-trick base by quality character
+    uint32_t fill_pairs = 0, n_pairs = 0;                        // pairs counted in bin 0 / bin n_code that were fills / N-trick positions
+    if (STATS) for (uint32_t i = tid; i < PKS_WORDS; i += PK_THREADS) cnt_tab[i] = 0;       // the first tile's barrier orders it
+    (void)win;
 
     const uint64_t R = g.R;
     const uint64_t ntiles = (n + R - 1) / R;
@@ -200,7 +209,6 @@ __global__ __launch_bounds__(PK_THREADS, STATS ? 4 : 5) void pack_tile_kernel(co
                     uint32_t b_lo, b_hi, q_lo, q_hi;
                     lds_window8(stage, (int32_t)so + j0, b_lo, b_hi);
                     lds_window8(stage, (int32_t)qo + j0, q_lo, q_hi);
-                    if (STATS && j0 > -8) hz.group8(b_lo, b_hi, q_lo, q_hi, j0 < 0 ? (uint32_t)(-j0) : 0u, lane_id());
                     if (j0 < 0) {   // window reaches above the first base: those symbols are zero (fill with code-0 characters)
                         uint32_t mlo, mhi;
                         window_masks((uint32_t)(-j0), mlo, mhi);
@@ -228,6 +236,27 @@ __global__ __launch_bounds__(PK_THREADS, STATS ? 4 : 5) void pack_tile_kernel(co
                         if (bq0 | bq1) generic = true;
                         ad0 = pack4<BD>(c0); ad1 = pack4<BD>(c1);
                         aq0 = pack4<BQ>(x0); aq1 = pack4<BQ>(x1);
+                        if (STATS) {
+                            if (generic) incomplete = true;          // a symbol outside the guess: not counted here
+                            else {
+                                const uint32_t bin0 = (c0 << 6) | x0, bin1 = (c1 << 6) | x1;        // BQ <= 6: a bin per byte
+                                uint8_t* hb = (uint8_t*)cnt_tab + ((lane_id() & (PKS_COPIES - 1)) << 2);
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) {
+                                    atomicAdd((uint32_t*)(hb + (((bin0 >> (8 * k)) & 0xFFu) * (4 * PKS_COPIES))), 1u);
+                                    atomicAdd((uint32_t*)(hb + (((bin1 >> (8 * k)) & 0xFFu) * (4 * PKS_COPIES))), 1u);
+                                }
+                                if (j0 < 0) fill_pairs += (uint32_t)(-j0);
+                                if (NTRICK && (e0 | e1)) {           // the N-trick base's own pairs, by quality character
+                                    const uint32_t m0 = nonzero_bytes(e0), m1 = nonzero_bytes(e1);
+#pragma unroll
+                                    for (int k = 0; k < 4; ++k) {
+                                        if ((m0 >> (8 * k)) & 1u) { atomicAdd(&cnt_tab[256 * PKS_COPIES + ((q_lo >> (8 * k)) & 0x7Fu)], 1u); ++n_pairs; }
+                                        if ((m1 >> (8 * k)) & 1u) { atomicAdd(&cnt_tab[256 * PKS_COPIES + ((q_hi >> (8 * k)) & 0x7Fu)], 1u); ++n_pairs; }
+                                    }
+                                }
+                            }
+                        }
                     }
                     if (generic) {
                         const uint32_t cbw[2] = {b_lo, b_hi};
@@ -316,8 +345,24 @@ __global__ __launch_bounds__(PK_THREADS, STATS ? 4 : 5) void pack_tile_kernel(co
     if (badr != 0xFFFFFFFFu) atomicMin(bad, (unsigned long long)badr);
     if (bad_tile != UQ_NONE) atomicMin(bad, (unsigned long long)bad_tile);
     if (STATS) {
+        // fills were counted as (code 0, code 0), N-trick positions as (code 0, n_code): take them off their bins (any copy: the
+        // flush sums the copies modulo 2^32)
+        if (fill_pairs) atomicSub(&cnt_tab[lane_id() & (PKS_COPIES - 1)], fill_pairs);
+        if (NTRICK && n_pairs) atomicSub(&cnt_tab[((g.n_code & 0xFFu) * PKS_COPIES) + (lane_id() & (PKS_COPIES - 1))], n_pairs);
         __syncthreads();
-        hz.flush();
+        const uint32_t qmin = 0x80u - (g.q_addlo & 0xFFu);
+        {
+            const uint32_t bin = tid;                            // 256 bins, 256 lanes
+            uint32_t v = 0;
+#pragma unroll
+            for (int c = 0; c < PKS_COPIES; ++c) v += cnt_tab[bin * PKS_COPIES + c];
+            const uint32_t base = (0x54474341u >> (8 * (bin >> 6))) & 0xFFu;                  // "ACGT"[code]
+            if (v) atomicAdd((unsigned long long*)&st->counts[base * 256 + qmin + (bin & 63u)], (unsigned long long)v);
+        }
+        if (NTRICK && tid < 128) {
+            const uint32_t v = cnt_tab[256 * PKS_COPIES + tid];
+            if (v) atomicAdd((unsigned long long*)&st->counts[(g.n_char & 0xFFu) * 256 + tid], (unsigned long long)v);
+        }
         acc.flush(st, first);
         if (incomplete) st->reserved = 1;
     }
@@ -371,7 +416,7 @@ PackKernel pick_nt(bool ntrick, bool fast) {
 // the fused pack + statistics kernels exist for the lookup-free path only (2-bit A/C/G/T, contiguous qualities)
 PackKernel pick_stats_kernel(int bq, bool ntrick) {
 #define UQ_PS(B) case B: return ntrick ? pack_tile_kernel<2, B, true, true, true> : pack_tile_kernel<2, B, false, true, true>;
-    switch (bq) { UQ_PS(1) UQ_PS(2) UQ_PS(3) UQ_PS(4) UQ_PS(5) UQ_PS(6) UQ_PS(7) default: return ntrick ? pack_tile_kernel<2, 8, true, true, true> : pack_tile_kernel<2, 8, false, true, true>; }
+    switch (bq) { UQ_PS(1) UQ_PS(2) UQ_PS(3) UQ_PS(4) UQ_PS(5) default: return ntrick ? pack_tile_kernel<2, 6, true, true, true> : pack_tile_kernel<2, 6, false, true, true>; }
 #undef UQ_PS
 }
 
@@ -496,8 +541,8 @@ static int pack_impl(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_s
         g.q_addhi = 0x01010101u * (uint32_t)(0x80 - qmin - nq);
         if (ntrick_bases == 1) { g.n_char = 0x01010101u * (uint32_t)nchar; g.n_code = 0x01010101u * (uint32_t)hp->n_qual[nchar]; }
     }
-    if (d_stats && !fast) return 0;              // the fused kernels exist for the lookup-free path only
-    const size_t lds = 16 + (size_t)g.stage_bytes + g.out_bytes + (4 * R + 4) * 4 + 3 * 512 + (d_stats ? HZ_WORDS * 4 : 0);
+    if (d_stats && (!fast || bq > 6)) return 0;  // the fused kernels exist for the lookup-free path with a bin per byte (<= 64 qualities) only
+    const size_t lds = 16 + (size_t)g.stage_bytes + g.out_bytes + (4 * R + 4) * 4 + 3 * 512 + (d_stats ? PKS_WORDS * 4 : 0);
     UQ_REQUIRE(lds <= 160 * 1024, "uq_pack: tile needs %zu bytes of LDS", lds);
     const uint64_t tiles = (nreads + R - 1) / R;
     uint32_t per_cu = (uint32_t)((160 * 1024) / lds);

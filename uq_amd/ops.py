@@ -189,6 +189,7 @@ def encode_stream(ctx, buf, guess, max_reads, with_stats=True):
 
 HEAD_BYTES = 24 << 20          # the slice of the file the one-pass encoder's guess is taken from
 HEAD_READS = 65536
+HEAD_READS_INDEXED = 8192
 
 
 def head_guess(ctx, buf, notricks=False, pad=False):
@@ -214,6 +215,27 @@ def head_guess(ctx, buf, notricks=False, pad=False):
     p = make_pack_params(d['bases'], d['qualities'], d['N_qual'], d['bits_per_base'], d['bits_per_quality'], d['variable_read_lengths'],
                          d['dna_bytes_per_row'], d['quality_bytes_per_row'], d['dna_max'], hs.max_record_bytes, avg_record_bytes=span // n)
     return p, n / span
+
+
+def head_guess_indexed(ctx, buf, line_start, nreads, notricks=False, pad=False):
+    """head_guess for a buffer whose record index exists already: the statistics of its first HEAD_READS reads -> decisions ->
+    uq_pack_params, or None (malformed head, Q9 new-code alphabets: no speculative kernel)."""
+    from . import analysis
+    # 8192 reads: the statistics kernel flushes its tables once per workgroup, and a sample of 150 tiles keeps that to 150
+    # workgroups (65 536 reads: 1024 workgroups, 0.15 ms of contended flushes for 22 MB of input)
+    n = min(int(nreads), HEAD_READS_INDEXED)
+    if n == 0:
+        return None
+    st = stats_new(ctx)
+    stats_accumulate(ctx, st, buf, line_start, 0, n)
+    hs = stats_fetch(ctx, st)
+    if hs.bad_plus is not None or hs.bad_len is not None:
+        return None
+    d = analysis.decide_from_counts(hs.counts, hs.len_min, hs.len_max, notricks=notricks, pad=pad)
+    if d['N_qual'] and max(d['N_qual'].values()) >= len(d['qualities']): return None
+    return make_pack_params(d['bases'], d['qualities'], d['N_qual'], d['bits_per_base'], d['bits_per_quality'], d['variable_read_lengths'],
+                            d['dna_bytes_per_row'], d['quality_bytes_per_row'], d['dna_max'], hs.max_record_bytes,
+                            avg_record_bytes=buf.numel() // max(int(nreads), 1))
 
 
 def encode_one_pass(ctx, buf, guess=None, notricks=False, pad=False, reads_per_byte=None):

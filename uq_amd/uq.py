@@ -60,7 +60,9 @@ def build_parser():
     p.add_argument('--one-pass', action='store_true', default=False,
                    help='census, record index, statistics and a speculative pack (decisions guessed from the head of the file, verified afterwards) '
                         'in ONE read of the stream (extension)')
-    p.add_argument('--multi-pass', action='store_true', default=False, help='the default: census, record index, statistics and pack as separate passes (extension)')
+    p.add_argument('--multi-pass', action='store_true', default=False,
+                   help='census, record index, statistics and pack as separate passes over the stream; the default counts the statistics in the pack kernel, '
+                        'packing speculatively with decisions guessed from the head of the file and verified afterwards (extension)')
     p.add_argument('--two-pass-decode', action='store_true', default=False,
                    help='decode through the fixed-pitch text arrays (uq_unpack + uq_emit_fastq) instead of the fused kernel (extension)')
     return p
@@ -147,12 +149,10 @@ class Session:
         self.load_device(d_buf, nlines=census['c'].end() if 'c' in census else None)
 
     def load_device(self, d_buf, nlines=None):
-        """The same for FASTQ bytes that are already in HBM (a uint8 device tensor): record index + pass-1 statistics, as
-        separate passes over the stream (census -> index -> statistics).  --one-pass does all of it in ONE read of the stream
-        together with a speculative pack (uq_encode_stream; the guess comes from the head of this file); analyse() /
-        _encode() keep those tables only if the decisions derived from the whole file's statistics equal the guess, and any
-        input the one-pass kernel declines takes the separate passes: same results.  (On MI355X the one-pass kernel is
-        currently the slower of the two -- DESIGN.md 4 -- hence opt-in.)"""
+        """The same for FASTQ bytes that are already in HBM (a uint8 device tensor): newline census, record index, pass-1
+        statistics -- the statistics counted by the pack kernel while it packs speculatively (see below), so the stream is read
+        twice.  --multi-pass: census -> index -> statistics -> pack as separate passes (three reads); --one-pass: all of it in ONE
+        read (uq_encode_stream; currently the slowest of the three on MI355X).  Same results whichever path."""
         ops, ctx, args = self.ops, self.ctx, self.args
         self.d_buf = d_buf
         if not hasattr(self, '_host'): self.path, self._host = None, None
@@ -169,8 +169,21 @@ class Session:
         self.total = nlines // 4
         if not one_pass:
             self.d_ls = ops.index_lines(ctx, self.d_buf, nlines)                 # record index
-            self.d_stats = ops.stats_new(ctx)
-            ops.stats_accumulate(ctx, self.d_stats, self.d_buf, self.d_ls, 0, self.total)
+            # pass-1 statistics.  Unless --multi-pass says otherwise they are counted by the PACK kernel (uq_pack_stats): it packs
+            # with decisions guessed from the first 8192 reads while it counts the (base, quality) codes it produces anyway, so
+            # the stream is read twice (census, pack) instead of three times; analyse() / _encode() keep the tables only if the
+            # decisions derived from the whole file's counts equal the guess (else uq_pack runs with the real ones), and counts
+            # the kernel could not complete (a symbol or a length outside the guess) are redone by the plain statistics pass.
+            if not getattr(args, 'multi_pass', False):
+                guess = ops.head_guess_indexed(ctx, self.d_buf, self.d_ls, self.total, args.notricks, args.pad)
+                res = ops.pack_stats(ctx, self.d_buf, self.d_ls, 0, self.total, guess) if guess is not None else None
+                if res is not None:
+                    self._spec = (guess,) + res[:3]
+                    self.d_stats = res[3]
+                    self.load_path = 'two reads (census; pack + statistics)'
+            if self._spec is None:
+                self.d_stats = ops.stats_new(ctx)
+                ops.stats_accumulate(ctx, self.d_stats, self.d_buf, self.d_ls, 0, self.total)
 
     @property
     def host(self):
