@@ -136,6 +136,8 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
             local_rank %= max(torch.cuda.device_count(), 1)
     ctx = Context(local_rank)
+    from uq_amd.device import SideContext
+    side = SideContext(ctx)
     red_dev = ctx.device if not (use_dist and dist.get_backend() == 'gloo') else 'cpu'     # where the closing all-reduces live
 
     n = args.reads
@@ -168,6 +170,17 @@ def main():
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         enc = None
         spec = None
+        guess = None
+        census = None
+        if not args.one_pass and not args.multi_pass:
+            # the census kernel is queued first; the guess (census / index / statistics of the shard's first 4 MB: small kernels,
+            # a read-back, the decisions on the host) runs meanwhile on a second stream and is ready when the census is
+            census = ops.ChunkedCensus(ctx, d_buf)
+            census.chunk(0, fastq_bytes)
+            g = ops.head_guess(side, d_buf, notricks=notricks, head_bytes=ops.HEAD_BYTES_SMALL, head_reads=ops.HEAD_READS_INDEXED)
+            if g is not None:
+                guess = g[0]
+                guess.avg_record_bytes = 0                      # set below from the shard's own census
         if args.one_pass:
             # ONE read of the stream (uq_encode_stream): census + record index + pass-1 statistics + pack with decisions guessed
             # from the head of this shard (its first 65536 reads, statistics pass of their own -- part of the step), verified
@@ -181,7 +194,7 @@ def main():
         if enc is not None and enc.line_start is not None:
             nlines, ls = enc.nlines, enc.line_start
         else:
-            nlines = enc.nlines if enc is not None else ops.count_lines(ctx, d_buf)
+            nlines = enc.nlines if enc is not None else (census.end() if census is not None else ops.count_lines(ctx, d_buf))
             ls = ops.index_lines(ctx, d_buf, nlines)              # record index
             enc = None
         nreads = nlines // 4
@@ -189,9 +202,9 @@ def main():
             st = enc.stats
         elif not args.one_pass and not args.multi_pass:
             # the default: TWO reads of the stream.  The pack kernel counts the statistics (uq_pack_stats) while it packs with
-            # decisions guessed from the shard's first 65536 reads (a statistics pass of their own, part of the step)
-            guess = ops.head_guess_indexed(ctx, d_buf, ls, nreads, notricks=notricks)
+            # decisions guessed from the shard's first 8192 reads (taken on the side stream while the census ran, above)
             if guess is not None:
+                guess.avg_record_bytes = fastq_bytes // max(nreads, 1)
                 e0.record()
                 spec = ops.pack_stats(ctx, d_buf, ls, 0, nreads, guess)
                 e1.record()

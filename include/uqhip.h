@@ -79,6 +79,9 @@ typedef struct uq_stats {
     uint32_t reserved;          /* uq_pack_stats only: non-zero = the counts above are incomplete, run uq_stats_accumulate */
 } uq_stats;
 int uq_stats_init(uq_ctx* ctx, uq_stats* d_stats);
+/* The device struct copied to the host (synchronous).  Same bytes as uq_d2h of the whole struct, but a file touches a few hundred
+ * of the 65 536 counters: they travel as a short list through the context's pinned buffer instead of 512 KiB to pageable memory. */
+int uq_stats_fetch(uq_ctx* ctx, const uq_stats* d_stats, uq_stats* h_stats);
 int uq_stats_accumulate(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start,
                         uint64_t first_read, uint64_t nreads, uq_stats* d_stats);
 /* uq_count_lines AND uq_stats_accumulate in ONE read of the stream ("a census that counts"): the statistics of a tile's records

@@ -85,6 +85,7 @@ SIGNATURES = {
     'uq_count_lines_end': [_vp, _vp, _u64, _P(_u64)],
     'uq_index_lines': [_vp, _vp, _u64, _u64, _vp],
     'uq_stats_init': [_vp, _vp],
+    'uq_stats_fetch': [_vp, _vp, _vp],
     'uq_stats_accumulate': [_vp, _vp, _vp, _u64, _u64, _vp],
     'uq_stats_export': [_vp, _vp, _u32, _u32, _u64, _vp],
     'uq_stats_import': [_vp, _vp, _u32, _vp],

@@ -317,6 +317,24 @@ __global__ void stats_import_kernel(const long long* __restrict__ buf, uint32_t 
     }
 }
 
+// ---- the statistics as a short list: a file uses a few hundred of the 65 536 (base, quality) counters, and reading 512 KiB back
+// (pageable: staged) costs more than the decisions that follow
+constexpr uint32_t SC_CAP = 2048;
+struct StatsCompact { uint32_t n, len_min, len_max, max_record_bytes, reserved, pad; uint64_t bad_plus, bad_len; uint32_t key[SC_CAP]; uint64_t count[SC_CAP]; };
+__global__ void stats_compact_kernel(const uq_stats* __restrict__ st, StatsCompact* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        out->len_min = st->len_min; out->len_max = st->len_max; out->max_record_bytes = st->max_record_bytes; out->reserved = st->reserved;
+        out->bad_plus = st->bad_plus; out->bad_len = st->bad_len;
+    }
+    if (i >= 65536) return;
+    const uint64_t c = st->counts[i];
+    if (c) {
+        const uint32_t k = atomicAdd(&out->n, 1u);
+        if (k < SC_CAP) { out->key[k] = i; out->count[k] = c; }
+    }
+}
+
 __global__ void stats_init_kernel(uq_stats* st) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < 65536) st->counts[i] = 0;
@@ -350,6 +368,29 @@ __global__ __launch_bounds__(256) void first_occurrence_kernel(const uint8_t* __
     if (seen[threadIdx.x] != UQ_NONE) atomicMin((unsigned long long*)&out[threadIdx.x], seen[threadIdx.x]);
 }
 }  // namespace
+
+extern "C" int uq_stats_fetch(uq_ctx* ctx, const uq_stats* d_stats, uq_stats* h_stats) {
+    UQ_REQUIRE(ctx && d_stats && h_stats, "uq_stats_fetch: null argument");
+    static_assert(sizeof(StatsCompact) <= 65536, "the compact form must fit the context's pinned staging buffer");
+    void* scr;
+    UQ_TRY(uq_scratch(ctx, sizeof(StatsCompact), &scr));
+    UQ_CHECK_HIP(hipMemsetAsync(scr, 0, 8, ctx->stream));
+    stats_compact_kernel<<<65536 / 256, 256, 0, ctx->stream>>>(d_stats, (StatsCompact*)scr);
+    UQ_LAUNCH_CHECK();
+    UQ_CHECK_HIP(hipMemcpyAsync(ctx->h_pinned, scr, sizeof(StatsCompact), hipMemcpyDeviceToHost, ctx->stream));
+    UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    const StatsCompact* c = (const StatsCompact*)ctx->h_pinned;
+    if (c->n > SC_CAP) {                                   // an unusually rich file: the whole table
+        UQ_CHECK_HIP(hipMemcpyAsync(h_stats, d_stats, sizeof(uq_stats), hipMemcpyDeviceToHost, ctx->stream));
+        UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        return 0;
+    }
+    memset(h_stats->counts, 0, sizeof(h_stats->counts));
+    for (uint32_t k = 0; k < c->n; ++k) h_stats->counts[c->key[k]] = c->count[k];
+    h_stats->bad_plus = c->bad_plus; h_stats->bad_len = c->bad_len; h_stats->len_min = c->len_min; h_stats->len_max = c->len_max;
+    h_stats->max_record_bytes = c->max_record_bytes; h_stats->reserved = c->reserved;
+    return 0;
+}
 
 extern "C" int uq_stats_init(uq_ctx* ctx, uq_stats* d_stats) {
     UQ_REQUIRE(ctx && d_stats, "uq_stats_init: null argument");

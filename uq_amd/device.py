@@ -78,3 +78,30 @@ class Context:
     @staticmethod
     def ptr(tensor):
         return C.c_void_p(tensor.data_ptr()) if tensor is not None else C.c_void_p(0)
+
+
+class SideContext:
+    """A second `uq_ctx` on the same device with a private stream of its own: small independent work (the encoder's guess from the
+    head of the file) runs and synchronises there while the main context's stream is busy with the census.  Shares the torch
+    device; tensors it allocates are used and synchronised on its own stream before they are dropped."""
+
+    def __init__(self, ctx):
+        self.torch, self.device, self.main = ctx.torch, ctx.device, ctx
+        h = C.c_void_p()
+        call('uq_ctx_create', int(ctx.device.index), None, C.byref(h))
+        self.h = h
+
+    def to_numpy(self, tensor, dtype=None, shape=None):
+        return self.main.to_numpy(tensor, dtype, shape)
+
+    def sync(self):
+        call('uq_ctx_sync', self.h)
+
+    def close(self):
+        if self.h:
+            call('uq_ctx_destroy', self.h)
+            self.h = None
+
+    def __del__(self):
+        try: self.close()
+        except Exception: pass

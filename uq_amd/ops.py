@@ -107,7 +107,7 @@ def index_and_stats(ctx, buf, nlines, fused=False):
 
 def stats_fetch(ctx, d_stats):
     raw = np.empty(1, dtype=STATS_DTYPE)
-    call('uq_d2h', ctx.h, C.c_void_p(raw.ctypes.data), _p(d_stats), raw.nbytes)
+    call('uq_stats_fetch', ctx.h, _p(d_stats), C.c_void_p(raw.ctypes.data))
     return HostStats(raw[0])
 
 
@@ -189,18 +189,19 @@ def encode_stream(ctx, buf, guess, max_reads, with_stats=True):
 
 HEAD_BYTES = 24 << 20          # the slice of the file the one-pass encoder's guess is taken from
 HEAD_READS = 65536
+HEAD_BYTES_SMALL = 4 << 20     # ... and the pack-and-count encoder's (8192 reads of <= 512 bytes)
 HEAD_READS_INDEXED = 8192
 
 
-def head_guess(ctx, buf, notricks=False, pad=False):
+def head_guess(ctx, buf, notricks=False, pad=False, head_bytes=None, head_reads=None):
     """uq_pack_params guessed from the head of the file itself: the multi-pass statistics (uq.py:366-425) of its first
     HEAD_READS reads -> the decisions of uq.py:448-545 on that sample.  Returns (params, reads per byte estimate) or None when
     the head holds no complete record.  A guess is only ever used speculatively: the caller verifies it against the
     statistics of the WHOLE file (uq_encode_stream counts them in the same pass)."""
     from . import analysis
-    head = buf[:HEAD_BYTES]
+    head = buf[:head_bytes or HEAD_BYTES]
     nl = count_lines(ctx, head)
-    n = min(nl // 4, HEAD_READS)
+    n = min(nl // 4, head_reads or HEAD_READS)
     if n == 0:
         return None
     ls = index_lines(ctx, head, nl)
