@@ -312,7 +312,8 @@ int uq_encode_int(uq_ctx* ctx, const int64_t* d_val, uint64_t n, int64_t sub, in
  * lengths uq_unpack produced, and the QNAME columns (device arrays, one value per read, little-endian
  * unsigned of itemsize[c] bytes).  Integer columns print str(value + add[c]) (add = 'min' when the
  * column has an offset); mapping columns copy string number `value` of a flattened table
- * (h_d_map_chars[c], h_d_map_offs[c][nmap + 1]; both NULL for integer columns).
+ * (h_d_map_chars[c], h_d_map_offs[c][nmap + 1]; both NULL for integer columns) and pass nmap in add[c] (0 = not
+ * given): a value >= nmap then reads the last string, never beyond the table -- uq_check_index_range tells the caller.
  * Record = prefix + fields joined by separators[c] + suffix '\n' SEQ '\n' '+' '\n' QUAL '\n'.
  * d_offsets: uint64[nreads + 1] workspace (record offsets on return).  With d_out == NULL only the total
  * size is computed (*h_total). */

@@ -50,6 +50,10 @@ __device__ __forceinline__ uint32_t ndigits_u64(uint64_t v) {
 // text length of field c of read r; for integers also returns the magnitude and sign
 __device__ __forceinline__ uint32_t field_from_raw(const EmitGeom& g, uint32_t c, uint64_t raw, uint64_t& mag, bool& neg, uint32_t& moff) {
     if (g.map_chars[c]) {
+        // add[c] of a mapping column = the number of its strings (0: not given): a stored code beyond the table reads its last
+        // string instead of whatever lies behind the offsets (callers that want the error ask uq_check_index_range first)
+        const uint64_t nmap = (uint64_t)g.add[c];
+        if (nmap && raw >= nmap) raw = nmap - 1;
         moff = g.map_offs[c][raw];
         mag = 0; neg = false;
         return g.map_offs[c][raw + 1] - moff;

@@ -489,6 +489,7 @@ def _emit_params(ctx, config, column_tensors):
             offt = ctx.to_device(offs)
             keep += [chars, offt]
             d_chars[i] = chars.data_ptr(); d_offs[i] = offt.data_ptr()
+            p.add[i] = len(strs)                                 # mapping columns: the table's length (codes are clamped to it on the device)
     return p, d_cols, d_chars, d_offs, keep
 
 
