@@ -4,7 +4,10 @@
 //
 // Keys are whole rows of C bytes (38 .. 227 B and more) compared like memcmp.  An LSD radix sort over
 // every byte would need C passes; instead the sort is MSD by 8-byte chunks with LSD radix inside:
-//   round 0   sort all rows by chunk 0 (their first 8 bytes as a big-endian u64), stable;
+//   round 0   sort all rows by chunk 0 (their first 8 bytes as a big-endian u64), stable -- or, for wide rows whose chunk 0
+//             is rich in its leading bits, by the 32 bits behind chunk 0's constant leading bits as u32 keys (four passes of
+//             20 B a pair instead of eight of 32 B); the rows that collide on those join the duplicates in round 1, which then
+//             sorts (tie segment, rest of chunk 0) as one key;
 //   round k   only rows that still tie with a neighbour ("active") are touched: they are compacted,
 //             sorted by chunk k, then stably regrouped by their tie-segment id, and written back into
 //             the slots their segment occupies.  Distinct rows drop out as soon as a chunk separates
@@ -104,36 +107,7 @@ __global__ void tail_differs_kernel(const uint8_t* __restrict__ table, uint32_t 
     if (diff) *flag = 1u;
 }
 
-// a[j] = row j (in sorted position) belongs to a tie segment of size >= 2; h[j] = a[j] && heads[j]
-__global__ void active_flags_kernel(const uint8_t* __restrict__ heads, uint64_t n, uint32_t* __restrict__ a, uint32_t* __restrict__ h) {
-    uint64_t j = (uint64_t)blockIdx.x * ST + threadIdx.x;
-    if (j >= n) return;
-    const bool hd = heads[j] != 0;
-    const bool next_head = (j + 1 == n) || heads[j + 1] != 0;
-    const bool act = !(hd && next_head);
-    a[j] = act ? 1u : 0u;
-    h[j] = (act && hd) ? 1u : 0u;
-}
-
-// compact the active slots: pos[u] = j, aval[u] = perm[j], sid[u] = dense id of j's tie segment;
-// and pull chunk k of each active row: keys[u], vals[u] = u
-__global__ void compact_active_kernel(const uint32_t* __restrict__ a, const uint32_t* __restrict__ apos, const uint32_t* __restrict__ h,
-                                      const uint32_t* __restrict__ hpos, const uint32_t* __restrict__ perm, uint64_t n,
-                                      const uint8_t* __restrict__ table, uint32_t C, uint32_t k,
-                                      uint32_t* __restrict__ pos, uint32_t* __restrict__ aval, uint32_t* __restrict__ sid,
-                                      uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
-    uint64_t j = (uint64_t)blockIdx.x * ST + threadIdx.x;
-    if (j >= n || !a[j]) return;
-    const uint32_t u = apos[j];
-    const uint32_t row = perm[j];
-    pos[u] = (uint32_t)j;
-    aval[u] = row;
-    sid[u] = hpos[j] + h[j] - 1;
-    keys[u] = load_chunk_be(table + (uint64_t)row * C, C, k);
-    vals[u] = u;
-}
-
-// ---- the same compaction without arrays of n flags and their scans: per block of CB sorted positions the number of rows
+// ---- compaction of the rows that still tie, without arrays of n flags and their scans: per block of CB sorted positions the number of rows
 // that still tie and of tie segments that start there (counts[2 b], [2 b + 1]); after a scan of those few counters the
 // second kernel recomputes the flags of its block, ranks them inside the block and writes the compacted lists.
 constexpr int CB = 1024;                     // positions per workgroup of 256: four per lane
@@ -231,7 +205,7 @@ int sort_rows_core(uq_ctx* ctx, const uint8_t* table, uint64_t n, uint32_t C, ui
     const size_t o_valsA = plan.add(n * 4), o_valsB = plan.add(n * 4);
     const size_t o_heads = plan.add(n + 16);
     const size_t o_a = plan.add(n * 4), o_h = plan.add(n * 4);
-    const size_t o_apos = plan.add(n * 4), o_hpos = plan.add(n * 4);
+    const size_t o_apos = plan.add(n * 4);
     const size_t o_pos = plan.add(n * 4), o_aval = plan.add(n * 4), o_sid = plan.add(n * 4);
     const size_t o_tot = plan.add(64);
     const size_t o_rws = plan.add(radix_ws_bytes(n));
@@ -243,7 +217,7 @@ int sort_rows_core(uq_ctx* ctx, const uint8_t* table, uint64_t n, uint32_t C, ui
     uint32_t* valsA = (uint32_t*)(b + o_valsA); uint32_t* valsB = (uint32_t*)(b + o_valsB);
     uint8_t* heads = b + o_heads;
     uint32_t* fa = (uint32_t*)(b + o_a); uint32_t* fh = (uint32_t*)(b + o_h);
-    uint32_t* apos = (uint32_t*)(b + o_apos); uint32_t* hpos = (uint32_t*)(b + o_hpos);
+    uint32_t* apos = (uint32_t*)(b + o_apos);
     uint32_t* pos = (uint32_t*)(b + o_pos); uint32_t* aval = (uint32_t*)(b + o_aval); uint32_t* sid = (uint32_t*)(b + o_sid);
     uint64_t* tot = (uint64_t*)(b + o_tot);
     void* rws = b + o_rws;
@@ -361,12 +335,7 @@ int sort_rows_core(uq_ctx* ctx, const uint8_t* table, uint64_t n, uint32_t C, ui
     return 0;
 }
 
-// ---- unique / inverse from the sorted order + head flags
-__global__ void heads_to_u32_kernel(const uint8_t* __restrict__ heads, uint64_t n, uint32_t* __restrict__ f) {
-    uint64_t j = (uint64_t)blockIdx.x * ST + threadIdx.x;
-    if (j < n) f[j] = heads[j];
-}
-// the same without the n-sized flag array and its scan: heads per block of CB positions, then ranks inside the block
+// ---- unique / inverse from the sorted order + head flags: heads per block of CB positions, then ranks inside the block
 __global__ __launch_bounds__(ST) void heads_count_kernel(const uint8_t* __restrict__ heads, uint64_t n, uint32_t* __restrict__ counts) {
     __shared__ uint32_t sc[ST / 64];
     const uint64_t j0 = (uint64_t)blockIdx.x * CB + (uint64_t)threadIdx.x * 4;
@@ -399,17 +368,6 @@ __global__ __launch_bounds__(ST) void keys_from_groups2_kernel(const uint8_t* __
         if (sorted_key) sorted_key[j] = g - 1;
         if (uidx && hd[i]) uidx[g - 1] = row;
     }
-}
-
-__global__ void keys_from_groups_kernel(const uint8_t* __restrict__ heads, const uint32_t* __restrict__ gscan, const uint32_t* __restrict__ perm,
-                                        uint64_t n, uint32_t* __restrict__ key, uint32_t* __restrict__ sorted_key, uint32_t* __restrict__ uidx) {
-    uint64_t j = (uint64_t)blockIdx.x * ST + threadIdx.x;
-    if (j >= n) return;
-    const uint32_t g = gscan[j] + heads[j] - 1;     // inclusive count of heads - 1
-    const uint32_t row = perm[j];
-    if (key) key[row] = g;
-    if (sorted_key) sorted_key[j] = g;
-    if (uidx && heads[j]) uidx[g] = row;
 }
 
 __global__ void lower_bound_rows_kernel(const uint8_t* __restrict__ table, uint64_t rows, uint32_t C, const uint8_t* __restrict__ probes,
