@@ -37,6 +37,7 @@ def main():
     ap.add_argument('--var-min', type=int, default=0, help='variable read lengths from this minimum (0 = fixed)')
     ap.add_argument('--n-rate', type=int, default=0)
     ap.add_argument('--reps', type=int, default=5)
+    ap.add_argument('--no-check', action='store_true', help='timing experiments with variant libraries (UQ_LIB_PATH): a wrong text is reported, not fatal')
     ap.add_argument('--only-fused', action='store_true', help='time uq_decode_fastq only (clean kernel / counter profiles)')
     args = ap.parse_args()
     ctx = Context(0)
@@ -78,7 +79,7 @@ def main():
     ms, (text, bad) = timed(lambda: ops.decode_fastq(ctx, config, cols, dna, qual, n), args.reps)
     same = bad is None and text.numel() == d_buf.numel() and bool(torch.equal(text, d_buf))
     report('decode_fastq', ms, dna.numel() + qual.numel() + sum(c.numel() * c.element_size() for c in cols) + text.numel(), round_trip=same)
-    if not same: sys.exit('decode bench: the one-pass text differs from the input')
+    if not same and not args.no_check: sys.exit('decode bench: the one-pass text differs from the input')
 
 
 if __name__ == '__main__':

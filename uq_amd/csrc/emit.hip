@@ -140,7 +140,7 @@ struct TileGeom {
     uint32_t o_off, o_len, o_flen, o_ind, o_inq;                 // LDS byte offsets behind the image
     uint32_t magicP;                                             // magic_u32(prefix_len)
     uint32_t bd, bq, Cd, Cq, G, magicG;                          // packed form: row geometry, G = 8-symbol groups per read
-    uint32_t variable, Gf, magicGf, o_cum;                       // Gf = whole groups of a fixed-length read
+    uint32_t variable, NC, magicNC, o_cum, RS;                   // fixed length: NC = chunks a line can touch, RS = reads a workgroup-step covers (EM_THREADS / NC)
     FastAlphabet fa;
 };
 struct NoLut {};
@@ -150,34 +150,52 @@ __device__ __forceinline__ uint32_t load_u32_any(const uint8_t* p) { uint32_t v;
 // ---- packed form, fast alphabet: eight symbols per lane without per-symbol work
 // byte k of the result = bits (7 - 2k .. 6 - 2k) of x: the four 2-bit base codes of one row byte, in text order
 __device__ __forceinline__ uint32_t spread2(uint32_t x) { return ((x >> 6) | (x << 4) | (x << 14) | (x << 24)) & 0x03030303u; }
-// the BQ row bytes at p hold eight BQ-bit quality codes, first character in the top bits: qlo = characters 0..3, qhi = 4..7, one per byte
-// (x, y) = the eight bytes at p as two little-endian dwords, fetched as the three ALIGNED dwords around them: half the LDS
-// instructions of BQ byte reads, and no 64-bit shifting to put the bytes together
+// ---- LDS access on gfx950 (tools/ldsbench.hip, profiles/r02_l_ldsbench.txt): a wave-instruction at its natural alignment
+// takes 3 - 7 cycles; the same instruction at a misaligned address takes 40 (reads) or 128 (writes) -- the lanes go one
+// by one.  So the decoder works from the DESTINATION: a lane produces one 8-byte-aligned chunk of the text image, and
+// pulls the bits of its eight symbols out of the packed rows through aligned dwords.
+// (32-bit multiplies and 64-bit shifts by a variable run at a quarter of the rate of the other integer instructions: the
+// index arithmetic below uses the 24-bit multiply, v_perm and v_alignbit instead)
+// selector of v_perm_b32 that takes the four bytes at + 3 .. at (in this order: a big-endian number) out of the two aligned dwords around `at`
+__device__ __forceinline__ uint32_t be_selector(uint32_t at) { return 0x00010203u + __builtin_amdgcn_perm(0u, at & 3u, 0u); }   // byte 0 of (at & 3) in all four
+// big-endian number of the four bytes tile[at .. at + 3] (any alignment), from the two aligned dwords around them
+__device__ __forceinline__ uint32_t be32_at(const uint8_t* tile, uint32_t at) {
+    const uint32_t* q = (const uint32_t*)(tile + (at & ~3u));
+    return __builtin_amdgcn_perm(q[1], q[0], be_selector(at));
+}
+// 2-bit codes of the symbols t0 + 7 .. t0 (t = index from the END of the read; text order = descending t) of the row whose
+// last byte is tile[end]: byte k of (lo, hi) = the code of text byte k of the chunk.  t0 may be negative or reach beyond the
+// read at the chunks on a line's edges: those bytes are never stored, and the addresses stay inside the rows' carve.
+__device__ __forceinline__ void dna_codes8(const uint8_t* tile, uint32_t end, int32_t t0, uint32_t& lo, uint32_t& hi) {
+    const int32_t b0 = 2 * t0;
+    const uint32_t w = be32_at(tile, (uint32_t)((int32_t)end - 3 - (b0 >> 3))) >> (b0 & 7);
+    lo = spread2((w >> 8) & 0xFFu); hi = spread2(w & 0xFFu);
+}
+// the same for BQ-bit quality codes
 template <int BQ>
-__device__ __forceinline__ void qual8(const uint8_t* p, uint32_t& qlo, uint32_t& qhi) {
-    const uint32_t a = (uint32_t)(uintptr_t)p & 3u;
-    const uint32_t* q = (const uint32_t*)(p - a);
-    const uint32_t d0 = q[0], d1 = q[1], d2 = BQ + 3 > 8 ? q[2] : 0u;          // BQ <= 5: bytes a .. a + BQ - 1 end inside d1
-    const uint32_t x = __builtin_amdgcn_alignbyte(d1, d0, a), y = __builtin_amdgcn_alignbyte(d2, d1, a);
-    const uint64_t be = ((uint64_t)__builtin_bswap32(x) << 32) | __builtin_bswap32(y);   // the bytes as one big-endian number
-    const uint64_t V = be >> (64 - 8 * BQ);
-    const uint32_t up = (uint32_t)(V >> (4 * BQ)), dn = (uint32_t)V & ((1u << (4 * BQ)) - 1u);       // 4 BQ <= 28 bits each
+__device__ __forceinline__ void qual_codes8(const uint8_t* tile, uint32_t end, int32_t t0, uint32_t& qlo, uint32_t& qhi) {
+    const int32_t b0 = __mul24(BQ, t0);
+    const uint32_t at = (uint32_t)((int32_t)end - 7 - (b0 >> 3));
+    const uint32_t* q = (const uint32_t*)(tile + (at & ~3u));
+    const uint32_t sel = be_selector(at);
+    const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+    const uint32_t whi = __builtin_amdgcn_perm(d1, d0, sel), wlo = __builtin_amdgcn_perm(d2, d1, sel), sh = (uint32_t)b0 & 7u;
+    const uint64_t V = ((uint64_t)(whi >> sh) << 32) | __builtin_amdgcn_alignbit(whi, wlo, sh);       // (whi : wlo) >> sh
+    const uint32_t up = (uint32_t)(V >> (4 * BQ)) & ((1u << (4 * BQ)) - 1u), dn = (uint32_t)V & ((1u << (4 * BQ)) - 1u);       // 4 BQ <= 28 bits each
     constexpr uint32_t M = (1u << BQ) - 1u;
     qlo = ((up >> (3 * BQ)) & M) | (((up >> (2 * BQ)) & M) << 8) | (((up >> BQ) & M) << 16) | ((up & M) << 24);
     qhi = ((dn >> (3 * BQ)) & M) | (((dn >> (2 * BQ)) & M) << 8) | (((dn >> BQ) & M) << 16) | ((dn & M) << 24);
 }
-// Eight text bytes (lo = 0..3, hi = 4..7) to the image at byte offset `at` (any alignment), as the ALIGNED dwords that
-// lie inside the run of whole groups: with at % 4 = a != 0 that is the dword the lane's bytes fill and -- when eight more
-// characters follow (has_dn; nb_lo = their first four, from the lane below) -- the dword that straddles the two groups.
-// The first 4 - a bytes of a read's top group and the last a of its bottom group are left to the per-read fix-up.
-__device__ __forceinline__ void store8(uint8_t* image, uint32_t at, uint32_t lo, uint32_t hi, uint32_t nb_lo, bool has_dn) {
-    // branch-free: with sh = -a mod 4, t1 = (hi:lo) >> 8 sh and t2 = (nb_lo:hi) >> 8 sh are (lo, hi) when a = 0 and the
-    // filled / the straddling dword otherwise
-    const uint32_t a = at & 3u, sh = (0u - a) & 3u;
-    uint8_t* base = image + (at & ~3u);
-    const uint32_t t1 = __builtin_amdgcn_alignbyte(hi, lo, sh), t2 = __builtin_amdgcn_alignbyte(nb_lo, hi, sh);
-    *(uint32_t*)(base + 4) = a ? t1 : t2;
-    if (!a || has_dn) *(uint32_t*)(base + (a ? 8 : 0)) = a ? t2 : t1;
+__device__ __forceinline__ void qual_codes8(uint32_t bq, const uint8_t* tile, uint32_t end, int32_t t0, uint32_t& qlo, uint32_t& qhi) {
+    switch (bq) {
+        case 1: qual_codes8<1>(tile, end, t0, qlo, qhi); break;
+        case 2: qual_codes8<2>(tile, end, t0, qlo, qhi); break;
+        case 3: qual_codes8<3>(tile, end, t0, qlo, qhi); break;
+        case 4: qual_codes8<4>(tile, end, t0, qlo, qhi); break;
+        case 5: qual_codes8<5>(tile, end, t0, qlo, qhi); break;
+        case 6: qual_codes8<6>(tile, end, t0, qlo, qhi); break;
+        default: qual_codes8<7>(tile, end, t0, qlo, qhi); break;
+    }
 }
 // one symbol through the tables: t = its index from the END of the read (rows are right-aligned)
 __device__ __forceinline__ void decode_symbol(const uint8_t* drow, const uint8_t* qrow, const TileGeom& tg, uint32_t t, const uint8_t* l_base,
@@ -218,7 +236,7 @@ __global__ __launch_bounds__(EM_THREADS, 4) void emit_tile_kernel(EmitGeom g, Ti
     unsigned long long* s_off = (unsigned long long*)(tile + tg.o_off);              // [R + 1] record offsets of the tile, as fetched
     uint32_t* s_len = (uint32_t*)(tile + tg.o_len);                                  // [R]
     uint16_t* flen = (uint16_t*)(tile + tg.o_flen);                                  // [R][ncols]
-    uint32_t* cum = (uint32_t*)(tile + tg.o_cum);                                    // [R + 1] packed form: whole 8-symbol groups before record i
+    uint32_t* cum = (uint32_t*)(tile + tg.o_cum);                                    // [R + 1] packed form: chunk items before record i
     __shared__ uint8_t l_tab[PACKED ? 768 : 4];
     const uint8_t* l_base = l_tab; const uint8_t* l_qual = l_tab + 256; const uint8_t* l_qn = l_tab + 512;
     // the QNAME layout (prefix, suffix, separators, the per-column pointers and offsets) is indexed per lane: an LDS copy
@@ -268,6 +286,8 @@ __global__ __launch_bounds__(EM_THREADS, 4) void emit_tile_kernel(EmitGeom g, Ti
         for (int u = 0; u < DE_NVQ; ++u) { const uint32_t i = u * EM_THREADS + tid; if (i < x.nvq) x.q[u] = sq[i]; }
         return x;
     };
+    uint32_t my_slot = 0, my_j = 0;                        // packed form, fixed length: this lane's place in a step (see stage 2)
+    if (PACKED) fast_divmod(tid, tg.NC, tg.magicNC, my_slot, my_j);
     Pre nx = fetch(blockIdx.x);
     Rows nr = fetch_rows(blockIdx.x);
     for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
@@ -278,8 +298,8 @@ __global__ __launch_bounds__(EM_THREADS, 4) void emit_tile_kernel(EmitGeom g, Ti
         if (tid < Rt) s_len[tid] = cur.L;
         uint32_t skd = 0, skq = 0;
         if constexpr (PACKED) {
-            if (tid < 64) {                               // wave 0 holds every length of the tile (R <= 64): running count of whole groups
-                uint32_t v = tid < Rt ? cur.L >> 3 : 0u;
+            if (tid < 64) {                               // wave 0 holds every length of the tile (R <= 64): running count of chunk items
+                uint32_t v = tid < Rt ? (cur.L + 14u) >> 3 : 0u;       // the most chunks a line of L characters can touch
 #pragma unroll
                 for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(v, d, 64); if (lane >= (uint32_t)d) v += o; }
                 if (tid < R) cum[tid + 1] = v;            // R + 1 entries: lanes beyond the tile have nowhere to write
@@ -368,84 +388,74 @@ __global__ __launch_bounds__(EM_THREADS, 4) void emit_tile_kernel(EmitGeom g, Ti
             const uint8_t* in_q = tile + tg.o_inq + skq;
             const FastAlphabet& fa = tg.fa;
             if (fa.fast) {
-                // whole groups of the lookup-free alphabet, flat over the tile: item = (read, group) in the order of cum[] (the
-                // running count of whole groups, left by wave 0 before the first barrier); byte k of (lo, hi) is the
-                // character at L - 8 gg - 8 + k, and the image receives aligned dwords only (store8).  A wave-step takes
-                // 63 items: lane 0 recomputes the item before them, which only supplies its bytes to lane 1.
-                const uint32_t total = cum[Rt];
-                for (uint32_t start = (tid >> 6) * 63u; start < total; start += (EM_THREADS / 64) * 63u) {
-                    const uint32_t item = start + lane - 1u;                 // lane 0 of the first step: none (wraps)
-                    const bool full = item < total;
-                    uint32_t r = 0, wg = 0, L = 0;
-                    if (full) {
-                        if (tg.variable) {                                   // largest r with cum[r] <= item
-                            uint32_t hi = Rt;
+                // the lookup-free alphabet, from the destination: a line of L characters that starts at image byte d lies in
+                // the aligned 8-byte chunks j = 0 .. (d % 8 + L - 1) / 8 behind d - d % 8; chunk j holds the characters
+                // p0 = 8 j - d % 8 .. p0 + 7.  A chunk wholly inside the line is one aligned LDS store of the main loop; the
+                // (at most two) others of a line are left to the edge pass below.
+                const uint32_t od = tg.o_ind + skd + tg.Cd - 1, oq = tg.o_inq + skq + tg.Cq - 1;      // last byte of row 0
+                auto seq8 = [&](uint32_t r, uint32_t L, int32_t p0) {        // characters p0 .. p0 + 7 of read r's SEQ line
+                    const int32_t t0 = (int32_t)L - 8 - p0;
+                    uint32_t clo, chi;
+                    dna_codes8(tile, od + __umul24(r, tg.Cd), t0, clo, chi);
+                    uint32_t blo = __builtin_amdgcn_perm(0u, fa.base_tab, clo), bhi = __builtin_amdgcn_perm(0u, fa.base_tab, chi);
+                    if (fa.has_n) {
+                        uint32_t qlo, qhi;
+                        qual_codes8(tg.bq, tile, oq + __umul24(r, tg.Cq), t0, qlo, qhi);
+                        const uint32_t mlo = ~nonzero_bytes(qlo ^ fa.n_code4), mhi = ~nonzero_bytes(qhi ^ fa.n_code4);
+                        blo = bfi(mlo, fa.n_char4, blo); bhi = bfi(mhi, fa.n_char4, bhi);
+                    }
+                    return ((uint64_t)bhi << 32) | blo;
+                };
+                auto qual8 = [&](uint32_t r, uint32_t L, int32_t p0) {       // ... of its QUAL line
+                    uint32_t qlo, qhi;
+                    qual_codes8(tg.bq, tile, oq + __umul24(r, tg.Cq), (int32_t)L - 8 - p0, qlo, qhi);
+                    // code + qmin; a code beyond the alphabet decodes to the tables' 0
+                    const uint32_t olo = nonzero_bytes((qlo + fa.q_over) & 0x80808080u), ohi = nonzero_bytes((qhi + fa.q_over) & 0x80808080u);
+                    qlo = (qlo + fa.qmin4) & ~olo; qhi = (qhi + fa.qmin4) & ~ohi;
+                    return ((uint64_t)qhi << 32) | qlo;
+                };
+                auto chunks = [&](uint32_t r, uint32_t j, uint32_t L) {      // chunk j of both lines of read r, where whole
+                    const uint32_t e = ro(r + 1), ds = e - 2 * L - 4, dq = e - L - 1;
+                    const int32_t ps = (int32_t)(8 * j) - (int32_t)(ds & 7u), pq = (int32_t)(8 * j) - (int32_t)(dq & 7u);
+                    if (ps >= 0 && ps + 8 <= (int32_t)L) *(uint64_t*)(tile + (ds & ~7u) + 8 * j) = seq8(r, L, ps);
+                    if (pq >= 0 && pq + 8 <= (int32_t)L) *(uint64_t*)(tile + (dq & ~7u) + 8 * j) = qual8(r, L, pq);
+                };
+                if (tg.variable || tg.RS == 0) {              // (RS = 0: fixed-length reads of more chunks than the workgroup has lanes)
+                    // flat over the tile: item = (read, chunk) in the order of cum[] (the running count of chunks, left by wave 0
+                    // before the first barrier)
+                    const uint32_t total = cum[Rt];
+                    for (uint32_t item = tid; item < total; item += EM_THREADS) {
+                        uint32_t r = 0, hi = Rt;                             // largest r with cum[r] <= item
 #pragma unroll
-                            for (int it = 0; it < 6; ++it) { const uint32_t mid = (r + hi) >> 1; if (cum[mid] <= item) r = mid; else hi = mid; }
-                            wg = item - cum[r];
-                        } else {
-                            fast_divmod(item, tg.Gf, tg.magicGf, r, wg);
-                        }
-                        L = s_len[r];
+                        for (int it = 0; it < 6; ++it) { const uint32_t mid = (r + hi) >> 1; if (cum[mid] <= item) r = mid; else hi = mid; }
+                        chunks(r, item - cum[r], s_len[r]);
                     }
-                    uint32_t blo = 0, bhi = 0, qlo = 0, qhi = 0;
-                    if (full) {
-                        const uint8_t* pd = in_d + r * tg.Cd + (tg.Cd - 2 * wg - 2);
-                        const uint8_t* pq = in_q + r * tg.Cq + (tg.Cq - tg.bq * (wg + 1));
-                        const uint32_t clo = spread2(pd[0]), chi = spread2(pd[1]);
-                        switch (tg.bq) {
-                            case 1: qual8<1>(pq, qlo, qhi); break;
-                            case 2: qual8<2>(pq, qlo, qhi); break;
-                            case 3: qual8<3>(pq, qlo, qhi); break;
-                            case 4: qual8<4>(pq, qlo, qhi); break;
-                            case 5: qual8<5>(pq, qlo, qhi); break;
-                            case 6: qual8<6>(pq, qlo, qhi); break;
-                            default: qual8<7>(pq, qlo, qhi); break;
-                        }
-                        blo = __builtin_amdgcn_perm(0u, fa.base_tab, clo); bhi = __builtin_amdgcn_perm(0u, fa.base_tab, chi);
-                        if (fa.has_n) {
-                            const uint32_t mlo = ~nonzero_bytes(qlo ^ fa.n_code4), mhi = ~nonzero_bytes(qhi ^ fa.n_code4);
-                            blo = bfi(mlo, fa.n_char4, blo); bhi = bfi(mhi, fa.n_char4, bhi);
-                        }
-                        // code + qmin; a code beyond the alphabet decodes to the tables' 0
-                        const uint32_t olo = nonzero_bytes((qlo + fa.q_over) & 0x80808080u), ohi = nonzero_bytes((qhi + fa.q_over) & 0x80808080u);
-                        qlo = (qlo + fa.qmin4) & ~olo; qhi = (qhi + fa.qmin4) & ~ohi;
-                    }
-                    const uint32_t nb_b = __shfl_up(blo, 1, 64), nb_q = __shfl_up(qlo, 1, 64);      // lane - 1 = group gg - 1 = the next eight characters
-                    if (full) {
-                        const uint32_t at = ro(r + 1) - 2 * L - 4 + (L - 8 * wg - 8);
-                        if (lane > 0) {
-                            store8(tile, at, blo, bhi, nb_b, wg > 0);
-                            store8(tile, at + L + 3, qlo, qhi, nb_q, wg > 0);
-                        }
-                    }
+                } else if (my_slot < tg.RS) {
+                    // fixed length: a lane keeps its chunk number for the whole kernel (my_slot, my_j = tid / NC, tid % NC) and
+                    // walks over the reads my_slot, my_slot + RS, ...
+                    for (uint32_t r = my_slot; r < Rt; r += tg.RS) chunks(r, my_j, g.dna_max);
                 }
-                // what is left of a read, a lane per byte: the symbols of the partial top group and those whose aligned dword is
-                // not wholly inside the run of whole groups (<= 3 at either end of each line) -- slots 0..9 from the front,
-                // 10..12 from the back -- and (slot 13) the separators
-                for (uint32_t idx = tid; idx < Rt * 16u; idx += EM_THREADS) {
-                    const uint32_t i = idx >> 4, k = idx & 15u;
-                    const uint32_t L = s_len[i], toff = ro(i + 1) - 2 * L - 4;
-                    uint8_t* ts = tile + toff;
-                    uint8_t* tq = ts + L + 3;
-                    if (k == 13) { ts[L] = '\n'; ts[L + 1] = '+'; ts[L + 2] = '\n'; tq[L] = '\n'; }
-                    if (k >= 13) continue;
-                    const uint32_t nsym = L & 7u;
-                    uint32_t headS = L, headQ = L, tailS = 0, tailQ = 0;
-                    if (L >= 8) {
-                        headS = nsym + ((0u - (toff + nsym)) & 3u); tailS = (toff + L) & 3u;
-                        headQ = nsym + ((0u - (toff + L + 3 + nsym)) & 3u); tailQ = (toff + L + 3 + L) & 3u;
-                    }
-                    uint32_t p; bool inS, inQ;
-                    if (k < 10) { p = k; inS = p < headS; inQ = p < headQ; }
-                    else { const uint32_t e = k - 10; p = L - 1 - e; inS = e < tailS; inQ = e < tailQ; }
-                    if (inS || inQ) {
-                        uint8_t cb, cc;
-                        decode_symbol(in_d + i * tg.Cd, in_q + i * tg.Cq, tg, L - 1 - p, l_base, l_qual, l_qn, cb, cc);
-                        if (inS) ts[p] = cb;
-                        if (inQ) tq[p] = cc;
-                    }
-                }
+                // the edge pass: wave 0 / 1 = first / last chunk of the SEQ lines, wave 2 / 3 = of the QUAL lines, a lane per read
+                // (R <= 64): the chunk's bytes inside the line one by one, where the main loop left it out.  Wave 0 also writes
+                // the separators.
+                static_assert(EM_THREADS == 4 * 64 && EM_RMAX <= 64, "the edge pass is one step of four waves");
+                do {
+                    const uint32_t i = lane, w = tid >> 6;
+                    if (i >= Rt) continue;
+                    const uint32_t L = s_len[i], e = ro(i + 1);
+                    const uint32_t d = w < 2 ? e - 2 * L - 4 : e - L - 1;
+                    if (w == 0) { tile[d + L] = '\n'; tile[d + L + 1] = '+'; tile[d + L + 2] = '\n'; tile[d + 2 * L + 3] = '\n'; }
+                    if (L == 0) continue;
+                    const uint32_t a = d & 7u, j = (w & 1u) ? (a + L - 1) >> 3 : 0u;
+                    if ((w & 1u) && j == 0) continue;                       // a one-chunk line: the head lane has it
+                    const int32_t p0 = (int32_t)(8 * j) - (int32_t)a;
+                    const int32_t k0 = p0 < 0 ? -p0 : 0, k1 = (int32_t)L - p0 < 8 ? (int32_t)L - p0 : 8;
+                    if (k0 == 0 && k1 == 8) continue;                        // whole: stored by the main loop
+                    const uint64_t v = w < 2 ? seq8(i, L, p0) : qual8(i, L, p0);
+                    uint8_t* c = tile + (d & ~7u) + 8 * j;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) if (k >= k0 && k < k1) c[k] = (uint8_t)(v >> (8 * k));
+                } while (false);
             } else {
                 // any other alphabet: a lane per 8 symbols, every symbol through the tables
                 for (uint32_t i = tid; i < Rt; i += EM_THREADS) {
@@ -528,7 +538,8 @@ __global__ __launch_bounds__(EM_THREADS, 4) void emit_tile_kernel(EmitGeom g, Ti
             if (skew) for (uint32_t b = skew + tid; b < 16 && b < endb; b += EM_THREADS) dst[b] = tile[b];
             if (v1 >= v0) for (uint32_t b = (v1 << 4) + tid; b < endb; b += EM_THREADS) dst[b] = tile[b];
         }
-        __syncthreads();
+        // no barrier here: what the next tile writes before ITS first barrier (offsets, lengths, field lengths, rows) is not read
+        // by stage 3, and every lane that gets there has passed the barrier above, behind the last readers of those arrays
     }
 }
 
@@ -635,6 +646,7 @@ size_t plan_tile(TileGeom& tg, uint64_t avg, const EmitGeom& g, bool packed) {
     uint64_t R = ((packed ? EM_BUDGET_PACKED : EM_BUDGET_TEXT) - 256) / per;
     if (R > EM_RMAX) R = EM_RMAX;
     if (packed) while (R > 0 && (R * tg.Cd + 48 > DE_NVD * EM_THREADS * 16u || R * tg.Cq + 48 > DE_NVQ * EM_THREADS * 16u)) --R;
+    if (packed && tg.fa.fast && !tg.variable && tg.RS && R > tg.RS) R -= R % tg.RS;      // whole steps of the fixed-length chunk loop
     const bool fits = R >= 1;
     if (!fits) R = 1;
     tg.R = (uint32_t)R;
@@ -700,7 +712,8 @@ extern "C" int uq_decode_fastq(uq_ctx* ctx, const uq_emit_params* hp, const uq_u
     UQ_REQUIRE(tg.Cd == (tg.bd * Lv + 7) / 8 && tg.Cq == (tg.bq * Lv + 7) / 8, "uq_decode_fastq: row bytes do not match the geometry");
     tg.G = (up->dna_max + 7) / 8;
     tg.magicG = magic_u32(tg.G);
-    tg.variable = variable; tg.Gf = up->dna_max / 8; tg.magicGf = tg.Gf ? magic_u32(tg.Gf) : 0;
+    tg.variable = variable; tg.NC = (up->dna_max + 14) / 8; tg.magicNC = magic_u32(tg.NC);
+    tg.RS = EM_THREADS / tg.NC;
     tg.fa = fast_alphabet(up);
     if (nreads == 0) return 0;
     UQ_REQUIRE(d_dna && d_qual && (d_len || !variable), "uq_decode_fastq: null buffer");
