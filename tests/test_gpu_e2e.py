@@ -363,6 +363,30 @@ def test_decode_many_qname_columns(ctx, tmp_path):
         if flags: assert _run_decode(ctx, path) == fq
 
 
+@pytest.mark.parametrize('shape', ['long-strings', 'twelve-columns', 'two-columns', 'long-reads'])
+def test_decode_variable_lengths_straight_to_hbm(ctx, tmp_path, shape):
+    """Variable read lengths with the lookup-free alphabet (2-bit bases, one contiguous quality range): uq_decode_fastq writes
+    SEQ / QUAL groups straight to HBM and stages only the QNAME lines (decode_stream_kernel).  Shapes: QNAME strings far beyond
+    the staging share of a line (a wave per line instead), more (record, field) items than lanes, lines
+    shorter than one group, reads of a few thousand bases (few reads per tile, flat group loop)."""
+    import random
+    rnd = random.Random(11)
+    recs = []
+    n = 300 if shape == 'long-reads' else 6000
+    for i in range(n):
+        L = rnd.choice([1, 2, 7, 8, 9, 15, 16, 17, 40, 63, 64, 65, 150]) if shape != 'long-reads' else rnd.choice([5, 800, 2047, 2048, 4100])
+        seq = ''.join(rnd.choice('ACGT') for _ in range(L)); q = ''.join(chr(rnd.randint(40, 70)) for _ in range(L))
+        if shape == 'long-strings': name = '@%s:%d:%s' % (rnd.choice(['flowcell-' + 'x' * 70, 'lane-' + 'y' * 130, 'z']), i, rnd.choice(['a' * 40, 'b']))
+        elif shape == 'twelve-columns': name = '@m%d:%d_%d %d/%d;%d,%d:%d:%d:%d:%d:%d#z' % (i, rnd.randint(0, 9), rnd.randint(-5, 5), 70000 + rnd.randint(0, 10 ** 6), rnd.randint(0, 3),
+                                                                                     rnd.randint(0, 255), rnd.randint(0, 65535), 2 ** 33 + rnd.randint(0, 1000), i % 3, rnd.randint(100, 999), i * 7, rnd.randint(0, 1))
+        else: name = '@r.%d %d' % (i, rnd.randint(0, 10 ** 9))
+        recs.append('%s\n%s\n+\n%s\n' % (name, seq, q))
+    fq = ''.join(recs).encode()
+    cfg, members, names, path = _run_encode(ctx, tmp_path, fq, ['--raw', 'DNA', 'QUAL', 'QNAME'])
+    assert cfg['bits_per_base'] == 2 and cfg['variable_read_lengths']
+    assert _run_decode(ctx, path) == fq
+
+
 def _rewrite_tar(src, dst, edit):
     """copy the container `src` to `dst` with member payloads changed by edit(name, bytes) -> bytes"""
     with tarfile.open(src) as t, tarfile.open(dst, 'w') as o:
