@@ -10,7 +10,7 @@
 //
 // All three kernels move a tile of TR table rows through LDS: the row-major side of a tile is one
 // contiguous span (16-byte coalesced loads/stores), the column-major side is C runs of TR bytes
-// (dword loads/stores, realigned with v_alignbyte when R is not a multiple of 4).
+// (dword loads/stores behind the run's first aligned address).
 // Algorithmic HBM bytes: 2 * R * C.
 #include "common.h"
 #include "tile_io.h"
@@ -22,10 +22,12 @@ struct PatGeom {
     uint64_t R;
     uint32_t C;
     uint32_t TR;      // rows per tile
-    uint32_t TRp;     // column pitch in LDS for the transposing kernels (multiple of 4)
+    uint32_t TRp;     // (unused)
     uint32_t fr, fc;  // flip rows / flip columns
     uint32_t magicC;  // ceil(2^32 / C)
 };
+
+__device__ __forceinline__ uint32_t load_u32_any(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 
 __device__ __forceinline__ void divmod_c(uint32_t k, const PatGeom& g, uint32_t& q, uint32_t& rem) {
     fast_divmod(k, g.C, g.magicC, q, rem);
@@ -70,106 +72,87 @@ __global__ __launch_bounds__(PT_THREADS) void pattern_rm_kernel(const uint8_t* _
     emit_span(out + ro0 * g.C, len, fn);
 }
 
-// ---------------------------------------------------------------- column-major, forward: T -> payload
+// ---------------------------------------------------------------- column-major family
+// The tile lies in LDS the way it lies in the TABLE (row-major, at the 16-byte phase of its address): that side moves with
+// 16-byte vectors, conflict-free.  The column runs of the payload are put together (forward) or taken apart (inverse) a dword
+// a lane -- four byte accesses at LDS stride C, and a wave's lanes 4 C bytes = C dwords apart: all 64 banks when C is odd (the
+// 113-byte quality rows), 32 when C = 2 mod 4 (38-byte DNA rows).  (Before: the LDS image was column-major and the row-major
+// side scattered / gathered single bytes whose lanes were 16 column pitches apart -- four banks for 64 lanes; the counters
+// showed more than half of the LDS time as bank conflicts, profiles/r02_n_pattern_pmc.txt.)
 __global__ __launch_bounds__(PT_THREADS) void pattern_cm_kernel(const uint8_t* __restrict__ T, PatGeom g, uint8_t* __restrict__ out) {
-    extern __shared__ __align__(16) uint8_t smem[];   // lds_t[c * TRp + i_out], + 16 bytes of slack
+    extern __shared__ __align__(16) uint8_t smem[];
     const uint64_t r0 = (uint64_t)blockIdx.x * g.TR;
     const uint32_t n = (uint32_t)((g.R - r0) < g.TR ? (g.R - r0) : g.TR);
-    const uint32_t len = n * g.C;
-    // A: 16-byte chunks of the row-major span, bytes scattered to their column runs
-    {
-        const uint8_t* src = T + r0 * g.C;
-        const uint64_t a0 = (uint64_t)(uintptr_t)src & ~uint64_t(15);
-        const uint32_t skew = (uint32_t)((uint64_t)(uintptr_t)src - a0);
-        const uint32_t nvec = (skew + len + 15) >> 4;
-        const uint4* s4 = (const uint4*)(uintptr_t)a0;
-        for (uint32_t q = threadIdx.x; q < nvec; q += PT_THREADS) {
-            uint4 v = s4[q];
-            uint32_t w[4] = {v.x, v.y, v.z, v.w};
-            int32_t k = (int32_t)(q * 16) - (int32_t)skew;
-            uint32_t rl = 0, c = 0;
-            if (k > 0) divmod_c((uint32_t)k, g, rl, c);
-#pragma unroll
-            for (int b = 0; b < 16; ++b, ++k) {
-                if (k >= 0 && (uint32_t)k < len) {
-                    uint32_t io = g.fr ? n - 1 - rl : rl;
-                    smem[c * g.TRp + io] = (uint8_t)(w[b >> 2] >> (8 * (b & 3)));
-                    if (++c == g.C) { c = 0; ++rl; }
-                }
-            }
-        }
-    }
+    const uint32_t skew = stage_span(T + r0 * g.C, n * g.C, smem);
     __syncthreads();
-    // B: each column run -> global, dword stores
     const uint64_t ro0 = g.fr ? g.R - r0 - n : r0;
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t* lds32 = (const uint32_t*)smem;
+    // run position p (0 .. n - 1) holds table row p, or n - 1 - p under a row flip: LDS byte first + p * step
+    const int32_t step = g.fr ? -(int32_t)g.C : (int32_t)g.C;
+    // (global accesses, unlike LDS ones, take any alignment at nearly full speed -- tools/storebench.hip -- so a run is moved as
+    // n / 4 dwords from its first byte, wherever that falls, and n % 4 bytes)
     for (uint32_t c = w; c < g.C; c += PT_THREADS / 64) {
         const uint32_t cc = g.fc ? g.C - 1 - c : c;
         uint8_t* s = out + (uint64_t)cc * g.R + ro0;
-        uint32_t head = (uint32_t)((4 - ((uintptr_t)s & 3)) & 3);
-        if (head > n) head = n;
-        const uint32_t nd = (n - head) >> 2;
-        const uint32_t tail = n - head - 4 * nd;
-        const uint8_t* col = smem + c * g.TRp;
-        if (lane < head) s[lane] = col[lane];
-        if (lane < tail) s[head + 4 * nd + lane] = col[head + 4 * nd + lane];
-        uint32_t* s32 = (uint32_t*)(s + head);
-        const uint32_t wbase = (c * g.TRp) >> 2;
+        const uint8_t* first = smem + skew + c + (g.fr ? (n - 1) * g.C : 0u);
+        const uint32_t nd = n >> 2;
         for (uint32_t d = lane; d < nd; d += 64) {
-            uint32_t lo = lds32[wbase + d], hi = lds32[wbase + d + 1];
-            s32[d] = __builtin_amdgcn_alignbyte(hi, lo, head);
+            const uint8_t* q = first + (int32_t)(4 * d) * step;
+            const uint32_t v = (uint32_t)q[0] | ((uint32_t)q[step] << 8) | ((uint32_t)q[2 * step] << 16) | ((uint32_t)q[3 * step] << 24);
+            __builtin_memcpy(s + 4 * d, &v, 4);
         }
+        if (lane < (n & 3u)) s[4 * nd + lane] = first[(int32_t)(4 * nd + lane) * step];
     }
 }
 
-// ---------------------------------------------------------------- column-major, inverse: payload -> T
-struct ColMajorInvFn {
-    const uint8_t* lds; const uint8_t* skewc; uint32_t n; const PatGeom& g;
-    __device__ __forceinline__ uint8_t at(uint32_t rl, uint32_t c) const {
-        uint32_t io = g.fr ? n - 1 - rl : rl;
-        return lds[c * g.TRp + skewc[c] + io];
-    }
-    __device__ __forceinline__ uint8_t byte(uint32_t k) const {
-        uint32_t i, c; divmod_c(k, g, i, c);
-        return at(i, c);
-    }
-    __device__ __forceinline__ void operator()(uint32_t k0, uint32_t* w) const {
-        uint32_t i, c; divmod_c(k0, g, i, c);
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            uint32_t v = 0;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                v |= (uint32_t)at(i, c) << (8 * b);
-                if (++c == g.C) { c = 0; ++i; }
-            }
-            w[d] = v;
-        }
-    }
-};
-
 __global__ __launch_bounds__(PT_THREADS) void unpattern_cm_kernel(const uint8_t* __restrict__ P, PatGeom g, uint8_t* __restrict__ T) {
-    extern __shared__ __align__(16) uint8_t smem[];   // [C * TRp] runs (each with its own 0..3 byte skew) + skew table [C]
-    uint8_t* skewc = smem + (size_t)g.C * g.TRp;
+    extern __shared__ __align__(16) uint8_t smem[];
     const uint64_t r0 = (uint64_t)blockIdx.x * g.TR;
     const uint32_t n = (uint32_t)((g.R - r0) < g.TR ? (g.R - r0) : g.TR);
     const uint64_t ro0 = g.fr ? g.R - r0 - n : r0;
+    uint8_t* dst = T + r0 * g.C;
+    const uint32_t skew = (uint32_t)((uintptr_t)dst & 15), len = n * g.C;
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    uint32_t* lds32 = (uint32_t*)smem;
-    for (uint32_t c = w; c < g.C; c += PT_THREADS / 64) {
-        const uint32_t cc = g.fc ? g.C - 1 - c : c;
-        const uint8_t* s = P + (uint64_t)cc * g.R + ro0;
-        const uint32_t sk = (uint32_t)((uintptr_t)s & 3);
-        const uint32_t* s32 = (const uint32_t*)(s - sk);
-        const uint32_t nd = (sk + n + 3) >> 2;
-        const uint32_t wbase = (c * g.TRp) >> 2;
-        for (uint32_t d = lane; d < nd; d += 64) lds32[wbase + d] = s32[d];
-        if (lane == 0) skewc[c] = (uint8_t)sk;
+    const int32_t step = g.fr ? -(int32_t)g.C : (int32_t)g.C;
+    // a wave takes the columns w, w + 4, ...; the dwords of PU runs are requested before the first is taken apart (a run is
+    // two cache lines somewhere in the payload: one request at a time leaves the wave waiting out each latency)
+    constexpr int PU = 4;
+    auto scatter = [&](uint32_t c, uint32_t d, uint32_t v) {            // the run's positions 4 d .. 4 d + 3
+        uint8_t* q = smem + skew + c + (g.fr ? (n - 1) * g.C : 0u) + (int32_t)(4 * d) * step;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q[j * step] = (uint8_t)(v >> (8 * j));
+    };
+    const uint32_t nd = n >> 2;
+    for (uint32_t c0 = w; c0 < g.C; c0 += PU * (PT_THREADS / 64)) {
+        const uint8_t* s[PU];
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+            const uint32_t c = c0 + u * (PT_THREADS / 64);
+            const uint32_t cc = g.fc ? g.C - 1 - c : c;
+            s[u] = c < g.C ? P + (uint64_t)cc * g.R + ro0 : nullptr;
+        }
+        for (uint32_t d = lane; d < nd; d += 64) {
+            uint32_t v[PU];
+#pragma unroll
+            for (int u = 0; u < PU; ++u) v[u] = s[u] ? load_u32_any(s[u] + 4 * d) : 0u;
+#pragma unroll
+            for (int u = 0; u < PU; ++u) if (s[u]) scatter(c0 + u * (PT_THREADS / 64), d, v[u]);
+        }
+        if (lane < (n & 3u)) {
+#pragma unroll
+            for (int u = 0; u < PU; ++u)
+                if (s[u]) smem[skew + c0 + u * (PT_THREADS / 64) + (g.fr ? (n - 1) * g.C : 0u) + (int32_t)(4 * nd + lane) * step] = s[u][4 * nd + lane];
+        }
     }
     __syncthreads();
-    ColMajorInvFn fn{smem, skewc, n, g};
-    emit_span(T + r0 * g.C, n * g.C, fn);
+    // the image mirrors the 16-byte phase of the destination: whole vectors inside the span, bytes at its two ends
+    uint8_t* a0 = dst - skew;
+    const uint32_t nvec = (skew + len + 15) >> 4;
+    for (uint32_t v = threadIdx.x; v < nvec; v += PT_THREADS) {
+        const uint32_t b0 = v * 16;
+        if (b0 >= skew && b0 + 16 <= skew + len) ((uint4*)a0)[v] = ((const uint4*)smem)[v];
+        else for (uint32_t b = b0 < skew ? skew : b0; b < b0 + 16 && b < skew + len; ++b) a0[b] = smem[b];
+    }
 }
 
 // Rows too wide for an LDS tile (long-read tables): one byte per lane, indexed directly.  Lanes walk the
@@ -239,10 +222,8 @@ int launch(uq_ctx* ctx, const uint8_t* in, uint64_t rows, uint32_t cols, int pat
         if (TR >= 64) TR &= ~63u; else if (TR >= 4) TR &= ~3u;
         if (TR == 0) TR = 1;
         if (TR > 2048) TR = 2048;
-        g.TR = TR;
-        g.TRp = ((TR + 3) & ~3u) + 8;           // room for the 0..3 byte skew and the hi word of alignbyte
-        if (((g.TRp >> 2) & 1) == 0) g.TRp += 4;  // odd number of dwords: consecutive columns shift banks
-        lds = (size_t)cols * g.TRp + 16 + cols + 16;
+        g.TR = TR; g.TRp = 0;
+        lds = (size_t)TR * cols + 48;
     }
     UQ_REQUIRE(lds <= 160 * 1024, "pattern: tile needs %zu bytes of LDS", lds);
     const uint64_t tiles = (rows + g.TR - 1) / g.TR;
