@@ -55,17 +55,19 @@ __global__ __launch_bounds__(ST) void extract_all_kernel(const uint8_t* __restri
         }
     }
 }
+// (one workgroup walking all the partials was 0.3 ms of latency for 3 MB: a grid of them, two atomics each, on words the caller
+// has set to ~0 and 0)
 __global__ __launch_bounds__(ST) void and_or_fold_kernel(const unsigned long long* __restrict__ part, uint64_t nblocks, unsigned long long* __restrict__ out) {
     __shared__ unsigned long long sa[ST / 64], so[ST / 64];
     unsigned long long a = ~0ull, o = 0ull;
-    for (uint64_t i = threadIdx.x; i < nblocks; i += ST) { a &= part[2 * i]; o |= part[2 * i + 1]; }
+    for (uint64_t i = (uint64_t)blockIdx.x * ST + threadIdx.x; i < nblocks; i += (uint64_t)gridDim.x * ST) { a &= part[2 * i]; o |= part[2 * i + 1]; }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { a &= __shfl_xor(a, d, 64); o |= __shfl_xor(o, d, 64); }
     if (lane_id() == 0) { sa[threadIdx.x >> 6] = a; so[threadIdx.x >> 6] = o; }
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < ST / 64; ++w) { a &= sa[w]; o |= so[w]; }
-        out[0] = a; out[1] = o;
+        atomicAnd(out, a); atomicOr(out + 1, o);
     }
 }
 // the 32 bits of chunk 0 behind its z constant leading bits
@@ -107,17 +109,78 @@ __global__ void tail_differs_kernel(const uint8_t* __restrict__ table, uint32_t 
     if (diff) *flag = 1u;
 }
 
+// ---- after the 32-bit round 0: the groups of rows that tie on the prefix are nearly all SHORT -- pairs that collide by chance
+// (n^2 / 2^33 of them) and duplicated reads -- so the lane at a group's first position sorts it on the spot: insertion sort of
+// its slice of `perm` by whole rows (memcmp order, stable: a row moves only past strictly greater ones), then the head flags
+// of the slice: 1 = a new row value, HEAD_DUP = equal to the row before AND final (the refinement rounds below leave the group
+// alone; the consumers count flag 1 only).  Groups beyond SEG_MAX rows keep their 0 flags and go through the radix rounds.
+constexpr uint32_t SEG_MAX = 32;
+constexpr uint8_t HEAD_DUP = 2;
+// memcmp order of two rows.  No early exit: the loads of the next words do not wait for the comparison of these (a row is one or
+// two cache lines, fetched whole anyway), four words of each row are in flight at a time.
+__device__ __forceinline__ int row_cmp(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, uint32_t C) {
+    int res = 0;
+    uint32_t i = 0;
+#pragma unroll 4
+    for (; i + 8 <= C; i += 8) {
+        uint64_t x, y;
+        __builtin_memcpy(&x, a + i, 8); __builtin_memcpy(&y, b + i, 8);
+        if (res == 0 && x != y) res = __builtin_bswap64(x) < __builtin_bswap64(y) ? -1 : 1;
+    }
+    if (i < C) {                                       // the last C % 8 bytes: the eight bytes that END the row, the overlap compared twice
+        uint64_t x, y;
+        if (C >= 8) { __builtin_memcpy(&x, a + C - 8, 8); __builtin_memcpy(&y, b + C - 8, 8); }
+        else { x = y = 0; for (uint32_t t = 0; t < C; ++t) { x |= (uint64_t)a[t] << (8 * t); y |= (uint64_t)b[t] << (8 * t); } }
+        if (res == 0 && x != y) res = __builtin_bswap64(x) < __builtin_bswap64(y) ? -1 : 1;
+    }
+    return res;
+}
+// The groups' first positions are compacted first (segment_starts_kernel, below the counting helpers): a lane per GROUP, every
+// lane of a wave busy -- a lane per POSITION left 60 of 64 lanes idle while the others chased pointers: 2.4 ms instead of 0.2.
+// `heads` is read, `flags` (a copy of it) is written: a lane must not mistake a flag its neighbour has just set for a group's first row.
+// *leftover is raised when a group was too long and keeps its 0 flags.
+__global__ __launch_bounds__(ST) void segment_sort_kernel(const uint8_t* __restrict__ table, uint32_t C, uint32_t* __restrict__ perm,
+                                                          const uint8_t* __restrict__ heads, uint8_t* __restrict__ flags, uint64_t n,
+                                                          const uint32_t* __restrict__ seg_start, const unsigned long long* __restrict__ totals,
+                                                          uint32_t* __restrict__ leftover) {
+    const uint64_t nseg = totals[0] >> 32;                        // {rows in open groups, open groups} as scanned
+    for (uint64_t sidx = (uint64_t)blockIdx.x * ST + threadIdx.x; sidx < nseg; sidx += (uint64_t)gridDim.x * ST) {
+        const uint64_t j = seg_start[sidx];
+        uint32_t k = 1;
+        while (j + k < n && heads[j + k] == 0 && k <= SEG_MAX) ++k;
+        if (k > SEG_MAX) { *leftover = 1u; continue; }
+        uint32_t* p = perm + j;
+        if (k == 2) {                                     // nearly every group: one comparison settles the order and the flag
+            const uint32_t x0 = p[0], x1 = p[1];
+            const int c = row_cmp(table + (uint64_t)x1 * C, table + (uint64_t)x0 * C, C);
+            if (c < 0) { p[0] = x1; p[1] = x0; }
+            flags[j + 1] = c == 0 ? HEAD_DUP : (uint8_t)1;
+            continue;
+        }
+        for (uint32_t i = 1; i < k; ++i) {
+            const uint32_t x = p[i];
+            const uint8_t* rx = table + (uint64_t)x * C;
+            uint32_t t = i;
+            while (t > 0 && row_cmp(rx, table + (uint64_t)p[t - 1] * C, C) < 0) { p[t] = p[t - 1]; --t; }
+            p[t] = x;
+        }
+        for (uint32_t i = 1; i < k; ++i)
+            flags[j + i] = row_cmp(table + (uint64_t)p[i] * C, table + (uint64_t)p[i - 1] * C, C) == 0 ? HEAD_DUP : (uint8_t)1;
+    }
+}
+
 // ---- compaction of the rows that still tie, without arrays of n flags and their scans: per block of CB sorted positions the number of rows
 // that still tie and of tie segments that start there (counts[2 b], [2 b + 1]); after a scan of those few counters the
 // second kernel recomputes the flags of its block, ranks them inside the block and writes the compacted lists.
 constexpr int CB = 1024;                     // positions per workgroup of 256: four per lane
+// flags: 1 = first row of a group, 0 = ties with the row before on everything looked at so far, HEAD_DUP = equal to the row before, final
 __device__ __forceinline__ void active_of(const uint8_t* __restrict__ heads, uint64_t n, uint64_t j, bool& act, bool& seg) {
     act = seg = false;
     if (j >= n) return;
-    const bool hd = heads[j] != 0;
-    const bool next_head = (j + 1 == n) || heads[j + 1] != 0;
-    act = !(hd && next_head);
-    seg = act && hd;
+    const uint8_t f = heads[j];
+    const bool next_open = (j + 1 < n) && heads[j + 1] == 0;
+    seg = f == 1 && next_open;                       // first row of a group that is still open
+    act = seg || f == 0;
 }
 __global__ __launch_bounds__(ST) void active_count_kernel(const uint8_t* __restrict__ heads, uint64_t n, uint32_t* __restrict__ counts) {
     __shared__ uint32_t sa[ST / 64], sh[ST / 64];
@@ -129,6 +192,20 @@ __global__ __launch_bounds__(ST) void active_count_kernel(const uint8_t* __restr
     if (lane_id() == 0) { sa[threadIdx.x >> 6] = a; sh[threadIdx.x >> 6] = h; }
     __syncthreads();
     if (threadIdx.x == 0) { counts[2 * (uint64_t)blockIdx.x] = sa[0] + sa[1] + sa[2] + sa[3]; counts[2 * (uint64_t)blockIdx.x + 1] = sh[0] + sh[1] + sh[2] + sh[3]; }
+}
+// first positions of the open groups, in order (offs as below)
+__global__ __launch_bounds__(ST) void segment_starts_kernel(const uint8_t* __restrict__ heads, const unsigned long long* __restrict__ offs, uint64_t n,
+                                                            uint32_t* __restrict__ seg_start) {
+    __shared__ uint32_t lds[ST / 64 + 1];
+    const uint64_t j0 = (uint64_t)blockIdx.x * CB + (uint64_t)threadIdx.x * 4;
+    bool seg[4];
+    uint32_t mine = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { bool act; active_of(heads, n, j0 + i, act, seg[i]); mine += seg[i]; }
+    uint32_t total;
+    uint32_t ex = block_exclusive_sum<uint32_t, ST / 64>(mine, lds, total) + (uint32_t)(offs[blockIdx.x] >> 32);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (seg[i]) seg_start[ex++] = (uint32_t)(j0 + i);
 }
 // offs = exclusive scan of counts (pairs interleaved: scanned as u64 = {actives, segments}, both below 2^32)
 __global__ __launch_bounds__(ST) void compact_active2_kernel(const uint8_t* __restrict__ heads, const unsigned long long* __restrict__ offs,
@@ -203,7 +280,7 @@ int sort_rows_core(uq_ctx* ctx, const uint8_t* table, uint64_t n, uint32_t C, ui
     ScratchPlan plan;
     const size_t o_keysA = plan.add(n * 8), o_keysB = plan.add(n * 8);
     const size_t o_valsA = plan.add(n * 4), o_valsB = plan.add(n * 4);
-    const size_t o_heads = plan.add(n + 16);
+    const size_t o_heads = plan.add(n + 16), o_heads2 = plan.add(n + 16);
     const size_t o_a = plan.add(n * 4), o_h = plan.add(n * 4);
     const size_t o_apos = plan.add(n * 4);
     const size_t o_pos = plan.add(n * 4), o_aval = plan.add(n * 4), o_sid = plan.add(n * 4);
@@ -232,7 +309,10 @@ int sort_rows_core(uq_ctx* ctx, const uint8_t* table, uint64_t n, uint32_t C, ui
     extract_all_kernel<<<blocks_for(n), ST, 0, s>>>(table, n, C, keysA, valsA, mode32 ? part : nullptr);
     UQ_LAUNCH_CHECK();
     if (mode32) {
-        and_or_fold_kernel<<<1, ST, 0, s>>>(part, blocks_for(n), (unsigned long long*)(tot + 4));
+        UQ_CHECK_HIP(hipMemsetAsync(tot + 4, 0xFF, 8, s));
+        UQ_CHECK_HIP(hipMemsetAsync(tot + 5, 0, 8, s));
+        const uint32_t fb = blocks_for(n) / (4 * ST) + 1;
+        and_or_fold_kernel<<<fb < 512 ? fb : 512, ST, 0, s>>>(part, blocks_for(n), (unsigned long long*)(tot + 4));
         UQ_LAUNCH_CHECK();
     }
     // A 64-bit LSD sort moves 32 B per pair and pass, eight passes.  Rows wider than a chunk go to refinement rounds anyway
@@ -252,7 +332,7 @@ int sort_rows_core(uq_ctx* ctx, const uint8_t* table, uint64_t n, uint32_t C, ui
     if (mode32) {
         uint32_t* k32a = (uint32_t*)keysB;                                      // keysB's n * 8 bytes hold both u32 key buffers
         uint32_t* k32b = k32a + n;
-        prefix32_kernel<<<blocks_for(n), ST, 0, s>>>(keysA, n, z, k32a, valsA);
+        prefix32_kernel<<<blocks_for(n), ST, 0, s>>>(keysA, n, z, k32a, d_perm);     // d_perm is the sort's value buffer: an even number of passes ends there
         UQ_LAUNCH_CHECK();
         static thread_local uint32_t h_hist[4 * 256];
         UQ_TRY(radix_census32(ctx, k32a, n, rws, h_hist));
@@ -265,10 +345,27 @@ int sort_rows_core(uq_ctx* ctx, const uint8_t* table, uint64_t n, uint32_t C, ui
         }
         if (coll > 0.3) mode32 = false;
         else {
-            UQ_TRY(radix_sort_pairs32(ctx, k32a, valsA, k32b, valsB, n, 0, 32, rws, &alt, h_hist));
-            UQ_CHECK_HIP(hipMemcpyAsync(d_perm, alt ? valsB : valsA, n * 4, hipMemcpyDeviceToDevice, s));
+            UQ_TRY(radix_sort_pairs32(ctx, k32a, d_perm, k32b, valsB, n, 0, 32, rws, &alt, h_hist));
+            if (alt) UQ_CHECK_HIP(hipMemcpyAsync(d_perm, valsB, n * 4, hipMemcpyDeviceToDevice, s));
             heads_first32_kernel<<<blocks_for(n), ST, 0, s>>>(alt ? k32b : k32a, n, heads);
             UQ_LAUNCH_CHECK();
+            // the groups that tie on the prefix are short (colliding pairs, duplicates): a lane sorts each by whole rows
+            uint8_t* flags = b + o_heads2;
+            UQ_CHECK_HIP(hipMemcpyAsync(flags, heads, n, hipMemcpyDeviceToDevice, s));
+            const uint64_t ncb0 = (n + CB - 1) / CB;
+            uint32_t* bcnt0 = apos;
+            active_count_kernel<<<(uint32_t)ncb0, ST, 0, s>>>(heads, n, bcnt0);
+            UQ_LAUNCH_CHECK();
+            UQ_TRY(uq_scan_exclusive_u64(ctx, (const uint64_t*)bcnt0, (uint64_t*)bcnt0, ncb0, tot));
+            segment_starts_kernel<<<(uint32_t)ncb0, ST, 0, s>>>(heads, (const unsigned long long*)bcnt0, n, pos);
+            UQ_LAUNCH_CHECK();
+            UQ_CHECK_HIP(hipMemsetAsync(tot + 3, 0, 8, s));
+            segment_sort_kernel<<<UQ_NUM_CU * 8, ST, 0, s>>>(table, C, d_perm, heads, flags, n, pos, (const unsigned long long*)tot, (uint32_t*)(tot + 3));
+            UQ_LAUNCH_CHECK();
+            heads = flags; out->heads = flags;
+            UQ_CHECK_HIP(hipMemcpyAsync(ctx->h_pinned, tot + 3, 8, hipMemcpyDeviceToHost, s));
+            UQ_CHECK_HIP(hipStreamSynchronize(s));
+            if ((uint32_t)ctx->h_pinned[0] == 0) return 0;        // every group settled: the order is final
         }
     }
     if (!mode32) {
@@ -341,7 +438,7 @@ __global__ __launch_bounds__(ST) void heads_count_kernel(const uint8_t* __restri
     const uint64_t j0 = (uint64_t)blockIdx.x * CB + (uint64_t)threadIdx.x * 4;
     uint32_t c = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) c += (j0 + i < n && heads[j0 + i]) ? 1u : 0u;
+    for (int i = 0; i < 4; ++i) c += (j0 + i < n && heads[j0 + i] == 1) ? 1u : 0u;
     c = wave_sum(c);
     if (lane_id() == 0) sc[threadIdx.x >> 6] = c;
     __syncthreads();
@@ -355,7 +452,7 @@ __global__ __launch_bounds__(ST) void keys_from_groups2_kernel(const uint8_t* __
     bool hd[4];
     uint32_t c = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { hd[i] = j0 + i < n && heads[j0 + i]; c += hd[i]; }
+    for (int i = 0; i < 4; ++i) { hd[i] = j0 + i < n && heads[j0 + i] == 1; c += hd[i]; }
     uint32_t total;
     uint32_t g = block_exclusive_sum<uint32_t, ST / 64>(c, lds, total) + boffs[blockIdx.x];       // heads in front of position j0
 #pragma unroll
