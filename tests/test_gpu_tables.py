@@ -130,6 +130,42 @@ def test_unique_rows(ctx, n, C, nd, prefix):
     assert np.array_equal(ctx.to_numpy(nk, O.narrow_key(rkey).dtype), O.narrow_key(rkey))
 
 
+def _rows_in_prefix_groups(rng, n, C, sizes):
+    """Rows that tie on their first 6 bytes in groups of the given sizes (the 32-bit round 0 of the sort cannot separate them),
+    members differing anywhere behind -- the last byte, the middle, right behind the prefix -- or not at all; shuffled."""
+    rows = []
+    while len(rows) < n:
+        k = int(rng.choice(sizes))
+        head = rng.randint(0, 256, size=min(6, C - 1)).astype(np.uint8)
+        distinct = max(1, int(rng.randint(1, k + 1)))
+        tails = rng.randint(0, 256, size=(distinct, C - len(head))).astype(np.uint8)
+        if distinct > 1: tails[1] = tails[0]; tails[1, -1] ^= 1                      # differ in the last byte only
+        if distinct > 2: tails[2] = tails[0]; tails[2, 0] ^= 0x80                    # ... right behind the prefix
+        for t in tails[rng.randint(0, distinct, size=k)]:
+            rows.append(np.concatenate([head, t]))
+    T = np.array(rows[:n], dtype=np.uint8)
+    return T[rng.permutation(n)]
+
+
+@pytest.mark.parametrize('C', [9, 13, 38, 113])
+@pytest.mark.parametrize('sizes', [(1, 2), (2, 3, 5, 31, 32), (33, 40, 2), (200,)], ids=['pairs', 'to-32', 'beyond-32', 'long'])
+def test_sort_groups_that_tie_on_the_prefix(ctx, C, sizes):
+    """Enough rows for the 32-bit round 0 (>= 65536): groups of up to 32 rows are settled a lane per group by whole rows
+    (segment_sort_kernel), longer ones by the radix refinement rounds, mixed in one table; order, duplicate flags (through unique /
+    inverse) and stability against numpy."""
+    n = 70_000
+    rng = np.random.RandomState(C * 7 + len(sizes))
+    T = _rows_in_prefix_groups(rng, n, C, sizes)
+    d_T = _dev(ctx, T.ravel())
+    perm = ctx.to_numpy(ops.argsort_rows(ctx, d_T, n, C), np.uint32).astype(np.int64)
+    assert np.array_equal(perm, O.argsort_rows(T))
+    perm2, key, skey, uniq, nu = ops.unique_rows(ctx, d_T, n, C)
+    ru, rkey = O.unique_rows(T)
+    assert nu == len(ru) and np.array_equal(ctx.to_numpy(uniq).reshape(nu, C), ru)
+    assert np.array_equal(ctx.to_numpy(key, np.uint32).astype(np.int64), rkey)
+    assert np.array_equal(ctx.to_numpy(perm2, np.uint32).astype(np.int64), np.argsort(rkey, kind='stable'))
+
+
 @pytest.mark.parametrize('n,C', [(1, 1), (100, 38), (5000, 113), (3000, 227), (4097, 25), (10, 300), (50000, 14)])
 @pytest.mark.parametrize('isz', [1, 2, 4, 8])
 def test_gather_rows(ctx, n, C, isz):

@@ -6,8 +6,9 @@
 // every byte would need C passes; instead the sort is MSD by 8-byte chunks with LSD radix inside:
 //   round 0   sort all rows by chunk 0 (their first 8 bytes as a big-endian u64), stable -- or, for wide rows whose chunk 0
 //             is rich in its leading bits, by the 32 bits behind chunk 0's constant leading bits as u32 keys (four passes of
-//             20 B a pair instead of eight of 32 B); the rows that collide on those join the duplicates in round 1, which then
-//             sorts (tie segment, rest of chunk 0) as one key;
+//             20 B a pair instead of eight of 32 B); the groups that tie on those -- chance collisions, duplicated reads -- are
+//             short: a lane per group sorts its slice of the order by whole rows (segment_sort_kernel) and flags duplicates as
+//             final; only groups of more than 32 rows go on to round 1, which sorts (tie segment, rest of chunk 0) as one key;
 //   round k   only rows that still tie with a neighbour ("active") are touched: they are compacted,
 //             sorted by chunk k, then stably regrouped by their tie-segment id, and written back into
 //             the slots their segment occupies.  Distinct rows drop out as soon as a chunk separates
