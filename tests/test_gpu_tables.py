@@ -305,3 +305,37 @@ def test_decode_fastq_is_the_input_and_the_two_pass_text(ctx, name, n, length, k
         rd2 = rd.copy(); rd2[7, :] = 0
         text, bad = ops.decode_fastq(ctx, cfg, cols, _dev(ctx, rd2.ravel()), qual, n)
         assert text is None and bad == 7
+
+
+@pytest.mark.parametrize('with_n', [False, True], ids=['acgt', 'n-trick'])
+@pytest.mark.parametrize('nq', [3, 4, 6, 12, 20, 41, 70], ids=lambda v: 'q%d' % v)
+def test_decode_fixed_length_quality_widths(ctx, nq, with_n):
+    """Fixed-length tables with the lookup-free alphabet at every quality width (2 .. 7 bits): uq_decode_fastq runs the instance of
+    the tile kernel compiled for that width and N-trick (2 .. 6 bits) or the run-time one (7), several tiles, a ragged last one."""
+    from uq_amd import qname
+    rng = np.random.default_rng(nq * 2 + with_n)
+    n, L = 3001, 151
+    recs = []
+    for i in range(n):
+        seq = rng.choice(np.frombuffer(b'ACGT', np.uint8), L)
+        q = rng.integers(40, 40 + nq, L).astype(np.uint8)
+        if with_n:
+            at = rng.random(L) < 0.02
+            seq[at] = ord('N'); q[at] = 35
+        recs.append(b'@x%d:%d/1\n' % (i, int(rng.integers(0, 99999))) + bytes(seq) + b'\n+\n' + bytes(q) + b'\n')
+    host = np.frombuffer(b''.join(recs), dtype=np.uint8)
+    hls = oracle_c.index_lines(host)
+    st = oracle_c.stats(host, hls, 0, n)
+    d = O.decide(O.histogram_to_static_qualities(st['counts'], st['first_seen']), st['len_min'], st['len_max'])
+    assert d['bits_per_base'] == 2 and not d['variable_read_lengths'] and bool(d['N_qual']) == with_n
+    rd, rq, _ = oracle_c.pack(host, hls, 0, n, d['bases'], d['qualities'], d['N_qual'], d['bits_per_base'], d['bits_per_quality'],
+                              d['variable_read_lengths'], d['dna_bytes_per_row'], d['quality_bytes_per_row'])
+    prefix, suffix, separators, columns, arrays = qname.analyse(qname.qname_lines(host, hls, n))
+    cfg = dict(bases=d['bases'], qualities=d['qualities'], N_qual=d['N_qual'], bits_per_base=d['bits_per_base'],
+               bits_per_quality=d['bits_per_quality'], variable_read_lengths=d['variable_read_lengths'], dna_max=d['dna_max'],
+               QNAME_prefix=prefix, QNAME_suffix=suffix, QNAME_separators=separators, QNAME_columns=columns)
+    cols = [_dev(ctx, np.ascontiguousarray(a)) for a in arrays]
+    ops.scribble_lds(ctx, 0x5A5A5A5A)
+    text, bad = ops.decode_fastq(ctx, cfg, cols, _dev(ctx, rd.ravel()), _dev(ctx, rq.ravel()), n)
+    assert bad is None
+    assert ctx.to_numpy(text).tobytes() == host.tobytes()
