@@ -569,14 +569,16 @@ struct StreamGeom {
     FastAlphabet fa;
 };
 
-// the eight characters of group t0 / 8 (t0 = index from the end of the read of the group's LAST character)
+// the eight characters of group t0 / 8 (t0 = index from the end of the read of the group's LAST character); BQ / HASN as in emit_tile_kernel
+template <int BQ, bool HASN>
 __device__ __forceinline__ void group_text(const uint8_t* tile, const StreamGeom& sg2, uint32_t endd, uint32_t endq, int32_t t0, uint64_t& vb, uint64_t& vq) {
     const FastAlphabet& fa = sg2.fa;
     uint32_t clo, chi, qlo, qhi;
     dna_codes8(tile, endd, t0, clo, chi);
-    qual_codes8(sg2.bq, tile, endq, t0, qlo, qhi);
+    if constexpr (BQ != 0) qual_codes8<BQ>(tile, endq, t0, qlo, qhi);
+    else qual_codes8(sg2.bq, tile, endq, t0, qlo, qhi);
     uint32_t blo = __builtin_amdgcn_perm(0u, fa.base_tab, clo), bhi = __builtin_amdgcn_perm(0u, fa.base_tab, chi);
-    if (fa.has_n) {
+    if (BQ ? HASN : fa.has_n != 0) {
         const uint32_t mlo = ~nonzero_bytes(qlo ^ fa.n_code4), mhi = ~nonzero_bytes(qhi ^ fa.n_code4);
         blo = bfi(mlo, fa.n_char4, blo); bhi = bfi(mhi, fa.n_char4, bhi);
     }
@@ -592,6 +594,7 @@ __device__ __forceinline__ void store_low_bytes(uint8_t* p, uint64_t v, uint32_t
     if (nb & 1u) *p = (uint8_t)v;
 }
 
+template <int BQ = 0, bool HASN = false>
 __global__ __launch_bounds__(EM_THREADS, 4) void decode_stream_kernel(EmitGeom g, StreamGeom tg, const uint8_t* __restrict__ dna, const uint8_t* __restrict__ qual,
                                                                    const uint32_t* __restrict__ len, uint64_t n, const uint64_t* __restrict__ offsets,
                                                                    uint8_t* __restrict__ out) {
@@ -741,7 +744,7 @@ __global__ __launch_bounds__(EM_THREADS, 4) void decode_stream_kernel(EmitGeom g
                 for (int it = 0; it < 6; ++it) { const uint32_t mid = (r + hi) >> 1; if (cum[mid] <= item) r = mid; else hi = mid; }
                 const uint32_t wg = cum[r + 1] - 1 - item, L = s_len[r];     // addresses rise with the lane
                 uint64_t vb, vq;
-                group_text(tile, tg, od + __umul24(r, tg.Cd), oq + __umul24(r, tg.Cq), (int32_t)(8 * wg), vb, vq);
+                group_text<BQ, HASN>(tile, tg, od + __umul24(r, tg.Cd), oq + __umul24(r, tg.Cq), (int32_t)(8 * wg), vb, vq);
                 uint8_t* ts = out + s_off[r + 1] - (L + 8 * wg + 12);    // line start = record end - 2 L - 4, the group at + L - 8 wg - 8
                 __builtin_memcpy(ts, &vb, 8);
                 __builtin_memcpy(ts + L + 3, &vq, 8);
@@ -753,7 +756,7 @@ __global__ __launch_bounds__(EM_THREADS, 4) void decode_stream_kernel(EmitGeom g
             uint32_t ed = od + my_slot * tg.Cd, eq = oq + my_slot * tg.Cq;
             for (uint32_t r = my_slot; r < Rt; r += tg.RS, ed += tg.RS * tg.Cd, eq += tg.RS * tg.Cq) {
                 uint64_t vb, vq;
-                group_text(tile, tg, ed, eq, (int32_t)(8 * my_wg), vb, vq);
+                group_text<BQ, HASN>(tile, tg, ed, eq, (int32_t)(8 * my_wg), vb, vq);
                 uint8_t* ts = out + s_off[r + 1] - back;
                 __builtin_memcpy(ts, &vb, 8);
                 __builtin_memcpy(ts + L + 3, &vq, 8);
@@ -767,7 +770,7 @@ __global__ __launch_bounds__(EM_THREADS, 4) void decode_stream_kernel(EmitGeom g
             uint8_t* tq = ts + L + 3;
             if (nsym) {
                 uint64_t vb, vq;
-                group_text(tile, tg, od + __umul24(i, tg.Cd), oq + __umul24(i, tg.Cq), (int32_t)(L & ~7u), vb, vq);
+                group_text<BQ, HASN>(tile, tg, od + __umul24(i, tg.Cd), oq + __umul24(i, tg.Cq), (int32_t)(L & ~7u), vb, vq);
                 const uint32_t drop = 8u * (8u - nsym);                  // characters 0 .. nsym - 1 = the last nsym bytes of the eight
                 store_low_bytes(ts, vb >> drop, nsym);
                 store_low_bytes(tq, vq >> drop, nsym);
@@ -1030,7 +1033,16 @@ extern "C" int uq_decode_fastq(uq_ctx* ctx, const uq_emit_params* hp, const uq_u
         const size_t lds = plan_stream(sg, g, up, tg.fa);
         if (lds) {
             const uint64_t tiles = (nreads + sg.R - 1) / sg.R;
-            decode_stream_kernel<<<tile_blocks(tiles, lds, 4), EM_THREADS, lds, ctx->stream>>>(g, sg, d_dna, d_qual, lens, nreads, d_offsets, d_out);
+            const uint32_t tb = tile_blocks(tiles, lds, 4);
+#define UQ_STREAM_CASE(Q) \
+            case Q: if (sg.fa.has_n) decode_stream_kernel<Q, true><<<tb, EM_THREADS, lds, ctx->stream>>>(g, sg, d_dna, d_qual, lens, nreads, d_offsets, d_out); \
+                    else decode_stream_kernel<Q, false><<<tb, EM_THREADS, lds, ctx->stream>>>(g, sg, d_dna, d_qual, lens, nreads, d_offsets, d_out); \
+                    break;
+            switch (sg.bq) {
+                UQ_STREAM_CASE(2) UQ_STREAM_CASE(3) UQ_STREAM_CASE(4) UQ_STREAM_CASE(5) UQ_STREAM_CASE(6)
+                default: decode_stream_kernel<><<<tb, EM_THREADS, lds, ctx->stream>>>(g, sg, d_dna, d_qual, lens, nreads, d_offsets, d_out);
+            }
+#undef UQ_STREAM_CASE
             UQ_LAUNCH_CHECK();
             return 0;
         }
