@@ -11,8 +11,11 @@ size_t radix_ws_bytes(uint64_t n);
 int radix_sort_pairs(uq_ctx* ctx, uint64_t* keys, uint32_t* vals, uint64_t* keys_alt, uint32_t* vals_alt,
                      uint64_t n, int begin_bit, int end_bit, void* ws, int* in_alt);
 // The same with 32-bit keys: 8 bytes a pair instead of 12, four digit positions instead of eight.
-// h_hist: the digit census of the keys (radix_census32: h_hist[p * 256 + d] = keys whose byte p is d) when the caller has
-// taken it already, else NULL.
+// h_hist: the digit census of the keys (h_hist[p * 256 + d] = keys whose byte p is d) when the caller has taken it already
+// (radix_prefix_census32), else NULL.
+// digit0_counted: the per-tile counts of the lowest digit are in `ws` already (radix_prefix_census32 left them there).
 int radix_sort_pairs32(uq_ctx* ctx, uint32_t* keys, uint32_t* vals, uint32_t* keys_alt, uint32_t* vals_alt,
-                       uint64_t n, int begin_bit, int end_bit, void* ws, int* in_alt, const uint32_t* h_hist);
-int radix_census32(uq_ctx* ctx, const uint32_t* keys, uint64_t n, void* ws, uint32_t* h_hist);
+                       uint64_t n, int begin_bit, int end_bit, void* ws, int* in_alt, const uint32_t* h_hist, int digit0_counted);
+// keys[i] = the 32 bits of keys64[i] behind its z leading bits, vals[i] = i, h_hist = the census of the new keys,
+// and the first pass's per-tile counts left in `ws`: one pass over keys64.
+int radix_prefix_census32(uq_ctx* ctx, const uint64_t* keys64, uint64_t n, uint32_t z, uint32_t* keys, uint32_t* vals, void* ws, uint32_t* h_hist);

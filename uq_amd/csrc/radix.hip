@@ -39,6 +39,41 @@ __global__ __launch_bounds__(RS_THREADS) void rs_census_kernel(const K* __restri
         if (h[i]) atomicAdd(&ghist[i], h[i]);
 }
 
+// What the row sort does before its 32-bit round 0, in one pass over the 64-bit chunk values: keys[i] = the 32 bits behind the z
+// leading bits, vals[i] = i, the census of all four digits of the new keys, and the per-tile histograms of their lowest digit --
+// what the first pass's rs_count would read the keys again for.  Workgroups walk tiles of the sort's own size.
+__global__ __launch_bounds__(RS_THREADS) void rs_prefix_census_kernel(const uint64_t* __restrict__ keys64, uint64_t n, uint32_t z, uint32_t* __restrict__ keys,
+                                                                      uint32_t* __restrict__ vals, uint32_t nb, uint32_t* __restrict__ ghist,
+                                                                      uint32_t* __restrict__ block_hist) {
+    constexpr int ITEMS = RsGeom<uint32_t>::ITEMS, TILE = RsGeom<uint32_t>::TILE;
+    __shared__ uint32_t h[4 * 256];          // this workgroup's census; digit 0 is added a tile at a time from h0
+    __shared__ uint32_t h0[256];             // digit 0 of the tile in hand (bin tid belongs to lane tid outside the counting phase)
+    const uint32_t tid = threadIdx.x;
+    for (int i = tid; i < 4 * 256; i += RS_THREADS) h[i] = 0;
+    for (uint32_t tile = blockIdx.x; tile < nb; tile += gridDim.x) {
+        h0[tid] = 0;
+        __syncthreads();
+        const uint64_t base = (uint64_t)tile * TILE;
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const uint64_t idx = base + (uint64_t)i * RS_THREADS + tid;
+            if (idx < n) {
+                const uint32_t k = (uint32_t)((keys64[idx] << z) >> 32);
+                keys[idx] = k; vals[idx] = (uint32_t)idx;
+                atomicAdd(&h0[k & 255u], 1u);
+                atomicAdd(&h[256 + ((k >> 8) & 255u)], 1u); atomicAdd(&h[512 + ((k >> 16) & 255u)], 1u); atomicAdd(&h[768 + (k >> 24)], 1u);
+            }
+        }
+        __syncthreads();
+        const uint32_t c = h0[tid];
+        block_hist[(uint64_t)tid * nb + tile] = c;
+        h[tid] += c;
+    }
+    __syncthreads();
+    for (int i = tid; i < 4 * 256; i += RS_THREADS)
+        if (h[i]) atomicAdd(&ghist[i], h[i]);
+}
+
 template <typename K>
 __global__ __launch_bounds__(RS_THREADS) void rs_count_kernel(const K* __restrict__ keys, uint64_t n, int shift,
                                                               uint32_t nb, uint32_t* __restrict__ block_hist) {
@@ -149,7 +184,7 @@ size_t radix_ws_bytes(uint64_t n) {
 
 template <typename K>
 static int radix_sort_impl(uq_ctx* ctx, K* keys, uint32_t* vals, K* keys_alt, uint32_t* vals_alt,
-                           uint64_t n, int begin_bit, int end_bit, void* ws, int* in_alt, const uint32_t* h_hist_in) {
+                           uint64_t n, int begin_bit, int end_bit, void* ws, int* in_alt, const uint32_t* h_hist_in, bool digit0_counted = false) {
     constexpr int ND = RsGeom<K>::DIGITS, TILE = RsGeom<K>::TILE;
     *in_alt = 0;
     if (n <= 1 || end_bit <= begin_bit) return 0;
@@ -174,8 +209,10 @@ static int radix_sort_impl(uq_ctx* ctx, K* keys, uint32_t* vals, K* keys_alt, ui
         for (int d = 0; d < 256; ++d)
             if (h_hist[p * 256 + d] == n) { trivial = true; break; }
         if (trivial) continue;
-        rs_count_kernel<K><<<nb, RS_THREADS, 0, ctx->stream>>>(kin, n, 8 * p, nb, block_hist);
-        UQ_LAUNCH_CHECK();
+        if (!(digit0_counted && p == 0)) {               // (digit 0's per-tile counts came with the census: radix_prefix_census32)
+            rs_count_kernel<K><<<nb, RS_THREADS, 0, ctx->stream>>>(kin, n, 8 * p, nb, block_hist);
+            UQ_LAUNCH_CHECK();
+        }
         UQ_TRY(uq_scan_exclusive_u32(ctx, block_hist, block_hist, (uint64_t)256 * nb, nullptr));
         rs_scatter_kernel<K><<<nb, RS_THREADS, 0, ctx->stream>>>(kin, vin, kout, vout, n, 8 * p, nb, block_hist);
         UQ_LAUNCH_CHECK();
@@ -192,15 +229,16 @@ int radix_sort_pairs(uq_ctx* ctx, uint64_t* keys, uint32_t* vals, uint64_t* keys
 }
 
 int radix_sort_pairs32(uq_ctx* ctx, uint32_t* keys, uint32_t* vals, uint32_t* keys_alt, uint32_t* vals_alt,
-                       uint64_t n, int begin_bit, int end_bit, void* ws, int* in_alt, const uint32_t* h_hist) {
-    return radix_sort_impl<uint32_t>(ctx, keys, vals, keys_alt, vals_alt, n, begin_bit, end_bit, ws, in_alt, h_hist);
+                       uint64_t n, int begin_bit, int end_bit, void* ws, int* in_alt, const uint32_t* h_hist, int digit0_counted) {
+    return radix_sort_impl<uint32_t>(ctx, keys, vals, keys_alt, vals_alt, n, begin_bit, end_bit, ws, in_alt, h_hist, digit0_counted != 0 && begin_bit == 0);
 }
 
-int radix_census32(uq_ctx* ctx, const uint32_t* keys, uint64_t n, void* ws, uint32_t* h_hist) {
+int radix_prefix_census32(uq_ctx* ctx, const uint64_t* keys64, uint64_t n, uint32_t z, uint32_t* keys, uint32_t* vals, void* ws, uint32_t* h_hist) {
     uint32_t* ghist = (uint32_t*)ws;
+    uint32_t* block_hist = ghist + 8 * 256 + 64;                      // where radix_sort_impl keeps its per-tile counts
     UQ_CHECK_HIP(hipMemsetAsync(ghist, 0, 4 * 256 * 4, ctx->stream));
-    const uint64_t nb = (n + RsGeom<uint32_t>::TILE - 1) / RsGeom<uint32_t>::TILE;
-    rs_census_kernel<uint32_t><<<(uint32_t)(nb < 2048 ? (nb ? nb : 1) : 2048), RS_THREADS, 0, ctx->stream>>>(keys, n, ghist);
+    const uint32_t nb = (uint32_t)((n + RsGeom<uint32_t>::TILE - 1) / RsGeom<uint32_t>::TILE);
+    rs_prefix_census_kernel<<<nb < 2048 ? (nb ? nb : 1) : 2048, RS_THREADS, 0, ctx->stream>>>(keys64, n, z, keys, vals, nb, ghist, block_hist);
     UQ_LAUNCH_CHECK();
     UQ_CHECK_HIP(hipMemcpyAsync(h_hist, ghist, 4 * 256 * 4, hipMemcpyDeviceToHost, ctx->stream));
     UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(ST) void extract_all_kernel(const uint8_t* __restri
     if (i < n) {
         const uint64_t k = load_chunk_be(table + i * C, C, 0);
         keys[i] = k;
-        vals[i] = (uint32_t)i;
+        if (vals) vals[i] = (uint32_t)i;                 // (the 32-bit round 0 numbers the rows itself)
         a = o = k;
     }
     if (andor) {      // per-workgroup partials (780 000 waves x 2 atomics on one word were 19 ms), folded by and_or_fold_kernel
@@ -71,12 +71,9 @@ __global__ __launch_bounds__(ST) void and_or_fold_kernel(const unsigned long lon
         atomicAnd(out, a); atomicOr(out + 1, o);
     }
 }
-// the 32 bits of chunk 0 behind its z constant leading bits
-__global__ void prefix32_kernel(const uint64_t* __restrict__ keys, uint64_t n, uint32_t z, uint32_t* __restrict__ k32, uint32_t* __restrict__ vals) {
-    uint64_t i = (uint64_t)blockIdx.x * ST + threadIdx.x;
-    if (i >= n) return;
-    k32[i] = (uint32_t)((keys[i] << z) >> 32);
-    vals[i] = (uint32_t)i;
+__global__ void iota_kernel(uint32_t* __restrict__ v, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * ST + threadIdx.x;
+    if (i < n) v[i] = (uint32_t)i;
 }
 __global__ void heads_first32_kernel(const uint32_t* __restrict__ keys, uint64_t n, uint8_t* __restrict__ heads) {
     uint64_t j = (uint64_t)blockIdx.x * ST + threadIdx.x;
@@ -307,7 +304,8 @@ int sort_rows_core(uq_ctx* ctx, const uint8_t* table, uint64_t n, uint32_t C, ui
     // ---- round 0: all rows by (a prefix of) chunk 0
     bool mode32 = C > 8 && n >= (1u << 16);
     unsigned long long* part = (unsigned long long*)keysB;                      // free until the sort: 16 B per workgroup
-    extract_all_kernel<<<blocks_for(n), ST, 0, s>>>(table, n, C, keysA, valsA, mode32 ? part : nullptr);
+    const bool numbered = !mode32;
+    extract_all_kernel<<<blocks_for(n), ST, 0, s>>>(table, n, C, keysA, mode32 ? nullptr : valsA, mode32 ? part : nullptr);
     UQ_LAUNCH_CHECK();
     if (mode32) {
         UQ_CHECK_HIP(hipMemsetAsync(tot + 4, 0xFF, 8, s));
@@ -333,10 +331,10 @@ int sort_rows_core(uq_ctx* ctx, const uint8_t* table, uint64_t n, uint32_t C, ui
     if (mode32) {
         uint32_t* k32a = (uint32_t*)keysB;                                      // keysB's n * 8 bytes hold both u32 key buffers
         uint32_t* k32b = k32a + n;
-        prefix32_kernel<<<blocks_for(n), ST, 0, s>>>(keysA, n, z, k32a, d_perm);     // d_perm is the sort's value buffer: an even number of passes ends there
-        UQ_LAUNCH_CHECK();
         static thread_local uint32_t h_hist[4 * 256];
-        UQ_TRY(radix_census32(ctx, k32a, n, rws, h_hist));
+        // keys, values (d_perm is the sort's value buffer: an even number of passes ends there), digit census and the first pass's
+        // per-tile counts in one pass over the chunk values
+        UQ_TRY(radix_prefix_census32(ctx, keysA, n, z, k32a, d_perm, rws, h_hist));
         // expected share of rows that tie on the prefix if its bytes were independent: n * prod_p sum_d (h[p][d] / n)^2
         double coll = (double)n;
         for (int p = 0; p < 4; ++p) {
@@ -346,7 +344,7 @@ int sort_rows_core(uq_ctx* ctx, const uint8_t* table, uint64_t n, uint32_t C, ui
         }
         if (coll > 0.3) mode32 = false;
         else {
-            UQ_TRY(radix_sort_pairs32(ctx, k32a, d_perm, k32b, valsB, n, 0, 32, rws, &alt, h_hist));
+            UQ_TRY(radix_sort_pairs32(ctx, k32a, d_perm, k32b, valsB, n, 0, 32, rws, &alt, h_hist, 1));
             if (alt) UQ_CHECK_HIP(hipMemcpyAsync(d_perm, valsB, n * 4, hipMemcpyDeviceToDevice, s));
             heads_first32_kernel<<<blocks_for(n), ST, 0, s>>>(alt ? k32b : k32a, n, heads);
             UQ_LAUNCH_CHECK();
@@ -370,6 +368,7 @@ int sort_rows_core(uq_ctx* ctx, const uint8_t* table, uint64_t n, uint32_t C, ui
         }
     }
     if (!mode32) {
+        if (!numbered) { iota_kernel<<<blocks_for(n), ST, 0, s>>>(valsA, n); UQ_LAUNCH_CHECK(); }
         UQ_TRY(radix_sort_pairs(ctx, keysA, valsA, keysB, valsB, n, 0, 64, rws, &alt));
         const uint64_t* K = alt ? keysB : keysA;
         const uint32_t* V = alt ? valsB : valsA;
