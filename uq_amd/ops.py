@@ -212,7 +212,9 @@ def head_guess(ctx, buf, notricks=False, pad=False, head_bytes=None, head_reads=
         return None
     d = analysis.decide_from_counts(hs.counts, hs.len_min, hs.len_max, notricks=notricks, pad=pad)
     if d['N_qual'] and max(d['N_qual'].values()) >= len(d['qualities']): return None       # Q9 new-code files: exact kernel only
-    span = int(ls[4 * n].item())
+    # bytes of the n reads, from the head's own byte and line counts (a read-back of ls[4 n] through torch would queue behind
+    # whatever runs on torch's stream -- the caller's census of the whole file -- and hold the host until that is done)
+    span = max(int(head.numel() * (4 * n) // max(nl, 1)), 4 * n)
     p = make_pack_params(d['bases'], d['qualities'], d['N_qual'], d['bits_per_base'], d['bits_per_quality'], d['variable_read_lengths'],
                          d['dna_bytes_per_row'], d['quality_bytes_per_row'], d['dna_max'], hs.max_record_bytes, avg_record_bytes=span // n)
     return p, n / span
