@@ -37,9 +37,12 @@ SEED = 20261003 + 2
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
+STATS_RESERVED_OFFSET = 65536 * 8 + 8 + 8 + 4 + 4 + 4      # byte offset of uq_stats.reserved (include/uqhip.h)
+
+
 def host_decide(hs, notricks=False, pad=False):
     from uq_amd import analysis
-    return analysis.decide_from_counts(hs.counts, hs.len_min, hs.len_max, notricks=notricks, pad=pad)
+    return analysis.decide_from_stats(hs, notricks=notricks, pad=pad)
 
 
 def cpu_baseline(sample_bytes, n_sample, d):
@@ -172,15 +175,28 @@ def main():
         spec = None
         guess = None
         census = None
+        queued = None
+        st = None
         if not args.one_pass and not args.multi_pass:
-            # the census kernel is queued first; the guess (census / index / statistics of the shard's first 4 MB: small kernels,
-            # a read-back, the decisions on the host) runs meanwhile on a second stream and is ready when the census is
+            # the census kernel is queued first, its closing scan right behind it (the line count stays on the device); the guess
+            # (census / index / statistics of the shard's first 4 MB: small kernels, a read-back, the decisions on the host) runs
+            # meanwhile on a second stream; the record index and the pack + statistics kernel are then queued behind the census
+            # with the count taken on the device -- the host reads it after everything has been queued (no mid-step round trip)
             census = ops.ChunkedCensus(ctx, d_buf)
             census.chunk(0, fastq_bytes)
+            census.end_async()
             g = ops.head_guess(side, d_buf, notricks=notricks, head_bytes=ops.HEAD_BYTES_SMALL, head_reads=ops.HEAD_READS_INDEXED)
             if g is not None:
-                guess = g[0]
-                guess.avg_record_bytes = 0                      # set below from the shard's own census
+                guess, rpb = g
+                cap_reads = int(fastq_bytes * rpb * 1.02) + 1024
+                guess.avg_record_bytes = int(1.0 / rpb)                     # tile sizing hint: the head's own records
+                ls_cap = ops.index_lines_async(ctx, d_buf, 4 * cap_reads)
+                e0.record()
+                sp = ops.pack_stats_async(ctx, d_buf, ls_cap, cap_reads, guess)
+                e1.record()
+                if sp is not None:
+                    # one rank: the statistics' read-back is queued (and waited for) first, the line count is there by then
+                    queued = (ls_cap, sp, None if use_dist else fetch(sp[3]))
         if args.one_pass:
             # ONE read of the stream (uq_encode_stream): census + record index + pass-1 statistics + pack with decisions guessed
             # from the head of this shard (its first 65536 reads, statistics pass of their own -- part of the step), verified
@@ -191,32 +207,38 @@ def main():
                 e0.record()
                 enc = ops.encode_stream(ctx, d_buf, guess, int(fastq_bytes * rpb * 1.02) + 1024)
                 e1.record()
-        if enc is not None and enc.line_start is not None:
-            nlines, ls = enc.nlines, enc.line_start
-        else:
-            nlines = enc.nlines if enc is not None else (census.end() if census is not None else ops.count_lines(ctx, d_buf))
-            ls = ops.index_lines(ctx, d_buf, nlines)              # record index
-            enc = None
-        nreads = nlines // 4
-        if enc is not None and enc.stats is not None:
-            st = enc.stats
-        elif not args.one_pass and not args.multi_pass:
-            # the default: TWO reads of the stream.  The pack kernel counts the statistics (uq_pack_stats) while it packs with
-            # decisions guessed from the shard's first 8192 reads (taken on the side stream while the census ran, above)
-            if guess is not None:
-                guess.avg_record_bytes = fastq_bytes // max(nreads, 1)
-                e0.record()
-                spec = ops.pack_stats(ctx, d_buf, ls, 0, nreads, guess)
-                e1.record()
-            if spec is not None:
-                st = spec[3]
+        hs = None
+        if census is not None:
+            nlines, ok = census.wait()
+            good = queued is not None and ok and nlines % 4 == 0 and nlines // 4 <= cap_reads
+            if not ok: nlines = ops.count_lines(ctx, d_buf)         # a tile's newline list overflowed: the bitmap form
+            nreads = nlines // 4
+            if good:
+                ls = queued[0][:nlines + 1]
+                dq = queued[1]
+                spec = (dq[0][:nreads * guess.dna_bytes_per_row], dq[1][:nreads * guess.quality_bytes_per_row], dq[2], dq[3])
+                st = dq[3]
+            elif queued is not None:                              # the queued form does not hold for this shard: the plain index, and
+                ls = ops.index_lines(ctx, d_buf, nlines)           # statistics flagged incomplete, so that EVERY rank redoes them below
+                st = queued[1][3]
+                st[STATS_RESERVED_OFFSET] = 1
+                queued = None
+            if st is not None:
+                hs = queued[2] if (queued is not None and queued[2] is not None) else fetch(st)     # N > 1: the all-reduce of the statistics
+        if hs is None:
+            if enc is not None and enc.line_start is not None:
+                nlines, ls = enc.nlines, enc.line_start
+            else:
+                if census is None: nlines = enc.nlines if enc is not None else ops.count_lines(ctx, d_buf)
+                ls = ops.index_lines(ctx, d_buf, nlines)              # record index
+                enc = None
+            nreads = nlines // 4
+            if enc is not None and enc.stats is not None:
+                st = enc.stats
             else:
                 st = ops.stats_new(ctx)
                 ops.stats_accumulate(ctx, st, d_buf, ls, 0, nreads)
-        else:
-            st = ops.stats_new(ctx)
-            ops.stats_accumulate(ctx, st, d_buf, ls, 0, nreads)
-        hs = fetch(st)                                            # N > 1: the all-reduce of the statistics
+            hs = fetch(st)                                            # N > 1: the all-reduce of the statistics
         if hs.incomplete:                                         # the speculative pass met something outside its guess
             spec = None
             st = ops.stats_new(ctx)

@@ -64,6 +64,15 @@ int uq_index_lines(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint64_t 
 int uq_count_lines_begin(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes);
 int uq_count_lines_chunk(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint64_t first_byte, uint64_t chunk_bytes);
 int uq_count_lines_end(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint64_t* h_nlines);
+/* The same census, the record index and the fused pack + statistics pass QUEUED one behind the other, without the host round trip that
+ * `wc -l` (uq.py:85) puts between counting and reading: _end_async queues the closing scan and leaves the line count on the device,
+ * uq_index_lines_async (d_line_start holds capacity_lines + 1 entries) and uq_pack_stats_async (below) read it there, and
+ * uq_count_lines_wait hands it to the host once everything has been queued.  *h_ok = 0: more lines than capacity_lines, or a 16 KiB
+ * tile with more newlines than its list holds -- the index (and what was packed from it) is not usable, take uq_count_lines +
+ * uq_index_lines.  Between _end_async and _wait the context must not start another census. */
+int uq_count_lines_end_async(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes);
+int uq_index_lines_async(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint64_t capacity_lines, uint64_t* d_line_start);
+int uq_count_lines_wait(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint64_t* h_nlines, int* h_ok);
 
 /* ---- a1: pass-1 statistics.  Replaces uq.py:366-375, 382, 388, 415-425.
  * counts[base * 256 + qual] over every (base, quality) pair of reads [0, nreads); DNA length range;
@@ -82,6 +91,17 @@ int uq_stats_init(uq_ctx* ctx, uq_stats* d_stats);
 /* The device struct copied to the host (synchronous).  Same bytes as uq_d2h of the whole struct, but a file touches a few hundred
  * of the 65 536 counters: they travel as a short list through the context's pinned buffer instead of 512 KiB to pageable memory. */
 int uq_stats_fetch(uq_ctx* ctx, const uq_stats* d_stats, uq_stats* h_stats);
+/* The same statistics as the list of their non-zero counters (a file uses a few hundred of the 65 536): key = base * 256 + quality, in
+ * no particular order.  n > UQ_STATS_COMPACT_CAP: the list is cut short, take uq_stats_fetch.  What the host decisions of
+ * uq.py:448-545 need, without 512 KiB crossing PCIe and being cleared and copied on the host for every shard. */
+#define UQ_STATS_COMPACT_CAP 2048u
+typedef struct uq_stats_compact {
+    uint32_t n, len_min, len_max, max_record_bytes, reserved, pad;
+    uint64_t bad_plus, bad_len;
+    uint32_t key[UQ_STATS_COMPACT_CAP];
+    uint64_t count[UQ_STATS_COMPACT_CAP];
+} uq_stats_compact;
+int uq_stats_fetch_compact(uq_ctx* ctx, const uq_stats* d_stats, uq_stats_compact* h_out);
 int uq_stats_accumulate(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start,
                         uint64_t first_read, uint64_t nreads, uq_stats* d_stats);
 /* uq_count_lines AND uq_stats_accumulate in ONE read of the stream ("a census that counts"): the statistics of a tile's records
@@ -145,6 +165,11 @@ int uq_pack(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start, uin
 int uq_pack_stats(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start, uint64_t first_read,
                   uint64_t nreads, const uq_pack_params* h_guess, uint8_t* d_dna, uint8_t* d_qual, uint64_t* d_bad,
                   uq_stats* d_stats, int* h_fused);
+/* uq_pack_stats of ALL reads of the buffer behind uq_count_lines_end_async + uq_index_lines_async (above): the number of reads
+ * (lines / 4) is taken on the device; d_dna / d_qual hold capacity_reads rows -- more reads than that raise d_stats->reserved. */
+int uq_pack_stats_async(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start, uint64_t capacity_reads,
+                        const uq_pack_params* h_guess, uint8_t* d_dna, uint8_t* d_qual, uint64_t* d_bad,
+                        uq_stats* d_stats, int* h_fused);
 
 /* ---- index + a1 + a3 / a4 in ONE pass over the stream: newline census, record index, pass-1 statistics and pack.
  * Replaces, in a single read of the FASTQ, `wc -l` and the line iteration (uq.py:85, 132-137), the pass-1 loop

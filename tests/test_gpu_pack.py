@@ -534,3 +534,50 @@ def test_census_that_counts_knows_what_it_cannot_vouch_for(ctx):
         big = t.empty(src.numel() + 64, dtype=t.uint8, device=ctx.device).fill_(10)
         big[off:off + src.numel()] = src
         _census_stats_check(ctx, big[off:off + src.numel()], True)
+
+
+@pytest.mark.parametrize('length,kw', [(150, {}), ((36, 301), dict(n_rate=1)), (100, dict(n_rate=2))], ids=['fixed150', 'var-ntrick', 'fixed100-ntrick'])
+def test_queued_census_index_pack_equals_the_plain_calls(ctx, length, kw):
+    """uq_count_lines_end_async + uq_index_lines_async + uq_pack_stats_async (line count taken on the device, nothing waits for the
+    host in between) against uq_count_lines + uq_index_lines + uq_pack_stats: same count, same index, same tables, same statistics;
+    a capacity that is too small and a buffer that is not the census's are refused the documented way."""
+    from uq_amd import analysis, synth
+    t = ctx.torch
+    n = 50_000
+    d_buf = ops.synth_fastq(ctx, synth.Spec(20261004, length, **kw), 0, n)
+    nl = ops.count_lines(ctx, d_buf); ls = ops.index_lines(ctx, d_buf, nl)
+    guess = ops.head_guess_indexed(ctx, d_buf, ls, n)
+    ref = ops.pack_stats(ctx, d_buf, ls, 0, n, guess)
+    assert ref is not None
+    hs_ref = ops.stats_fetch(ctx, ref[3])
+    for chunks in (1, 3):
+        cen = ops.ChunkedCensus(ctx, d_buf)
+        step = ((d_buf.numel() // chunks) // 16384 + 1) * 16384
+        for lo in range(0, d_buf.numel(), step): cen.chunk(lo, min(step, d_buf.numel() - lo))
+        cen.end_async()
+        cap = n + 1000
+        ls2 = ops.index_lines_async(ctx, d_buf, 4 * cap)
+        got = ops.pack_stats_async(ctx, d_buf, ls2, cap, guess)
+        assert got is not None
+        hs = ops.stats_fetch(ctx, got[3])
+        nl2, ok = cen.wait()
+        assert ok and nl2 == nl
+        assert t.equal(ls2[:nl + 1], ls)
+        assert t.equal(got[0][:n * guess.dna_bytes_per_row], ref[0]) and t.equal(got[1][:n * guess.quality_bytes_per_row], ref[1])
+        assert not hs.incomplete and np.array_equal(hs.counts, hs_ref.counts)
+        assert (hs.len_min, hs.len_max, hs.max_record_bytes) == (hs_ref.len_min, hs_ref.len_max, hs_ref.max_record_bytes)
+    # tables / index too small for the file: flagged, nothing written beyond them
+    cen = ops.ChunkedCensus(ctx, d_buf); cen.chunk(0, d_buf.numel()); cen.end_async()
+    cap = n // 2
+    ls3 = ops.index_lines_async(ctx, d_buf, 4 * cap)
+    got = ops.pack_stats_async(ctx, d_buf, ls3, cap, guess)
+    hs = ops.stats_fetch(ctx, got[3])
+    nl3, ok = cen.wait()
+    assert nl3 == nl and not ok and hs.incomplete
+    assert t.equal(ls3[:4 * cap + 1], ls[:4 * cap + 1])
+    # the queued calls belong to the census that was closed last
+    other = ops.synth_fastq(ctx, synth.Spec(5, 50), 0, 100)
+    cen = ops.ChunkedCensus(ctx, d_buf); cen.chunk(0, d_buf.numel()); cen.end_async()
+    with pytest.raises(Exception):
+        ops.index_lines_async(ctx, other, 1000)
+    assert cen.wait()[0] == nl

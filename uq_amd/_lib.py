@@ -83,9 +83,13 @@ SIGNATURES = {
     'uq_count_lines_begin': [_vp, _vp, _u64],
     'uq_count_lines_chunk': [_vp, _vp, _u64, _u64, _u64],
     'uq_count_lines_end': [_vp, _vp, _u64, _P(_u64)],
+    'uq_count_lines_end_async': [_vp, _vp, _u64],
+    'uq_index_lines_async': [_vp, _vp, _u64, _u64, _vp],
+    'uq_count_lines_wait': [_vp, _vp, _u64, _P(_u64), _P(_int)],
     'uq_index_lines': [_vp, _vp, _u64, _u64, _vp],
     'uq_stats_init': [_vp, _vp],
     'uq_stats_fetch': [_vp, _vp, _vp],
+    'uq_stats_fetch_compact': [_vp, _vp, _vp],
     'uq_stats_accumulate': [_vp, _vp, _vp, _u64, _u64, _vp],
     'uq_stats_export': [_vp, _vp, _u32, _u32, _u64, _vp],
     'uq_stats_import': [_vp, _vp, _u32, _vp],
@@ -93,6 +97,7 @@ SIGNATURES = {
     'uq_first_occurrence': [_vp, _vp, _vp, _u64, _u64, _u64, _vp],
     'uq_pack': [_vp, _vp, _vp, _u64, _u64, _P(PackParams), _vp, _vp, _vp],
     'uq_pack_stats': [_vp, _vp, _vp, _u64, _u64, _P(PackParams), _vp, _vp, _vp, _vp, _P(_int)],
+    'uq_pack_stats_async': [_vp, _vp, _vp, _u64, _P(PackParams), _vp, _vp, _vp, _vp, _P(_int)],
     'uq_encode_stream': [_vp, _vp, _u64, _P(PackParams), _u64, _vp, _vp, _vp, _vp, _P(EncodeResult)],
     'uq_pattern': [_vp, _vp, _u64, _u32, _int, _vp],
     'uq_unpattern': [_vp, _vp, _u64, _u32, _int, _vp],

@@ -1,5 +1,5 @@
 """Host-side decisions between pass 1 and pass 3: alphabets, the N-trick, bit
-widths and row bytes, from the 256 x 256 (base, quality) count matrix the device produced.
+widths and row bytes, from the 256 x 256 (base, quality) count matrix the device produced -- or from the list of its non-zero entries.
 
 Mirrors uq.py:448-457 (alphabets, ASCII-sorted), 477-494 (N-trick), 497-516 and 534-545 (widths and
 bytes per row).  Negligible work (<= 65536 counters), so it stays on the host like the reference's.
@@ -25,43 +25,63 @@ def decide_from_counts(counts, len_min, len_max, notricks=False, pad=False, firs
     first occurrence; it orders the N-trick candidates the way the reference's dict iteration does
     (uq.py:480 under pypy / py3: first appearance).  Only consulted when two or more bases qualify.
     """
-    counts = np.asarray(counts).reshape(256, 256)
-    base_tot = counts.sum(axis=1)
-    dna_bases = np.flatnonzero(base_tot).tolist()                 # uq.py:456 sorted(keys)
-    if not dna_bases:
+    flat = np.asarray(counts).reshape(65536)
+    keys = np.flatnonzero(flat)
+    return decide_from_pairs(keys, flat[keys], len_min, len_max, notricks=notricks, pad=pad, first_seen=first_seen)
+
+
+def decide_from_stats(hs, notricks=False, pad=False, first_seen=None):
+    """The same from a HostStats (ops.stats_fetch): its list of non-zero counters when it holds one, else its dense table."""
+    if getattr(hs, 'nz_keys', None) is not None:
+        return decide_from_pairs(hs.nz_keys, hs.nz_counts, hs.len_min, hs.len_max, notricks=notricks, pad=pad, first_seen=first_seen)
+    return decide_from_counts(hs.counts, hs.len_min, hs.len_max, notricks=notricks, pad=pad, first_seen=first_seen)
+
+
+def decide_from_pairs(keys, cnts, len_min, len_max, notricks=False, pad=False, first_seen=None):
+    """The decisions from the NON-ZERO counters alone: keys = base * 256 + quality (any order), cnts their counts.  A file uses a
+    few hundred of the 65 536 counters; everything below is arithmetic on that list."""
+    keys = np.asarray(keys, dtype=np.int64); cnts = np.asarray(cnts, dtype=np.int64)
+    live = cnts != 0
+    if not live.all(): keys, cnts = keys[live], cnts[live]
+    if keys.size == 0:
         raise ValueError('no bases counted')
-    live = counts[dna_bases]                                      # the few rows that hold anything
-    qual_tot = live.sum(axis=0)
+    order = np.argsort(keys, kind='stable')
+    keys, cnts = keys[order], cnts[order]
+    b, q = keys >> 8, keys & 255
+    # sums of at most 2^53 (a float64 holds them exactly: 9 * 10^15 symbols), far beyond a file
+    base_tot = np.bincount(b, weights=cnts, minlength=256).astype(np.int64); qual_tot = np.bincount(q, weights=cnts, minlength=256).astype(np.int64)
+    dna_bases = np.flatnonzero(base_tot).tolist()                 # uq.py:456 sorted(keys)
     quals = np.flatnonzero(qual_tot).tolist()                     # uq.py:457
     all_bases = list(dna_bases)
     N_qual = {}
     total_quals = len(quals)
     if not notricks:                                              # uq.py:479-494
-        nq = (live != 0).sum(axis=1)
-        cand = [b for b, k in zip(dna_bases, nq.tolist()) if k == 1]
+        nq = np.bincount(b, minlength=256)                        # distinct qualities a base occurs with
+        cand = [x for x in dna_bases if nq[x] == 1]
         if len(cand) > 1:
             fs = first_seen() if callable(first_seen) else first_seen
             if fs is not None:
-                cand.sort(key=lambda b: int(fs[b]))
-        for b in cand:
+                cand.sort(key=lambda x: int(fs[x]))
+        for x in cand:
             if len(dna_bases) == 1: continue
-            dna_bases.remove(b)
-            q = int(np.nonzero(counts[b])[0][0])
-            if counts[b][q] == qual_tot[q]:
-                N_qual[chr(b)] = quals.index(q)
+            dna_bases.remove(x)
+            at = int(np.searchsorted(b, x))                       # the base's one entry (keys are sorted: base-major)
+            qq, c = int(q[at]), int(cnts[at])
+            if c == int(qual_tot[qq]):
+                N_qual[chr(x)] = quals.index(qq)
             else:
                 total_quals += 1
-                N_qual[chr(b)] = total_quals                      # SURVEY.md Q9: replicated
+                N_qual[chr(x)] = total_quals                      # SURVEY.md Q9: replicated
     bits_per_base = bits_for(len(dna_bases), pad)
     bits_per_quality = bits_for(total_quals, pad)
     variable = int(len_min) != int(len_max)                       # uq.py:512-513
     lv = int(len_max) + (1 if variable else 0)
     return {
-        'bases': ''.join(chr(b) for b in dna_bases), 'qualities': ''.join(chr(q) for q in quals),
+        'bases': ''.join(chr(x) for x in dna_bases), 'qualities': ''.join(chr(x) for x in quals),
         'N_qual': N_qual, 'total_quals': total_quals,
         'bits_per_base': bits_per_base, 'bits_per_quality': bits_per_quality,
         'variable_read_lengths': variable, 'dna_max': int(len_max), 'dna_min': int(len_min),
         'dna_bytes_per_row': -(-bits_per_base * lv // 8), 'quality_bytes_per_row': -(-bits_per_quality * lv // 8),
-        'base_distribution': {chr(b): int(base_tot[b]) for b in all_bases},
-        'qual_distribution': {chr(q): int(qual_tot[q]) for q in quals},
+        'base_distribution': {chr(x): int(base_tot[x]) for x in all_bases},
+        'qual_distribution': {chr(x): int(qual_tot[x]) for x in quals},
     }

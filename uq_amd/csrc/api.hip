@@ -35,6 +35,8 @@ extern "C" int uq_ctx_create(int device, void* stream, uq_ctx** out) {
     UQ_CHECK_HIP(hipEventCreate(&c->ev0));
     UQ_CHECK_HIP(hipEventCreate(&c->ev1));
     UQ_CHECK_HIP(hipHostMalloc((void**)&c->h_pinned, 65536, hipHostMallocDefault));
+    UQ_CHECK_HIP(hipHostGetDevicePointer((void**)&c->d_pinned, c->h_pinned, 0));
+    UQ_CHECK_HIP(hipMalloc((void**)&c->d_async, 64));
     *out = c;
     return 0;
 }
@@ -48,10 +50,27 @@ extern "C" int uq_ctx_destroy(uq_ctx* c) {
     if (c->idx_bitmap) (void)hipFree(c->idx_bitmap);
     if (c->scan_ws) (void)hipFree(c->scan_ws);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    if (c->d_async) (void)hipFree(c->d_async);
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
+    return 0;
+}
+
+namespace {
+__global__ void read_back_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, uint32_t nwords) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += gridDim.x * blockDim.x) dst[i] = src[i];
+}
+}  // namespace
+
+int uq_read_back(uq_ctx* c, void* h_dst, const void* d_src, size_t bytes) {
+    const size_t off = (size_t)((const uint8_t*)h_dst - (const uint8_t*)c->h_pinned);
+    UQ_REQUIRE(bytes % 4 == 0 && off % 4 == 0 && off + bytes <= 65536, "uq_read_back: destination outside the pinned staging buffer");
+    if (bytes == 0) return 0;
+    const uint32_t nwords = (uint32_t)(bytes / 4);
+    read_back_kernel<<<nwords > 1024 ? 8 : 1, 256, 0, c->stream>>>((const uint32_t*)d_src, (uint32_t*)((uint8_t*)c->d_pinned + off), nwords);
+    UQ_LAUNCH_CHECK();
     return 0;
 }
 

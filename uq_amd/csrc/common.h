@@ -22,7 +22,11 @@ struct uq_ctx {
     uint32_t* idx_partials; size_t idx_partials_cap;
     uint16_t* idx_bitmap;   // newline bitmap of that buffer: one u16 per 16-byte vector (index.hip)
     uint64_t* h_pinned;     // small pinned host staging (64 KiB)
+    uint64_t* d_pinned;     // the same memory as the device sees it (uq_read_back)
     void* scan_ws; size_t scan_ws_bytes;   // partial sums of the hierarchical scans
+    // the queued form of the census (uq_count_lines_end_async): the line count stays on the device for the kernels queued behind it
+    unsigned long long* d_async;           // [0] line count  [1] line_start capacity exceeded
+    const uint8_t* async_buf; uint64_t async_nbytes; bool async_read;
 };
 
 void uq_set_error(const char* fmt, ...);
@@ -45,6 +49,11 @@ void uq_set_error(const char* fmt, ...);
     do { int _r = (expr); if (_r) return _r; } while (0)
 
 #define UQ_LAUNCH_CHECK() UQ_CHECK_HIP(hipGetLastError())
+
+// Small results for the host: a kernel stores `bytes` (a multiple of 4) from d_src into the context's pinned staging at h_dst (which
+// must lie inside ctx->h_pinned), queued on the context's stream -- no copy command: under a kernel that fills the device a blit / DMA
+// copy of a few bytes was seen to wait 0.2 - 0.6 ms for its turn, an ordinary one-workgroup kernel is dispatched at once.
+int uq_read_back(uq_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
 
 // Scratch: returns a pointer into the context's pool, growing it if needed.  A grow synchronises the
 // stream first (the old pool may still be in use by queued kernels).

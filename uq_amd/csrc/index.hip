@@ -106,17 +106,26 @@ __global__ __launch_bounds__(IDX_THREADS) void census_list_kernel(const uint4* _
 }
 
 // A wave per tile: line_start[rank + 1] = stream position of the byte after the newline.
+// d_async (the queued form, uq_index_lines_async): the line count is read from d_async[0] -- the census's scan, queued in front,
+// left it there -- and line_start holds `cap` + 1 entries: lines beyond are dropped and d_async[1] is raised.
 __global__ __launch_bounds__(IDX_THREADS) void expand_list_kernel(const uint16_t* __restrict__ list, uint32_t mis, const uint32_t* __restrict__ offsets,
-                                                                   uint64_t nb, uint64_t nlines, uint64_t* __restrict__ line_start) {
+                                                                   uint64_t nb, uint64_t nlines, uint64_t* __restrict__ line_start,
+                                                                   unsigned long long* __restrict__ d_async, uint64_t cap) {
     const uint32_t lane = lane_id();
     const uint64_t tile = (uint64_t)blockIdx.x * (IDX_THREADS / 64) + (threadIdx.x >> 6);
     if (tile >= nb) return;
+    if (d_async) nlines = d_async[0];
     if (tile == 0 && lane == 0) line_start[0] = 0;
     const uint64_t P = offsets[tile];
     const uint64_t end = tile + 1 < nb ? (uint64_t)offsets[tile + 1] : nlines;
     const uint32_t cnt = (uint32_t)(end - P);
     const uint16_t* slot = list + tile * IDX_LIST_CAP;
     const int64_t p0 = (int64_t)(tile * IDX_TILE) - (int64_t)mis + 1;
+    if (d_async && end > cap) {
+        if (lane == 0) d_async[1] = 1ull;
+        for (uint32_t j = lane; j < cnt; j += 64) if (P + j + 1 <= cap) line_start[P + j + 1] = (uint64_t)(p0 + slot[j]);
+        return;
+    }
     for (uint32_t j = lane; j < cnt; j += 64) line_start[P + j + 1] = (uint64_t)(p0 + slot[j]);
 }
 
@@ -352,8 +361,8 @@ static int finish_count(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint
     void* scr;
     UQ_TRY(uq_scratch(ctx, 256, &scr));
     UQ_TRY(uq_scan_exclusive_u32(ctx, ctx->idx_partials, ctx->idx_partials, nb, (uint64_t*)scr));
-    UQ_CHECK_HIP(hipMemcpyAsync(ctx->h_pinned, scr, 8, hipMemcpyDeviceToHost, ctx->stream));
-    UQ_CHECK_HIP(hipMemcpyAsync(ctx->h_pinned + 1, ctx->idx_bitmap + nb * IDX_TILE_VECS, 4, hipMemcpyDeviceToHost, ctx->stream));
+    UQ_TRY(uq_read_back(ctx, ctx->h_pinned, scr, 8));
+    UQ_TRY(uq_read_back(ctx, ctx->h_pinned + 1, ctx->idx_bitmap + nb * IDX_TILE_VECS, 4));
     UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     *h_nlines = ctx->h_pinned[0];
     // the lists are only good when every tile's newlines fitted its slot; otherwise uq_index_lines runs the bitmap form
@@ -444,6 +453,61 @@ extern "C" int uq_count_lines_end(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nb
     return finish_count(ctx, d_buf, nbytes, nb, h_nlines);
 }
 
+// ---- the census and the record index without a host round trip between them: the closing scan is queued behind the chunks and
+// leaves the line count ON THE DEVICE (ctx->d_async); uq_index_lines_async and uq_pack_stats_async, queued behind it, read it
+// there; the host learns it from uq_count_lines_wait, after everything else of the step has been queued.  (A step that waits for
+// the count before it can size and queue the index and the pack kernel leaves the device idle for two launch latencies and a
+// synchronisation: ~0.14 ms of a 2.4 ms step.)
+extern "C" int uq_count_lines_end_async(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes) {
+    UQ_REQUIRE(ctx && (d_buf || nbytes == 0), "uq_count_lines_end_async: null argument");
+    ctx->idx_buf = nullptr; ctx->async_buf = nullptr; ctx->async_read = false;
+    UQ_CHECK_HIP(hipMemsetAsync(ctx->d_async, 0, 64, ctx->stream));
+    if (nbytes == 0) { ctx->h_pinned[8000] = 0; ctx->h_pinned[8001] = 0; ctx->h_pinned[8002] = 0; ctx->async_buf = d_buf; ctx->async_nbytes = 0; return 0; }
+    const uint32_t mis = (uint32_t)((uintptr_t)d_buf & 15);
+    const uint64_t nb = (((nbytes + mis + 15) / 16) * 16 + IDX_TILE - 1) / IDX_TILE;
+    UQ_TRY(uq_scan_exclusive_u32(ctx, ctx->idx_partials, ctx->idx_partials, nb, (uint64_t*)ctx->d_async));
+    ctx->async_buf = d_buf; ctx->async_nbytes = nbytes;
+    return 0;
+}
+
+extern "C" int uq_index_lines_async(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint64_t capacity_lines, uint64_t* d_line_start) {
+    UQ_REQUIRE(ctx && d_line_start, "uq_index_lines_async: null argument");
+    UQ_REQUIRE(ctx->async_buf == d_buf && ctx->async_nbytes == nbytes, "uq_index_lines_async: not the buffer of the last uq_count_lines_end_async");
+    UQ_REQUIRE(capacity_lines < (uint64_t(1) << 32), "uq_index_lines_async: more than 2^32-1 lines in one shard");
+    if (nbytes == 0) { UQ_CHECK_HIP(hipMemsetAsync(d_line_start, 0, 8, ctx->stream)); return 0; }
+    const uint32_t mis = (uint32_t)((uintptr_t)d_buf & 15);
+    const uint64_t nb = (((nbytes + mis + 15) / 16) * 16 + IDX_TILE - 1) / IDX_TILE;
+    expand_list_kernel<<<(uint32_t)((nb + IDX_THREADS / 64 - 1) / (IDX_THREADS / 64)), IDX_THREADS, 0, ctx->stream>>>(ctx->idx_bitmap, mis, ctx->idx_partials,
+                                                                                                                 nb, 0, d_line_start, ctx->d_async, capacity_lines);
+    UQ_LAUNCH_CHECK();
+    // what uq_count_lines_wait hands out, on its way to the host already
+    UQ_TRY(uq_read_back(ctx, ctx->h_pinned + 8000, ctx->d_async, 16));
+    UQ_TRY(uq_read_back(ctx, ctx->h_pinned + 8002, ctx->idx_bitmap + nb * IDX_TILE_VECS, 4));
+    ctx->async_read = true;
+    return 0;
+}
+
+// *h_ok = 0: a tile held more newlines than its list (the index above is not usable: uq_count_lines + uq_index_lines take the bitmap
+// form) or more lines than the capacity given to uq_index_lines_async.
+extern "C" int uq_count_lines_wait(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint64_t* h_nlines, int* h_ok) {
+    UQ_REQUIRE(ctx && h_nlines && h_ok, "uq_count_lines_wait: null argument");
+    UQ_REQUIRE(ctx->async_buf == d_buf && ctx->async_nbytes == nbytes, "uq_count_lines_wait: not the buffer of the last uq_count_lines_end_async");
+    *h_nlines = 0; *h_ok = 1;
+    ctx->async_buf = nullptr;
+    if (nbytes == 0) return 0;
+    const uint32_t mis = (uint32_t)((uintptr_t)d_buf & 15);
+    const uint64_t nb = (((nbytes + mis + 15) / 16) * 16 + IDX_TILE - 1) / IDX_TILE;
+    if (!ctx->async_read) {
+        UQ_TRY(uq_read_back(ctx, ctx->h_pinned + 8000, ctx->d_async, 16));
+        UQ_TRY(uq_read_back(ctx, ctx->h_pinned + 8002, ctx->idx_bitmap + nb * IDX_TILE_VECS, 4));
+    }
+    ctx->async_read = false;
+    UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    *h_nlines = ctx->h_pinned[8000];
+    *h_ok = ctx->h_pinned[8001] == 0 && (uint32_t)ctx->h_pinned[8002] == 0;
+    return 0;
+}
+
 extern "C" int uq_index_lines(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint64_t nlines, uint64_t* d_line_start) {
     UQ_REQUIRE(ctx && d_line_start, "uq_index_lines: null argument");
     UQ_REQUIRE(nlines < (uint64_t(1) << 32), "uq_index_lines: more than 2^32-1 lines in one shard");
@@ -460,7 +524,7 @@ extern "C" int uq_index_lines(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes
         nb = (nvec * 16 + IDX_TILE - 1) / IDX_TILE;
         ctx->idx_buf = nullptr;
         expand_list_kernel<<<(uint32_t)((nb + IDX_THREADS / 64 - 1) / (IDX_THREADS / 64)), IDX_THREADS, 0, ctx->stream>>>(ctx->idx_bitmap, mis, ctx->idx_partials,
-                                                                                                                     nb, nlines, d_line_start);
+                                                                                                                     nb, nlines, d_line_start, nullptr, 0);
         UQ_LAUNCH_CHECK();
         return 0;
     }

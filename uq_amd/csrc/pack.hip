@@ -108,7 +108,7 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && NTRICK) ? 4 : 5) void pack_ti
                                                                uint64_t n, PackLut lut, PackGeom g,
                                                                uint8_t* __restrict__ dna, uint8_t* __restrict__ qual,
                                                                unsigned long long* __restrict__ bad,
-                                                               uq_stats* __restrict__ st, uint32_t win) {
+                                                               uq_stats* __restrict__ st, const unsigned long long* __restrict__ d_async) {
     constexpr int NV = STATS ? PK_NV_STATS : PK_NV;
     extern __shared__ __align__(16) uint8_t smem[];
     uint8_t* stage = smem + 16;                       // reads of up to 8 bytes below offset 0 stay in bounds
@@ -127,7 +127,10 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && NTRICK) ? 4 : 5) void pack_ti
     uint32_t* cnt_tab = (uint32_t*)(l_nq + 256);                 // [256 bins][PKS_COPIES], then [128] N-trick base by quality character
     uint32_t fill_pairs = 0, n_pairs = 0;                        // pairs counted in bin 0 / bin n_code that were fills / N-trick positions
     if (STATS) for (uint32_t i = tid; i < PKS_WORDS; i += PK_THREADS) cnt_tab[i] = 0;       // the first tile's barrier orders it
-    (void)win;
+    if (d_async) {                                    // the queued form (uq_pack_stats_async): the census in front left the line count on the device;
+        const uint64_t have = d_async[0] / 4;         // `n` is what the tables hold
+        if (have > n) incomplete = true; else n = have;
+    }
 
     const uint64_t R = g.R;
     const uint64_t ntiles = (n + R - 1) / R;
@@ -405,7 +408,7 @@ __global__ __launch_bounds__(256) void pack_carry_kernel(const uint8_t* __restri
 }
 
 typedef void (*PackKernel)(const uint8_t*, const uint64_t*, uint64_t, uint64_t, PackLut, PackGeom, uint8_t*, uint8_t*, unsigned long long*,
-                           uq_stats*, uint32_t);
+                           uq_stats*, const unsigned long long*);
 
 template <int BD, int BQ>
 PackKernel pick_nt(bool ntrick, bool fast) {
@@ -442,7 +445,7 @@ PackKernel pick_kernel(int bd, int bq, bool ntrick, bool fast) {
 // (*h_fused = 1); if not, nothing is launched and *h_fused = 0.
 static int pack_impl(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start, uint64_t first_read,
                      uint64_t nreads, const uq_pack_params* hp, uint8_t* d_dna, uint8_t* d_qual, uint64_t* d_bad,
-                     uq_stats* d_stats, int* h_fused) {
+                     uq_stats* d_stats, int* h_fused, const unsigned long long* d_async = nullptr) {
     UQ_REQUIRE(ctx && d_buf && d_line_start && hp && d_dna && d_qual && d_bad, "uq_pack: null argument");
     if (h_fused) *h_fused = 0;
     UQ_REQUIRE(hp->bits_per_base >= 1 && hp->bits_per_base <= 8 && hp->bits_per_quality >= 1 && hp->bits_per_quality <= 8,
@@ -549,12 +552,10 @@ static int pack_impl(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_s
     if (per_cu > 6) per_cu = 6;
     if (per_cu < 1) per_cu = 1;
     const uint64_t blocks = tiles < (uint64_t)UQ_NUM_CU * per_cu ? tiles : (uint64_t)UQ_NUM_CU * per_cu;
-    // statistics windows: 32 base bytes from '@', 64 quality bytes around the guessed alphabet (speed only)
-    const uint32_t qbase = qmin >= 64 ? 59u : (qmin < 33 ? 0u : 33u);
     PackKernel k = d_stats ? pick_stats_kernel((int)bq, ntrick) : pick_kernel((int)bd, (int)bq, ntrick, fast);
     if (lds > 48 * 1024) UQ_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     k<<<(uint32_t)blocks, PK_THREADS, lds, ctx->stream>>>(d_buf, d_line_start, first_read, nreads, lut, g, d_dna, d_qual,
-                                                         (unsigned long long*)d_bad, d_stats, (64u << 8) | qbase);
+                                                         (unsigned long long*)d_bad, d_stats, d_async);
     UQ_LAUNCH_CHECK();
     if (h_fused) *h_fused = 1;
     return 0;
@@ -570,4 +571,14 @@ extern "C" int uq_pack_stats(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* 
                              uq_stats* d_stats, int* h_fused) {
     UQ_REQUIRE(d_stats && h_fused, "uq_pack_stats: null argument");
     return pack_impl(ctx, d_buf, d_line_start, first_read, nreads, h_guess, d_dna, d_qual, d_bad, d_stats, h_fused);
+}
+
+// uq_pack_stats behind a census still in flight (uq_count_lines_end_async + uq_index_lines_async): the number of reads is taken on the
+// device; `capacity_reads` is what d_dna / d_qual hold (more reads than that: the statistics come back flagged incomplete).
+extern "C" int uq_pack_stats_async(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start, uint64_t capacity_reads,
+                                   const uq_pack_params* h_guess, uint8_t* d_dna, uint8_t* d_qual, uint64_t* d_bad,
+                                   uq_stats* d_stats, int* h_fused) {
+    UQ_REQUIRE(d_stats && h_fused, "uq_pack_stats_async: null argument");
+    UQ_REQUIRE(ctx && ctx->async_buf == d_buf, "uq_pack_stats_async: not the buffer of the last uq_count_lines_end_async");
+    return pack_impl(ctx, d_buf, d_line_start, 0, capacity_reads, h_guess, d_dna, d_qual, d_bad, d_stats, h_fused, ctx->d_async);
 }

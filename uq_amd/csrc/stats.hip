@@ -319,8 +319,8 @@ __global__ void stats_import_kernel(const long long* __restrict__ buf, uint32_t 
 
 // ---- the statistics as a short list: a file uses a few hundred of the 65 536 (base, quality) counters, and reading 512 KiB back
 // (pageable: staged) costs more than the decisions that follow
-constexpr uint32_t SC_CAP = 2048;
-struct StatsCompact { uint32_t n, len_min, len_max, max_record_bytes, reserved, pad; uint64_t bad_plus, bad_len; uint32_t key[SC_CAP]; uint64_t count[SC_CAP]; };
+constexpr uint32_t SC_CAP = UQ_STATS_COMPACT_CAP;
+typedef uq_stats_compact StatsCompact;
 __global__ void stats_compact_kernel(const uq_stats* __restrict__ st, StatsCompact* __restrict__ out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) {
@@ -369,17 +369,24 @@ __global__ __launch_bounds__(256) void first_occurrence_kernel(const uint8_t* __
 }
 }  // namespace
 
-extern "C" int uq_stats_fetch(uq_ctx* ctx, const uq_stats* d_stats, uq_stats* h_stats) {
-    UQ_REQUIRE(ctx && d_stats && h_stats, "uq_stats_fetch: null argument");
-    static_assert(sizeof(StatsCompact) <= 65536, "the compact form must fit the context's pinned staging buffer");
+// the non-zero counters as a list (n entries, any order) + the scalars, in the context's pinned staging; n > SC_CAP: list cut short
+static int stats_fetch_compact(uq_ctx* ctx, const uq_stats* d_stats, const StatsCompact** out) {
+    static_assert(sizeof(StatsCompact) <= 63000 && sizeof(StatsCompact) % 4 == 0, "the compact form must fit the context's pinned staging buffer");
     void* scr;
     UQ_TRY(uq_scratch(ctx, sizeof(StatsCompact), &scr));
     UQ_CHECK_HIP(hipMemsetAsync(scr, 0, 8, ctx->stream));
     stats_compact_kernel<<<65536 / 256, 256, 0, ctx->stream>>>(d_stats, (StatsCompact*)scr);
     UQ_LAUNCH_CHECK();
-    UQ_CHECK_HIP(hipMemcpyAsync(ctx->h_pinned, scr, sizeof(StatsCompact), hipMemcpyDeviceToHost, ctx->stream));
+    UQ_TRY(uq_read_back(ctx, ctx->h_pinned, scr, sizeof(StatsCompact)));
     UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-    const StatsCompact* c = (const StatsCompact*)ctx->h_pinned;
+    *out = (const StatsCompact*)ctx->h_pinned;
+    return 0;
+}
+
+extern "C" int uq_stats_fetch(uq_ctx* ctx, const uq_stats* d_stats, uq_stats* h_stats) {
+    UQ_REQUIRE(ctx && d_stats && h_stats, "uq_stats_fetch: null argument");
+    const StatsCompact* c;
+    UQ_TRY(stats_fetch_compact(ctx, d_stats, &c));
     if (c->n > SC_CAP) {                                   // an unusually rich file: the whole table
         UQ_CHECK_HIP(hipMemcpyAsync(h_stats, d_stats, sizeof(uq_stats), hipMemcpyDeviceToHost, ctx->stream));
         UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
@@ -389,6 +396,17 @@ extern "C" int uq_stats_fetch(uq_ctx* ctx, const uq_stats* d_stats, uq_stats* h_
     for (uint32_t k = 0; k < c->n; ++k) h_stats->counts[c->key[k]] = c->count[k];
     h_stats->bad_plus = c->bad_plus; h_stats->bad_len = c->bad_len; h_stats->len_min = c->len_min; h_stats->len_max = c->len_max;
     h_stats->max_record_bytes = c->max_record_bytes; h_stats->reserved = c->reserved;
+    return 0;
+}
+
+extern "C" int uq_stats_fetch_compact(uq_ctx* ctx, const uq_stats* d_stats, uq_stats_compact* h_out) {
+    UQ_REQUIRE(ctx && d_stats && h_out, "uq_stats_fetch_compact: null argument");
+    const StatsCompact* c;
+    UQ_TRY(stats_fetch_compact(ctx, d_stats, &c));
+    const uint32_t n = c->n < SC_CAP ? c->n : SC_CAP;
+    memcpy(h_out, c, offsetof(StatsCompact, key));
+    memcpy(h_out->key, c->key, n * sizeof(uint32_t));
+    memcpy(h_out->count, c->count, n * sizeof(uint64_t));
     return 0;
 }
 

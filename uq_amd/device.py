@@ -13,7 +13,14 @@ from ._lib import call, UqHipError
 
 
 class Context:
-    """Binds a `uq_ctx` to a torch device and a dedicated torch stream (made current)."""
+    """Binds a `uq_ctx` to a torch device and a dedicated torch stream (made current).
+
+    All Contexts of a process on one device share that ONE stream: the kernels behind the C ABI and the torch operations of the
+    caller (allocations, comparisons, copies) are ordered by being on the same stream, and a second Context that made a stream of
+    its own current would silently take that ordering away from the first (its kernels would race with torch operations issued
+    afterwards).  Work that is meant to run beside it takes a SideContext."""
+
+    _streams = {}        # device index -> the torch stream every Context on that device uses
 
     def __init__(self, device=0):
         import torch
@@ -23,7 +30,10 @@ class Context:
             raise UqHipError('no HIP device visible: the uQ hot path runs on MI355X only (no CPU fallback)')
         self.device = torch.device('cuda', device)
         torch.cuda.set_device(self.device)
-        self.stream = torch.cuda.Stream(device=self.device)
+        idx = self.device.index or 0
+        if idx not in Context._streams:
+            Context._streams[idx] = torch.cuda.Stream(device=self.device)
+        self.stream = Context._streams[idx]
         torch.cuda.set_stream(self.stream)
         h = C.c_void_p()
         call('uq_ctx_create', int(device), C.c_void_p(self.stream.cuda_stream), C.byref(h))

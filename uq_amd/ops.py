@@ -44,6 +44,16 @@ class ChunkedCensus:
         call('uq_count_lines_end', self.ctx.h, _p(self.buf), self.buf.numel(), C.byref(out))
         return out.value
 
+    # the queued form: end_async() -> index_lines_async / pack_stats_async (they take the line count on the device) -> wait()
+    def end_async(self):
+        call('uq_count_lines_end_async', self.ctx.h, _p(self.buf), self.buf.numel())
+
+    def wait(self):
+        """(line count, ok): ok False = the index made meanwhile is not usable (list or capacity overflow)."""
+        out, ok = C.c_uint64(), C.c_int(0)
+        call('uq_count_lines_wait', self.ctx.h, _p(self.buf), self.buf.numel(), C.byref(out), C.byref(ok))
+        return out.value, bool(ok.value)
+
 
 def index_lines(ctx, buf, nlines):
     """int64 tensor [nlines + 1] of line start offsets (bit pattern of uint64)."""
@@ -53,26 +63,55 @@ def index_lines(ctx, buf, nlines):
     return ls
 
 
+def index_lines_async(ctx, buf, capacity_lines):
+    """The record index behind ChunkedCensus.end_async(): int64 tensor [capacity_lines + 1]; entries [0, lines] are written."""
+    t = ctx.torch
+    ls = t.empty(capacity_lines + 1, dtype=t.int64, device=ctx.device)
+    call('uq_index_lines_async', ctx.h, _p(buf), buf.numel(), capacity_lines, _p(ls))
+    return ls
+
+
 # ------------------------------------------------------------------ pass-1 statistics
 STATS_DTYPE = np.dtype([('counts', np.uint64, (65536,)), ('bad_plus', np.uint64), ('bad_len', np.uint64), ('len_min', np.uint32),
                         ('len_max', np.uint32), ('max_record_bytes', np.uint32), ('reserved', np.uint32)])    # struct uq_stats
 assert STATS_DTYPE.itemsize == C.sizeof(Stats)
 
 
+STATS_COMPACT_CAP = 2048
+STATS_COMPACT_DTYPE = np.dtype([('n', np.uint32), ('len_min', np.uint32), ('len_max', np.uint32), ('max_record_bytes', np.uint32), ('reserved', np.uint32),
+                                ('pad', np.uint32), ('bad_plus', np.uint64), ('bad_len', np.uint64), ('key', np.uint32, (STATS_COMPACT_CAP,)),
+                                ('count', np.uint64, (STATS_COMPACT_CAP,))])                              # struct uq_stats_compact
+
+
 class HostStats:
-    """Host copy of uq_stats: counts[256][256] + ranges + first bad records."""
+    """Host copy of uq_stats: counts[256][256] + ranges + first bad records.  From uq_stats_fetch_compact it holds the non-zero
+    counters as a list (nz_keys = base * 256 + quality, nz_counts) and builds the dense table only when somebody asks for it."""
 
     def __init__(self, s):
-        """`s`: a ctypes `Stats` or a numpy record of STATS_DTYPE (same layout)."""
+        """`s`: a ctypes `Stats`, a numpy record of STATS_DTYPE (same layout) or one of STATS_COMPACT_DTYPE."""
         if isinstance(s, Stats):
             s = np.frombuffer(s, dtype=STATS_DTYPE, count=1)[0]
-        self.counts = s['counts'].reshape(256, 256).copy()
+        if 'key' in s.dtype.names:
+            n = int(s['n'])
+            self.nz_keys = s['key'][:n].astype(np.int64); self.nz_counts = s['count'][:n].astype(np.int64)
+            self._counts = None
+        else:
+            self.nz_keys = self.nz_counts = None
+            self._counts = s['counts'].reshape(256, 256).copy()
         bad_plus, bad_len = int(s['bad_plus']), int(s['bad_len'])
         self.bad_plus = None if bad_plus == UQ_NONE else bad_plus
         self.bad_len = None if bad_len == UQ_NONE else bad_len
         self.len_min, self.len_max = int(s['len_min']), int(s['len_max'])
         self.max_record_bytes = int(s['max_record_bytes'])
         self.incomplete = bool(s['reserved'])         # set by uq_pack_stats only: counts not usable
+
+    @property
+    def counts(self):
+        if self._counts is None:
+            c = np.zeros(65536, dtype=np.uint64)
+            c[self.nz_keys] = self.nz_counts.astype(np.uint64)
+            self._counts = c.reshape(256, 256)
+        return self._counts
 
 
 def stats_new(ctx):
@@ -106,7 +145,11 @@ def index_and_stats(ctx, buf, nlines, fused=False):
 
 
 def stats_fetch(ctx, d_stats):
-    raw = np.empty(1, dtype=STATS_DTYPE)
+    raw = np.empty(1, dtype=STATS_COMPACT_DTYPE)
+    call('uq_stats_fetch_compact', ctx.h, _p(d_stats), C.c_void_p(raw.ctypes.data))
+    if int(raw[0]['n']) <= STATS_COMPACT_CAP:
+        return HostStats(raw[0])
+    raw = np.empty(1, dtype=STATS_DTYPE)              # more non-zero counters than the list holds: the whole table
     call('uq_stats_fetch', ctx.h, _p(d_stats), C.c_void_p(raw.ctypes.data))
     return HostStats(raw[0])
 
@@ -155,6 +198,19 @@ def pack_stats(ctx, buf, line_start, first_read, nreads, guess):
     st = stats_new(ctx)
     fused = C.c_int(0)
     call('uq_pack_stats', ctx.h, _p(buf), _p(line_start), first_read, nreads, C.byref(guess), _p(dna), _p(qual), _p(bad), _p(st), C.byref(fused))
+    return (dna, qual, bad, st) if fused.value else None
+
+
+def pack_stats_async(ctx, buf, line_start, capacity_reads, guess):
+    """pack_stats of every read of `buf` behind ChunkedCensus.end_async() + index_lines_async: tables of capacity_reads rows (the
+    caller narrows them once wait() has told it the count).  Returns (dna, qual, bad, d_stats) or None (no fused kernel)."""
+    t = ctx.torch
+    dna = t.empty(capacity_reads * guess.dna_bytes_per_row, dtype=t.uint8, device=ctx.device)
+    qual = t.empty(capacity_reads * guess.quality_bytes_per_row, dtype=t.uint8, device=ctx.device)
+    bad = t.empty(1, dtype=t.int64, device=ctx.device)
+    st = stats_new(ctx)
+    fused = C.c_int(0)
+    call('uq_pack_stats_async', ctx.h, _p(buf), _p(line_start), capacity_reads, C.byref(guess), _p(dna), _p(qual), _p(bad), _p(st), C.byref(fused))
     return (dna, qual, bad, st) if fused.value else None
 
 
@@ -210,7 +266,7 @@ def head_guess(ctx, buf, notricks=False, pad=False, head_bytes=None, head_reads=
     hs = stats_fetch(ctx, st)
     if hs.bad_plus is not None or hs.bad_len is not None:
         return None
-    d = analysis.decide_from_counts(hs.counts, hs.len_min, hs.len_max, notricks=notricks, pad=pad)
+    d = analysis.decide_from_stats(hs, notricks=notricks, pad=pad)
     if d['N_qual'] and max(d['N_qual'].values()) >= len(d['qualities']): return None       # Q9 new-code files: exact kernel only
     # bytes of the n reads, from the head's own byte and line counts (a read-back of ls[4 n] through torch would queue behind
     # whatever runs on torch's stream -- the caller's census of the whole file -- and hold the host until that is done)
@@ -234,7 +290,7 @@ def head_guess_indexed(ctx, buf, line_start, nreads, notricks=False, pad=False):
     hs = stats_fetch(ctx, st)
     if hs.bad_plus is not None or hs.bad_len is not None:
         return None
-    d = analysis.decide_from_counts(hs.counts, hs.len_min, hs.len_max, notricks=notricks, pad=pad)
+    d = analysis.decide_from_stats(hs, notricks=notricks, pad=pad)
     if d['N_qual'] and max(d['N_qual'].values()) >= len(d['qualities']): return None
     return make_pack_params(d['bases'], d['qualities'], d['N_qual'], d['bits_per_base'], d['bits_per_quality'], d['variable_read_lengths'],
                             d['dna_bytes_per_row'], d['quality_bytes_per_row'], d['dna_max'], hs.max_record_bytes,

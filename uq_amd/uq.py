@@ -237,7 +237,7 @@ class Session:
         if hs.bad_len is not None:
             error('ERROR: Length of DNA does not match the length of the quality scores for entry ' + str(hs.bad_len))
         self.hs = hs
-        d = analysis.decide_from_counts(hs.counts, hs.len_min, hs.len_max, notricks=args.notricks, pad=args.pad, first_seen=self.first_seen)
+        d = analysis.decide_from_stats(hs, notricks=args.notricks, pad=args.pad, first_seen=self.first_seen)
         self.d = d
         try:
             prefix, suffix, separators, columns, arrays = self.analyse_qname()
