@@ -378,8 +378,8 @@ def main():
 
     mode = (' [ONE pass over the stream: decisions guessed from the shard\'s first 65536 reads, tables kept only because the whole '
             'shard\'s statistics -- counted in the same pass -- gave the same decisions]' if one_pass else
-            (' [TWO reads of the stream: census + index, then pack + statistics in one kernel with decisions guessed from the shard\'s first '
-             '65536 reads; the tables were kept because the whole shard\'s statistics gave the same decisions]' if two_reads else
+            (' [TWO reads of the stream, queued back to back (the line count stays on the device for the index and the pack kernel): census + index, then pack + statistics in one kernel with decisions guessed from the shard\'s first '
+             '8192 reads; the tables were kept because the whole shard\'s statistics gave the same decisions]' if two_reads else
              ' [three reads of the stream: census, statistics, pack]'))
     result = {
         'metric': 'FASTQ encode MB/s (150bp synthetic; bit-exact tables vs reference)',
