@@ -108,25 +108,31 @@ __global__ __launch_bounds__(IDX_THREADS) void census_list_kernel(const uint4* _
 // A wave per tile: line_start[rank + 1] = stream position of the byte after the newline.
 // d_async (the queued form, uq_index_lines_async): the line count is read from d_async[0] -- the census's scan, queued in front,
 // left it there -- and line_start holds `cap` + 1 entries: lines beyond are dropped and d_async[1] is raised.
+constexpr uint32_t EXP_TILES = 4;            // census tiles per wave: a tile's ~200 offsets alone are too little work for a wave's set-up
 __global__ __launch_bounds__(IDX_THREADS) void expand_list_kernel(const uint16_t* __restrict__ list, uint32_t mis, const uint32_t* __restrict__ offsets,
                                                                    uint64_t nb, uint64_t nlines, uint64_t* __restrict__ line_start,
                                                                    unsigned long long* __restrict__ d_async, uint64_t cap) {
     const uint32_t lane = lane_id();
-    const uint64_t tile = (uint64_t)blockIdx.x * (IDX_THREADS / 64) + (threadIdx.x >> 6);
-    if (tile >= nb) return;
+    const uint64_t tile0 = ((uint64_t)blockIdx.x * (IDX_THREADS / 64) + (threadIdx.x >> 6)) * EXP_TILES;
+    if (tile0 >= nb) return;
     if (d_async) nlines = d_async[0];
-    if (tile == 0 && lane == 0) line_start[0] = 0;
-    const uint64_t P = offsets[tile];
-    const uint64_t end = tile + 1 < nb ? (uint64_t)offsets[tile + 1] : nlines;
-    const uint32_t cnt = (uint32_t)(end - P);
-    const uint16_t* slot = list + tile * IDX_LIST_CAP;
-    const int64_t p0 = (int64_t)(tile * IDX_TILE) - (int64_t)mis + 1;
-    if (d_async && end > cap) {
-        if (lane == 0) d_async[1] = 1ull;
-        for (uint32_t j = lane; j < cnt; j += 64) if (P + j + 1 <= cap) line_start[P + j + 1] = (uint64_t)(p0 + slot[j]);
-        return;
+    if (tile0 == 0 && lane == 0) line_start[0] = 0;
+    // the tiles' first ranks (and the rank behind the last one) once, a lane each
+    const uint64_t tl = tile0 + lane;
+    const uint64_t mine = lane <= EXP_TILES ? (tl < nb ? (uint64_t)offsets[tl] : nlines) : 0;
+    for (uint32_t k = 0; k < EXP_TILES && tile0 + k < nb; ++k) {
+        const uint64_t tile = tile0 + k;
+        const uint64_t P = __shfl(mine, k, 64), end = __shfl(mine, k + 1, 64);
+        const uint32_t cnt = (uint32_t)(end - P);
+        const uint16_t* slot = list + tile * IDX_LIST_CAP;
+        const int64_t p0 = (int64_t)(tile * IDX_TILE) - (int64_t)mis + 1;
+        if (d_async && end > cap) {
+            if (lane == 0) d_async[1] = 1ull;
+            for (uint32_t j = lane; j < cnt; j += 64) if (P + j + 1 <= cap) line_start[P + j + 1] = (uint64_t)(p0 + slot[j]);
+            continue;
+        }
+        for (uint32_t j = lane; j < cnt; j += 64) line_start[P + j + 1] = (uint64_t)(p0 + slot[j]);
     }
-    for (uint32_t j = lane; j < cnt; j += 64) line_start[P + j + 1] = (uint64_t)(p0 + slot[j]);
 }
 
 // One workgroup per census tile: 256 lanes x one 64-bit bitmap word (= 64 stream bytes) each.
@@ -477,7 +483,7 @@ extern "C" int uq_index_lines_async(uq_ctx* ctx, const uint8_t* d_buf, uint64_t 
     if (nbytes == 0) { UQ_CHECK_HIP(hipMemsetAsync(d_line_start, 0, 8, ctx->stream)); return 0; }
     const uint32_t mis = (uint32_t)((uintptr_t)d_buf & 15);
     const uint64_t nb = (((nbytes + mis + 15) / 16) * 16 + IDX_TILE - 1) / IDX_TILE;
-    expand_list_kernel<<<(uint32_t)((nb + IDX_THREADS / 64 - 1) / (IDX_THREADS / 64)), IDX_THREADS, 0, ctx->stream>>>(ctx->idx_bitmap, mis, ctx->idx_partials,
+    expand_list_kernel<<<(uint32_t)((nb + EXP_TILES * (IDX_THREADS / 64) - 1) / (EXP_TILES * (IDX_THREADS / 64))), IDX_THREADS, 0, ctx->stream>>>(ctx->idx_bitmap, mis, ctx->idx_partials,
                                                                                                                  nb, 0, d_line_start, ctx->d_async, capacity_lines);
     UQ_LAUNCH_CHECK();
     // what uq_count_lines_wait hands out, on its way to the host already
@@ -523,7 +529,7 @@ extern "C" int uq_index_lines(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes
                    (unsigned long long)nlines, (unsigned long long)ctx->idx_nlines);
         nb = (nvec * 16 + IDX_TILE - 1) / IDX_TILE;
         ctx->idx_buf = nullptr;
-        expand_list_kernel<<<(uint32_t)((nb + IDX_THREADS / 64 - 1) / (IDX_THREADS / 64)), IDX_THREADS, 0, ctx->stream>>>(ctx->idx_bitmap, mis, ctx->idx_partials,
+        expand_list_kernel<<<(uint32_t)((nb + EXP_TILES * (IDX_THREADS / 64) - 1) / (EXP_TILES * (IDX_THREADS / 64))), IDX_THREADS, 0, ctx->stream>>>(ctx->idx_bitmap, mis, ctx->idx_partials,
                                                                                                                      nb, nlines, d_line_start, nullptr, 0);
         UQ_LAUNCH_CHECK();
         return 0;
