@@ -885,8 +885,8 @@ int emit_offsets(uq_ctx* ctx, const EmitGeom& g, const uint32_t* d_len, uint64_t
     emit_sizes_kernel<<<(uint32_t)((nreads + 255) / 256), 256, 0, ctx->stream>>>(g, d_len, nreads, d_offsets);
     UQ_LAUNCH_CHECK();
     UQ_TRY(uq_scan_exclusive_u64(ctx, d_offsets, d_offsets, nreads, d_offsets + nreads));
-    UQ_CHECK_HIP(hipMemcpyAsync(ctx->h_pinned, d_offsets + nreads, 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (d_bad) UQ_CHECK_HIP(hipMemcpyAsync(ctx->h_pinned + 1, d_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
+    UQ_TRY(uq_read_back(ctx, ctx->h_pinned, d_offsets + nreads, 8));
+    if (d_bad) UQ_TRY(uq_read_back(ctx, ctx->h_pinned + 1, d_bad, 8));
     UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     *h_total = ctx->h_pinned[0];
     if (d_bad && h_bad) *h_bad = ctx->h_pinned[1];
@@ -1020,8 +1020,8 @@ extern "C" int uq_decode_fastq(uq_ctx* ctx, const uq_emit_params* hp, const uq_u
         return 0;
     }
     // second call: d_len / d_offsets hold what the first one left; the total is its last offset
-    UQ_CHECK_HIP(hipMemcpyAsync(ctx->h_pinned, d_offsets + nreads, 8, hipMemcpyDeviceToHost, ctx->stream));
-    UQ_CHECK_HIP(hipMemcpyAsync(ctx->h_pinned + 1, d_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
+    UQ_TRY(uq_read_back(ctx, ctx->h_pinned, d_offsets + nreads, 8));
+    UQ_TRY(uq_read_back(ctx, ctx->h_pinned + 1, d_bad, 8));
     UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     *h_total = ctx->h_pinned[0]; *h_bad = ctx->h_pinned[1];
     UQ_REQUIRE(capacity >= *h_total, "uq_decode_fastq: output buffer too small (%llu < %llu)", (unsigned long long)capacity, (unsigned long long)*h_total);

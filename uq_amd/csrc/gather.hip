@@ -185,7 +185,7 @@ extern "C" int uq_check_index_range(uq_ctx* ctx, const void* d_index, int index_
     index_range_kernel<<<(uint32_t)(want < UQ_NUM_CU * 8ull ? want : UQ_NUM_CU * 8ull), 256, 0, ctx->stream>>>(d_index, index_itemsize, n, limit,
                                                                                                                (unsigned long long*)ws);
     UQ_LAUNCH_CHECK();
-    UQ_CHECK_HIP(hipMemcpyAsync(ctx->h_pinned, ws, 8, hipMemcpyDeviceToHost, ctx->stream));
+    UQ_TRY(uq_read_back(ctx, ctx->h_pinned, ws, 8));
     UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     *h_first_bad = ctx->h_pinned[0];
     return 0;

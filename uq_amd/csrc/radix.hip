@@ -200,8 +200,9 @@ static int radix_sort_impl(uq_ctx* ctx, K* keys, uint32_t* vals, K* keys_alt, ui
         uint32_t cb = nb < 2048 ? nb : 2048;
         rs_census_kernel<K><<<cb, RS_THREADS, 0, ctx->stream>>>(keys, n, ghist);
         UQ_LAUNCH_CHECK();
-        UQ_CHECK_HIP(hipMemcpyAsync(h_hist, ghist, ND * 256 * 4, hipMemcpyDeviceToHost, ctx->stream));
+        UQ_TRY(uq_read_back(ctx, ctx->h_pinned + 4096, ghist, ND * 256 * 4));          // (pageable h_hist: through the pinned staging)
         UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        memcpy(h_hist, ctx->h_pinned + 4096, ND * 256 * 4);
     }
     K* kin = keys; uint32_t* vin = vals; K* kout = keys_alt; uint32_t* vout = vals_alt;
     for (int p = begin_bit / 8; p * 8 < end_bit; ++p) {
@@ -240,7 +241,8 @@ int radix_prefix_census32(uq_ctx* ctx, const uint64_t* keys64, uint64_t n, uint3
     const uint32_t nb = (uint32_t)((n + RsGeom<uint32_t>::TILE - 1) / RsGeom<uint32_t>::TILE);
     rs_prefix_census_kernel<<<nb < 2048 ? (nb ? nb : 1) : 2048, RS_THREADS, 0, ctx->stream>>>(keys64, n, z, keys, vals, nb, ghist, block_hist);
     UQ_LAUNCH_CHECK();
-    UQ_CHECK_HIP(hipMemcpyAsync(h_hist, ghist, 4 * 256 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    UQ_TRY(uq_read_back(ctx, ctx->h_pinned + 4096, ghist, 4 * 256 * 4));
     UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(h_hist, ctx->h_pinned + 4096, 4 * 256 * 4);
     return 0;
 }

@@ -321,7 +321,7 @@ int sort_rows_core(uq_ctx* ctx, const uint8_t* table, uint64_t n, uint32_t C, ui
     // with the true duplicates.  Tables whose rows crowd on few prefixes (the digit census says so) keep the 64-bit sort.
     uint32_t z = 0;
     if (mode32) {
-        UQ_CHECK_HIP(hipMemcpyAsync(ctx->h_pinned + 4, tot + 4, 16, hipMemcpyDeviceToHost, s));
+        UQ_TRY(uq_read_back(ctx, ctx->h_pinned + 4, tot + 4, 16));
         UQ_CHECK_HIP(hipStreamSynchronize(s));
         const uint64_t same = ~(ctx->h_pinned[4] ^ ctx->h_pinned[5]);           // bits every key agrees on
         while (z < 64 && ((same >> (63 - z)) & 1)) ++z;
@@ -362,7 +362,7 @@ int sort_rows_core(uq_ctx* ctx, const uint8_t* table, uint64_t n, uint32_t C, ui
             segment_sort_kernel<<<UQ_NUM_CU * 8, ST, 0, s>>>(table, C, d_perm, heads, flags, n, pos, (const unsigned long long*)tot, (uint32_t*)(tot + 3));
             UQ_LAUNCH_CHECK();
             heads = flags; out->heads = flags;
-            UQ_CHECK_HIP(hipMemcpyAsync(ctx->h_pinned, tot + 3, 8, hipMemcpyDeviceToHost, s));
+            UQ_TRY(uq_read_back(ctx, ctx->h_pinned, tot + 3, 8));
             UQ_CHECK_HIP(hipStreamSynchronize(s));
             if ((uint32_t)ctx->h_pinned[0] == 0) return 0;        // every group settled: the order is final
         }
@@ -393,7 +393,7 @@ int sort_rows_core(uq_ctx* ctx, const uint8_t* table, uint64_t n, uint32_t C, ui
         active_count_kernel<<<(uint32_t)ncb, ST, 0, s>>>(heads, n, bcnt);
         UQ_LAUNCH_CHECK();
         UQ_TRY(uq_scan_exclusive_u64(ctx, (const uint64_t*)bcnt, (uint64_t*)bcnt, ncb, tot));      // {actives, segments} packed in one u64
-        UQ_CHECK_HIP(hipMemcpyAsync(ctx->h_pinned, tot, 24, hipMemcpyDeviceToHost, s));
+        UQ_TRY(uq_read_back(ctx, ctx->h_pinned, tot, 24));
         UQ_CHECK_HIP(hipStreamSynchronize(s));
         const uint64_t m = ctx->h_pinned[0] & 0xFFFFFFFFull, nseg = ctx->h_pinned[0] >> 32;
         if ((uint32_t)ctx->h_pinned[2] == 0 || m == 0) break;
@@ -542,7 +542,7 @@ extern "C" int uq_unique_rows(uq_ctx* ctx, const uint8_t* d_table, uint64_t rows
     UQ_TRY(uq_scan_exclusive_u32(ctx, f, gscan, ncb, tot));
     keys_from_groups2_kernel<<<(uint32_t)ncb, ST, 0, ctx->stream>>>(c.heads, gscan, d_perm, rows, d_key, d_sorted_key, d_unique ? uidx : nullptr);
     UQ_LAUNCH_CHECK();
-    UQ_CHECK_HIP(hipMemcpyAsync(ctx->h_pinned, tot, 8, hipMemcpyDeviceToHost, ctx->stream));
+    UQ_TRY(uq_read_back(ctx, ctx->h_pinned, tot, 8));
     UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     *h_nunique = ctx->h_pinned[0];
     if (d_unique) UQ_TRY(uq_gather_rows_internal(ctx, d_table, rows, cols, uidx, 4, *h_nunique, d_unique));
