@@ -330,8 +330,10 @@ extern "C" int uq_qname_layout(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t
                                                                                      (LayoutOut*)scr);
         UQ_LAUNCH_CHECK();
     }
-    UQ_CHECK_HIP(hipMemcpyAsync(h_out, scr, sizeof(LayoutOut), hipMemcpyDeviceToHost, ctx->stream));
+    static_assert(sizeof(LayoutOut) % 4 == 0 && sizeof(LayoutOut) <= 16384, "read back through the pinned staging");
+    UQ_TRY(uq_read_back(ctx, ctx->h_pinned, scr, sizeof(LayoutOut)));
     UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(h_out, ctx->h_pinned, sizeof(LayoutOut));
     for (uint32_t k = 0; k < l1.nch; ++k) h_out->ch[k] = l1.ch[k];
     h_out->nch = l1.nch;
     return 0;
@@ -366,8 +368,10 @@ extern "C" int uq_qname_tokenise(uq_ctx* ctx, const uint8_t* d_buf, const uint64
         qname_tokenise_kernel<<<grid_for(nreads), QN_THREADS, 0, ctx->stream>>>(d_buf, d_line_start, nreads, sp, d_vals, d_strs, (ColsOut*)base);
         UQ_LAUNCH_CHECK();
     }
-    UQ_CHECK_HIP(hipMemcpyAsync(h_out, base, sizeof(ColsOut), hipMemcpyDeviceToHost, ctx->stream));
+    static_assert(sizeof(ColsOut) % 4 == 0 && sizeof(ColsOut) <= 16384, "read back through the pinned staging");
+    UQ_TRY(uq_read_back(ctx, ctx->h_pinned, base, sizeof(ColsOut)));
     UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(h_out, ctx->h_pinned, sizeof(ColsOut));
     return 0;
 }
 
@@ -391,8 +395,9 @@ extern "C" int uq_prefix_distinct(uq_ctx* ctx, const void* d_perm, int perm_item
         prefix_distinct_kernel<unsigned long long><<<grid_for(n), QN_THREADS, 0, ctx->stream>>>((const unsigned long long*)d_perm, d_sorted_key, n, d_th,
                                                                                                nthresholds, d_cnt);
     UQ_LAUNCH_CHECK();
-    UQ_CHECK_HIP(hipMemcpyAsync(h_counts, d_cnt, nthresholds * 8, hipMemcpyDeviceToHost, ctx->stream));
+    UQ_TRY(uq_read_back(ctx, ctx->h_pinned, d_cnt, (size_t)nthresholds * 8));
     UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(h_counts, ctx->h_pinned, (size_t)nthresholds * 8);
     return 0;
 }
 
@@ -418,8 +423,9 @@ extern "C" int uq_int_prefix_distinct(uq_ctx* ctx, const int64_t* d_val, uint64_
     UQ_LAUNCH_CHECK();
     first_seen_count_kernel<<<grid_for(range), QN_THREADS, 0, ctx->stream>>>(d_first, (uint32_t)range, d_th, nthresholds, d_cnt);
     UQ_LAUNCH_CHECK();
-    UQ_CHECK_HIP(hipMemcpyAsync(h_counts, d_cnt, nthresholds * 8, hipMemcpyDeviceToHost, ctx->stream));
+    UQ_TRY(uq_read_back(ctx, ctx->h_pinned, d_cnt, (size_t)nthresholds * 8));
     UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(h_counts, ctx->h_pinned, (size_t)nthresholds * 8);
     return 0;
 }
 
