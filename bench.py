@@ -182,6 +182,7 @@ def main():
             # (census / index / statistics of the shard's first 4 MB: small kernels, a read-back, the decisions on the host) runs
             # meanwhile on a second stream; the record index and the pack + statistics kernel are then queued behind the census
             # with the count taken on the device -- the host reads it after everything has been queued (no mid-step round trip)
+            st_q = ops.stats_new(ctx)                                    # (initialised before the census: off the critical path)
             census = ops.ChunkedCensus(ctx, d_buf)
             census.chunk(0, fastq_bytes)
             census.end_async()
@@ -192,7 +193,7 @@ def main():
                 guess.avg_record_bytes = int(1.0 / rpb)                     # tile sizing hint: the head's own records
                 ls_cap = ops.index_lines_async(ctx, d_buf, 4 * cap_reads)
                 e0.record()
-                sp = ops.pack_stats_async(ctx, d_buf, ls_cap, cap_reads, guess)
+                sp = ops.pack_stats_async(ctx, d_buf, ls_cap, cap_reads, guess, st=st_q)
                 e1.record()
                 if sp is not None:
                     # one rank: the statistics' read-back is queued (and waited for) first, the line count is there by then

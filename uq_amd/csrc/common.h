@@ -54,6 +54,7 @@ void uq_set_error(const char* fmt, ...);
 // must lie inside ctx->h_pinned), queued on the context's stream -- no copy command: under a kernel that fills the device a blit / DMA
 // copy of a few bytes was seen to wait 0.2 - 0.6 ms for its turn, an ordinary one-workgroup kernel is dispatched at once.
 int uq_read_back(uq_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
+int uq_async_read_back(uq_ctx* ctx);        // index.hip: the queued census's results (line count, overflow flags) -> pinned staging
 
 // Scratch: returns a pointer into the context's pool, growing it if needed.  A grow synchronises the
 // stream first (the old pool may still be in use by queued kernels).

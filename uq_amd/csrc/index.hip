@@ -486,7 +486,15 @@ extern "C" int uq_index_lines_async(uq_ctx* ctx, const uint8_t* d_buf, uint64_t 
     expand_list_kernel<<<(uint32_t)((nb + EXP_TILES * (IDX_THREADS / 64) - 1) / (EXP_TILES * (IDX_THREADS / 64))), IDX_THREADS, 0, ctx->stream>>>(ctx->idx_bitmap, mis, ctx->idx_partials,
                                                                                                                  nb, 0, d_line_start, ctx->d_async, capacity_lines);
     UQ_LAUNCH_CHECK();
-    // what uq_count_lines_wait hands out, on its way to the host already
+    return 0;
+}
+
+// what uq_count_lines_wait hands out, sent on its way to the host (uq_pack_stats_async queues this behind its kernel: nothing small
+// stands between the index and the pack kernel)
+int uq_async_read_back(uq_ctx* ctx) {
+    if (!ctx->async_buf || ctx->async_nbytes == 0 || ctx->async_read) return 0;
+    const uint32_t mis = (uint32_t)((uintptr_t)ctx->async_buf & 15);
+    const uint64_t nb = (((ctx->async_nbytes + mis + 15) / 16) * 16 + IDX_TILE - 1) / IDX_TILE;
     UQ_TRY(uq_read_back(ctx, ctx->h_pinned + 8000, ctx->d_async, 16));
     UQ_TRY(uq_read_back(ctx, ctx->h_pinned + 8002, ctx->idx_bitmap + nb * IDX_TILE_VECS, 4));
     ctx->async_read = true;
@@ -499,15 +507,10 @@ extern "C" int uq_count_lines_wait(uq_ctx* ctx, const uint8_t* d_buf, uint64_t n
     UQ_REQUIRE(ctx && h_nlines && h_ok, "uq_count_lines_wait: null argument");
     UQ_REQUIRE(ctx->async_buf == d_buf && ctx->async_nbytes == nbytes, "uq_count_lines_wait: not the buffer of the last uq_count_lines_end_async");
     *h_nlines = 0; *h_ok = 1;
-    ctx->async_buf = nullptr;
-    if (nbytes == 0) return 0;
-    const uint32_t mis = (uint32_t)((uintptr_t)d_buf & 15);
-    const uint64_t nb = (((nbytes + mis + 15) / 16) * 16 + IDX_TILE - 1) / IDX_TILE;
-    if (!ctx->async_read) {
-        UQ_TRY(uq_read_back(ctx, ctx->h_pinned + 8000, ctx->d_async, 16));
-        UQ_TRY(uq_read_back(ctx, ctx->h_pinned + 8002, ctx->idx_bitmap + nb * IDX_TILE_VECS, 4));
-    }
+    if (nbytes == 0) { ctx->async_buf = nullptr; return 0; }
+    UQ_TRY(uq_async_read_back(ctx));
     ctx->async_read = false;
+    ctx->async_buf = nullptr;
     UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     *h_nlines = ctx->h_pinned[8000];
     *h_ok = ctx->h_pinned[8001] == 0 && (uint32_t)ctx->h_pinned[8002] == 0;

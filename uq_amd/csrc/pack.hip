@@ -580,5 +580,6 @@ extern "C" int uq_pack_stats_async(uq_ctx* ctx, const uint8_t* d_buf, const uint
                                    uq_stats* d_stats, int* h_fused) {
     UQ_REQUIRE(d_stats && h_fused, "uq_pack_stats_async: null argument");
     UQ_REQUIRE(ctx && ctx->async_buf == d_buf, "uq_pack_stats_async: not the buffer of the last uq_count_lines_end_async");
-    return pack_impl(ctx, d_buf, d_line_start, 0, capacity_reads, h_guess, d_dna, d_qual, d_bad, d_stats, h_fused, ctx->d_async);
+    UQ_TRY(pack_impl(ctx, d_buf, d_line_start, 0, capacity_reads, h_guess, d_dna, d_qual, d_bad, d_stats, h_fused, ctx->d_async));
+    return uq_async_read_back(ctx);
 }

@@ -201,14 +201,15 @@ def pack_stats(ctx, buf, line_start, first_read, nreads, guess):
     return (dna, qual, bad, st) if fused.value else None
 
 
-def pack_stats_async(ctx, buf, line_start, capacity_reads, guess):
+def pack_stats_async(ctx, buf, line_start, capacity_reads, guess, st=None):
     """pack_stats of every read of `buf` behind ChunkedCensus.end_async() + index_lines_async: tables of capacity_reads rows (the
-    caller narrows them once wait() has told it the count).  Returns (dna, qual, bad, d_stats) or None (no fused kernel)."""
+    caller narrows them once wait() has told it the count; `st`: a stats_new() made earlier, so that its initialisation is not queued
+    between the index and the pack kernel).  Returns (dna, qual, bad, d_stats) or None (no fused kernel)."""
     t = ctx.torch
     dna = t.empty(capacity_reads * guess.dna_bytes_per_row, dtype=t.uint8, device=ctx.device)
     qual = t.empty(capacity_reads * guess.quality_bytes_per_row, dtype=t.uint8, device=ctx.device)
     bad = t.empty(1, dtype=t.int64, device=ctx.device)
-    st = stats_new(ctx)
+    if st is None: st = stats_new(ctx)
     fused = C.c_int(0)
     call('uq_pack_stats_async', ctx.h, _p(buf), _p(line_start), capacity_reads, C.byref(guess), _p(dna), _p(qual), _p(bad), _p(st), C.byref(fused))
     return (dna, qual, bad, st) if fused.value else None
