@@ -177,6 +177,7 @@ def main():
         census = None
         queued = None
         st = None
+        ls_async = None
         if not args.one_pass and not args.multi_pass:
             # the census kernel is queued first, its closing scan right behind it (the line count stays on the device); the guess
             # (census / index / statistics of the shard's first 4 MB: small kernels, a read-back, the decisions on the host) runs
@@ -191,7 +192,7 @@ def main():
                 guess, rpb = g
                 cap_reads = int(fastq_bytes * rpb * 1.02) + 1024
                 guess.avg_record_bytes = int(1.0 / rpb)                     # tile sizing hint: the head's own records
-                ls_cap = ops.index_lines_async(ctx, d_buf, 4 * cap_reads)
+                ls_cap = ls_async = ops.index_lines_async(ctx, d_buf, 4 * cap_reads)
                 e0.record()
                 sp = ops.pack_stats_async(ctx, d_buf, ls_cap, cap_reads, guess, st=st_q)
                 e1.record()
@@ -231,7 +232,10 @@ def main():
                 nlines, ls = enc.nlines, enc.line_start
             else:
                 if census is None: nlines = enc.nlines if enc is not None else ops.count_lines(ctx, d_buf)
-                ls = ops.index_lines(ctx, d_buf, nlines)              # record index
+                if census is not None and ls_async is not None and ok and nlines <= 4 * cap_reads:
+                    ls = ls_async[:nlines + 1]                        # the queued index holds (there is no fused pack kernel for this alphabet)
+                else:
+                    ls = ops.index_lines(ctx, d_buf, nlines)          # record index
                 enc = None
             nreads = nlines // 4
             if enc is not None and enc.stats is not None:
