@@ -301,12 +301,20 @@ __global__ __launch_bounds__(EM_THREADS, 4) void emit_tile_kernel(EmitGeom g, Ti
         if (tid < Rt) s_len[tid] = cur.L;
         uint32_t skd = 0, skq = 0;
         if constexpr (PACKED) {
-            if (tid < 64) {                               // wave 0 holds every length of the tile (R <= 64): running count of chunk items
-                uint32_t v = tid < Rt ? (cur.L + 14u) >> 3 : 0u;       // the most chunks a line of L characters can touch
+            if (tid < 64) {                               // wave 0 holds every offset and length of the tile (R <= 63 here / 64)
+                if constexpr (BQ != 0) {
+                    // the compile-time instances (fixed lengths, per-lane chunk mapping) need no running count of chunk items:
+                    // the array holds the records' image offsets as 32-bit numbers instead (ro() below: one LDS dword, no 64-bit
+                    // arithmetic per chunk)
+                    const unsigned long long first = __shfl(cur.off, 0, 64);
+                    if (tid <= Rt) cum[tid] = (uint32_t)(cur.off - first) + (uint32_t)((uintptr_t)(out + first) & 15);
+                } else {
+                    uint32_t v = tid < Rt ? (cur.L + 14u) >> 3 : 0u;       // running count of chunk items: the most chunks a line of L characters can touch
 #pragma unroll
-                for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(v, d, 64); if (lane >= (uint32_t)d) v += o; }
-                if (tid < R) cum[tid + 1] = v;            // R + 1 entries: lanes beyond the tile have nowhere to write
-                if (tid == 0) cum[0] = 0;
+                    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(v, d, 64); if (lane >= (uint32_t)d) v += o; }
+                    if (tid < R) cum[tid + 1] = v;            // R + 1 entries: lanes beyond the tile have nowhere to write
+                    if (tid == 0) cum[0] = 0;
+                }
             }
             skd = nr.skd; skq = nr.skq;
 #pragma unroll
@@ -341,7 +349,7 @@ __global__ __launch_bounds__(EM_THREADS, 4) void emit_tile_kernel(EmitGeom g, Ti
         }
         // record i starts at image byte ro(i); its QUAL line ends right before ro(i + 1), so its SEQ text starts at
         // ro(i + 1) - 2 L - 4 whatever the QNAME was: the three parts below need no barrier between them
-        auto ro = [&](uint32_t i) { return (uint32_t)(s_off[i] - o0) + skew; };
+        auto ro = [&](uint32_t i) { if constexpr (PACKED && BQ != 0) return cum[i]; else return (uint32_t)(s_off[i] - o0) + skew; };
         // ---- 1b: render the fields, the separators and (lane of the last field) the suffix + '\n'
         for (uint32_t idx = tid; idx < Rt * ncols; idx += EM_THREADS) {
             const uint32_t i = idx / ncols, c = idx - i * ncols;
@@ -901,6 +909,7 @@ size_t plan_tile(TileGeom& tg, uint64_t avg, const EmitGeom& g, bool packed) {
     const uint64_t per = text + 8 + 4 + 4 + 2ull * ncols + (packed ? tg.Cd + tg.Cq : 0);
     uint64_t R = ((packed ? EM_BUDGET_PACKED : EM_BUDGET_TEXT) - 256) / per;
     if (R > EM_RMAX) R = EM_RMAX;
+    if (packed && R > EM_RMAX - 1) R = EM_RMAX - 1;           // wave 0 holds the tile's R + 1 record offsets
     if (packed) while (R > 0 && (R * tg.Cd + 48 > DE_NVD * EM_THREADS * 16u || R * tg.Cq + 48 > DE_NVQ * EM_THREADS * 16u)) --R;
     if (packed && tg.fa.fast && !tg.variable && tg.RS && R > tg.RS) R -= R % tg.RS;      // whole steps of the fixed-length chunk loop
     const bool fits = R >= 1;
