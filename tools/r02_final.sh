@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round-2 closing records -> gpurun_out/r02u/: full GPU suite, bench line (+ rocprofv3 kernel stats of the same command), table kernels at
+# Round-2 closing records -> gpurun_out/r02y/: full GPU suite, bench line (+ rocprofv3 kernel stats of the same command), table kernels at
 # BASELINE configs[2] size, decode kernels, CLI end to end.
-R=${GRAFT_REPO_ROOT:-$PWD}; OUT=$R/gpurun_out/r02u; mkdir -p $OUT; cd $R
+R=${GRAFT_REPO_ROOT:-$PWD}; OUT=$R/gpurun_out/r02y; mkdir -p $OUT; cd $R
 timeout -k 10 600 python -m pytest tests -m gpu -q --durations=10 > $OUT/gpu_suite.log 2>&1; echo "suite rc=$?"; tail -3 $OUT/gpu_suite.log
 python3 bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; tail -c 400 $OUT/bench.json; echo
 python3 bench.py --steps 20 --warmup 5 --one-pass --cpu-sample 0 > $OUT/bench_one_pass.json 2>/dev/null
