@@ -308,21 +308,21 @@ def test_decode_fastq_is_the_input_and_the_two_pass_text(ctx, name, n, length, k
 
 
 @pytest.mark.parametrize('variable', [False, True], ids=['fixed', 'variable'])
-@pytest.mark.parametrize('with_n', [False, True], ids=['acgt', 'n-trick'])
+@pytest.mark.parametrize('with_n', [False, True, 'six'], ids=['acgt', 'n-trick', 'six-bases'])
 @pytest.mark.parametrize('nq', [3, 4, 6, 12, 20, 41, 70], ids=lambda v: 'q%d' % v)
 def test_decode_quality_widths(ctx, nq, with_n, variable):
     """Tables with the lookup-free alphabet at every quality width (2 .. 7 bits): uq_decode_fastq runs the instance of the tile kernel
     (fixed lengths) or of the streaming kernel (variable lengths) compiled for that width and N-trick (2 .. 6 bits) or the run-time
-    one (7); several tiles, a ragged last one."""
+    one (7); several tiles, a ragged last one.  'six-bases': a 3-bit base alphabet (ACGTRY), lookup-free too (v_perm over eight characters)."""
     from uq_amd import qname
-    rng = np.random.default_rng(nq * 2 + with_n)
+    rng = np.random.default_rng(nq * 2 + (with_n is True))
     n = 3001
     recs = []
     for i in range(n):
         L = int(rng.integers(1, 161)) if variable else 151
-        seq = rng.choice(np.frombuffer(b'ACGT', np.uint8), L)
+        seq = rng.choice(np.frombuffer(b'ACGTRY' if with_n == 'six' else b'ACGT', np.uint8), L)
         q = rng.integers(40, 40 + nq, L).astype(np.uint8)
-        if with_n:
+        if with_n is True:
             at = rng.random(L) < 0.02
             seq[at] = ord('N'); q[at] = 35
         recs.append(b'@x%d:%d/1\n' % (i, int(rng.integers(0, 99999))) + bytes(seq) + b'\n+\n' + bytes(q) + b'\n')
@@ -330,7 +330,7 @@ def test_decode_quality_widths(ctx, nq, with_n, variable):
     hls = oracle_c.index_lines(host)
     st = oracle_c.stats(host, hls, 0, n)
     d = O.decide(O.histogram_to_static_qualities(st['counts'], st['first_seen']), st['len_min'], st['len_max'])
-    assert d['bits_per_base'] == 2 and bool(d['variable_read_lengths']) == variable and bool(d['N_qual']) == with_n
+    assert d['bits_per_base'] == (3 if with_n == 'six' else 2) and bool(d['variable_read_lengths']) == variable and bool(d['N_qual']) == (with_n is True)
     rd, rq, _ = oracle_c.pack(host, hls, 0, n, d['bases'], d['qualities'], d['N_qual'], d['bits_per_base'], d['bits_per_quality'],
                               d['variable_read_lengths'], d['dna_bytes_per_row'], d['quality_bytes_per_row'])
     prefix, suffix, separators, columns, arrays = qname.analyse(qname.qname_lines(host, hls, n))

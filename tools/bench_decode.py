@@ -37,6 +37,7 @@ def main():
     ap.add_argument('--var-min', type=int, default=0, help='variable read lengths from this minimum (0 = fixed)')
     ap.add_argument('--n-rate', type=int, default=0)
     ap.add_argument('--reps', type=int, default=5)
+    ap.add_argument('--notricks', action='store_true', help='no N-trick: N stays a base (3-bit DNA), the alphabets go through the tables')
     ap.add_argument('--no-check', action='store_true', help='timing experiments with variant libraries (UQ_LIB_PATH): a wrong text is reported, not fatal')
     ap.add_argument('--only-fused', action='store_true', help='time uq_decode_fastq only (clean kernel / counter profiles)')
     args = ap.parse_args()
@@ -46,7 +47,7 @@ def main():
     d_buf = ops.synth_fastq(ctx, spec, 0, n)
     nl = ops.count_lines(ctx, d_buf); ls = ops.index_lines(ctx, d_buf, nl)
     st = ops.stats_new(ctx); ops.stats_accumulate(ctx, st, d_buf, ls, 0, n); hs = ops.stats_fetch(ctx, st)
-    d = analysis.decide_from_counts(hs.counts, hs.len_min, hs.len_max)
+    d = analysis.decide_from_stats(hs, notricks=args.notricks)
     p = ops.make_pack_params(d['bases'], d['qualities'], d['N_qual'], d['bits_per_base'], d['bits_per_quality'], d['variable_read_lengths'],
                              d['dna_bytes_per_row'], d['quality_bytes_per_row'], d['dna_max'], hs.max_record_bytes)
     dna, qual, bad = ops.pack(ctx, d_buf, ls, 0, n, p)

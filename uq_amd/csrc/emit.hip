@@ -407,8 +407,9 @@ __global__ __launch_bounds__(EM_THREADS, 4) void emit_tile_kernel(EmitGeom g, Ti
                 auto seq8 = [&](uint32_t r, uint32_t L, int32_t p0) {        // characters p0 .. p0 + 7 of read r's SEQ line
                     const int32_t t0 = (int32_t)L - 8 - p0;
                     uint32_t clo, chi;
-                    dna_codes8(tile, od + __umul24(r, tg.Cd), t0, clo, chi);
-                    uint32_t blo = __builtin_amdgcn_perm(0u, fa.base_tab, clo), bhi = __builtin_amdgcn_perm(0u, fa.base_tab, chi);
+                    if (fa.bd == 2) dna_codes8(tile, od + __umul24(r, tg.Cd), t0, clo, chi);
+                    else qual_codes8<3>(tile, od + __umul24(r, tg.Cd), t0, clo, chi);       // 3-bit bases: rows laid out like quality rows
+                    uint32_t blo = __builtin_amdgcn_perm(fa.base_tab_hi, fa.base_tab, clo), bhi = __builtin_amdgcn_perm(fa.base_tab_hi, fa.base_tab, chi);
                     if (BQ ? HASN : fa.has_n != 0) {
                         uint32_t qlo, qhi;
                         if constexpr (BQ != 0) qual_codes8<BQ>(tile, oq + __umul24(r, tg.Cq), t0, qlo, qhi);
@@ -582,10 +583,11 @@ template <int BQ, bool HASN>
 __device__ __forceinline__ void group_text(const uint8_t* tile, const StreamGeom& sg2, uint32_t endd, uint32_t endq, int32_t t0, uint64_t& vb, uint64_t& vq) {
     const FastAlphabet& fa = sg2.fa;
     uint32_t clo, chi, qlo, qhi;
-    dna_codes8(tile, endd, t0, clo, chi);
+    if (fa.bd == 2) dna_codes8(tile, endd, t0, clo, chi);
+    else qual_codes8<3>(tile, endd, t0, clo, chi);                   // 3-bit bases: rows laid out like quality rows
     if constexpr (BQ != 0) qual_codes8<BQ>(tile, endq, t0, qlo, qhi);
     else qual_codes8(sg2.bq, tile, endq, t0, qlo, qhi);
-    uint32_t blo = __builtin_amdgcn_perm(0u, fa.base_tab, clo), bhi = __builtin_amdgcn_perm(0u, fa.base_tab, chi);
+    uint32_t blo = __builtin_amdgcn_perm(fa.base_tab_hi, fa.base_tab, clo), bhi = __builtin_amdgcn_perm(fa.base_tab_hi, fa.base_tab, chi);
     if (BQ ? HASN : fa.has_n != 0) {
         const uint32_t mlo = ~nonzero_bytes(qlo ^ fa.n_code4), mhi = ~nonzero_bytes(qhi ^ fa.n_code4);
         blo = bfi(mlo, fa.n_char4, blo); bhi = bfi(mhi, fa.n_char4, bhi);

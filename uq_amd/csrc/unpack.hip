@@ -325,7 +325,7 @@ extern "C" int uq_unpack(uq_ctx* ctx, const uint8_t* d_dna, const uint8_t* d_qua
     {
         // is this alphabet one the lookup-free path decodes?  (anything else: the table path, same results)
         const FastAlphabet a = fast_alphabet(hp);
-        g.fast = a.fast; g.base_tab = a.base_tab; g.qmin4 = a.qmin4; g.q_over = a.q_over; g.has_n = a.has_n; g.n_code4 = a.n_code4; g.n_char4 = a.n_char4;
+        g.fast = a.fast && a.bd == 2; g.base_tab = a.base_tab; g.qmin4 = a.qmin4; g.q_over = a.q_over; g.has_n = a.has_n; g.n_code4 = a.n_code4; g.n_char4 = a.n_char4;
     }
     // the pipelined kernel: tiles of R reads within ~31 KiB of LDS (five workgroups per CU) and the register budget
     uint32_t Rp = (31 * 1024) / per_read;
