@@ -211,3 +211,32 @@ def test_integration_md_snippets_match_the_binding():
     for name in re.findall(r'\b(uq_\w+)\s*\(', hdr):
         if name in _lib.SIGNATURES or name == 'uq_last_error':
             assert '`%s`' % name in doc or '`%s' % name in doc or name in doc, name + ' missing from INTEGRATION.md'
+
+
+def test_decisions_from_the_nonzero_counters_equal_the_dense_ones():
+    """analysis.decide_from_pairs (what the product feeds from uq_stats_fetch_compact: the non-zero (base, quality) counters as a list, in
+    any order) against the dense 256 x 256 form on random tables: N-trick candidates (one quality only), several of them ordered by first
+    occurrence, counts beyond 2^32, --notricks / --pad; and HostStats built from the compact record gives the same dense table back."""
+    import numpy as np
+    from uq_amd import analysis, ops
+    rng = np.random.default_rng(7)
+    for trial in range(200):
+        c = np.zeros((256, 256), np.int64)
+        for b in rng.choice(256, int(rng.integers(1, 7)), replace=False):
+            k = int(rng.integers(1, 3)) if rng.random() < 0.4 else int(rng.integers(2, 60))
+            for q in rng.choice(np.arange(33, 120), k, replace=False): c[b][q] = int(rng.integers(1, 10 ** 12))
+        fs = rng.permutation(256)
+        flat = c.reshape(-1); keys = np.flatnonzero(flat); perm = rng.permutation(len(keys))
+        for kw in (dict(), dict(notricks=True), dict(pad=True)):
+            a = analysis.decide_from_counts(c, 10, 10 + trial % 2, first_seen=fs, **kw)
+            b = analysis.decide_from_pairs(keys[perm], flat[keys][perm], 10, 10 + trial % 2, first_seen=fs, **kw)
+            assert a == b
+            assert a['base_distribution'] == {chr(x): int(c[x].sum()) for x in np.flatnonzero(c.sum(axis=1))}
+        raw = np.zeros(1, dtype=ops.STATS_COMPACT_DTYPE)
+        n = min(len(keys), ops.STATS_COMPACT_CAP)
+        raw[0]['n'] = n; raw[0]['key'][:n] = keys[perm][:n]; raw[0]['count'][:n] = flat[keys][perm][:n]
+        raw[0]['len_min'] = 10; raw[0]['len_max'] = 11; raw[0]['bad_plus'] = ops.UQ_NONE; raw[0]['bad_len'] = ops.UQ_NONE
+        hs = ops.HostStats(raw[0])
+        if n == len(keys):
+            assert np.array_equal(hs.counts.astype(np.int64), c)
+            assert analysis.decide_from_stats(hs, first_seen=fs) == analysis.decide_from_counts(c, 10, 11, first_seen=fs)
