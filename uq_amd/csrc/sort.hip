@@ -75,12 +75,6 @@ __global__ void iota_kernel(uint32_t* __restrict__ v, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * ST + threadIdx.x;
     if (i < n) v[i] = (uint32_t)i;
 }
-__global__ void heads_first32_kernel(const uint32_t* __restrict__ keys, uint64_t n, uint8_t* __restrict__ heads) {
-    uint64_t j = (uint64_t)blockIdx.x * ST + threadIdx.x;
-    if (j >= n) return;
-    heads[j] = (j == 0 || keys[j] != keys[j - 1]) ? 1 : 0;
-}
-
 __global__ void heads_first_kernel(const uint64_t* __restrict__ keys, uint64_t n, uint8_t* __restrict__ heads) {
     uint64_t j = (uint64_t)blockIdx.x * ST + threadIdx.x;
     if (j >= n) return;
@@ -191,6 +185,34 @@ __global__ __launch_bounds__(ST) void active_count_kernel(const uint8_t* __restr
     __syncthreads();
     if (threadIdx.x == 0) { counts[2 * (uint64_t)blockIdx.x] = sa[0] + sa[1] + sa[2] + sa[3]; counts[2 * (uint64_t)blockIdx.x + 1] = sh[0] + sh[1] + sh[2] + sh[3]; }
 }
+// after the 32-bit round 0, in one pass over the sorted keys: the group-head flags (two copies: segment_sort_kernel reads one and
+// writes the other) and the per-block counters of active_count_kernel
+__global__ __launch_bounds__(ST) void heads32_count_kernel(const uint32_t* __restrict__ keys, uint64_t n, uint8_t* __restrict__ heads,
+                                                           uint8_t* __restrict__ flags, uint32_t* __restrict__ counts) {
+    __shared__ uint32_t sa[ST / 64], sh[ST / 64];
+    const uint64_t j0 = (uint64_t)blockIdx.x * CB + (uint64_t)threadIdx.x * 4;
+    uint32_t k[6];                                   // keys j0 - 1 .. j0 + 4
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { const uint64_t j = j0 + i; k[i] = (j >= 1 && j - 1 < n) ? keys[j - 1] : 0u; }
+    uint32_t a = 0, h = 0, packed = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint64_t j = j0 + i;
+        if (j >= n) break;
+        const bool hd = j == 0 || k[i + 1] != k[i];
+        const bool next_open = j + 1 < n && k[i + 2] == k[i + 1];
+        const bool seg = hd && next_open;
+        a += (seg || !hd) ? 1u : 0u; h += seg ? 1u : 0u;
+        packed |= (hd ? 1u : 0u) << (8 * i);
+    }
+    if (j0 + 4 <= n) { *(uint32_t*)(heads + j0) = packed; *(uint32_t*)(flags + j0) = packed; }      // (j0 is a multiple of 4, the arrays 16-byte aligned)
+    else for (int i = 0; i < 4 && j0 + i < n; ++i) { heads[j0 + i] = (uint8_t)(packed >> (8 * i)); flags[j0 + i] = (uint8_t)(packed >> (8 * i)); }
+    a = wave_sum(a); h = wave_sum(h);
+    if (lane_id() == 0) { sa[threadIdx.x >> 6] = a; sh[threadIdx.x >> 6] = h; }
+    __syncthreads();
+    if (threadIdx.x == 0) { counts[2 * (uint64_t)blockIdx.x] = sa[0] + sa[1] + sa[2] + sa[3]; counts[2 * (uint64_t)blockIdx.x + 1] = sh[0] + sh[1] + sh[2] + sh[3]; }
+}
+
 // first positions of the open groups, in order (offs as below)
 __global__ __launch_bounds__(ST) void segment_starts_kernel(const uint8_t* __restrict__ heads, const unsigned long long* __restrict__ offs, uint64_t n,
                                                             uint32_t* __restrict__ seg_start) {
@@ -346,14 +368,11 @@ int sort_rows_core(uq_ctx* ctx, const uint8_t* table, uint64_t n, uint32_t C, ui
         else {
             UQ_TRY(radix_sort_pairs32(ctx, k32a, d_perm, k32b, valsB, n, 0, 32, rws, &alt, h_hist, 1));
             if (alt) UQ_CHECK_HIP(hipMemcpyAsync(d_perm, valsB, n * 4, hipMemcpyDeviceToDevice, s));
-            heads_first32_kernel<<<blocks_for(n), ST, 0, s>>>(alt ? k32b : k32a, n, heads);
-            UQ_LAUNCH_CHECK();
             // the groups that tie on the prefix are short (colliding pairs, duplicates): a lane sorts each by whole rows
             uint8_t* flags = b + o_heads2;
-            UQ_CHECK_HIP(hipMemcpyAsync(flags, heads, n, hipMemcpyDeviceToDevice, s));
             const uint64_t ncb0 = (n + CB - 1) / CB;
             uint32_t* bcnt0 = apos;
-            active_count_kernel<<<(uint32_t)ncb0, ST, 0, s>>>(heads, n, bcnt0);
+            heads32_count_kernel<<<(uint32_t)ncb0, ST, 0, s>>>(alt ? k32b : k32a, n, heads, flags, bcnt0);
             UQ_LAUNCH_CHECK();
             UQ_TRY(uq_scan_exclusive_u64(ctx, (const uint64_t*)bcnt0, (uint64_t*)bcnt0, ncb0, tot));
             segment_starts_kernel<<<(uint32_t)ncb0, ST, 0, s>>>(heads, (const unsigned long long*)bcnt0, n, pos);
