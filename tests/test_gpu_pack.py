@@ -581,3 +581,40 @@ def test_queued_census_index_pack_equals_the_plain_calls(ctx, length, kw):
     with pytest.raises(Exception):
         ops.index_lines_async(ctx, other, 1000)
     assert cen.wait()[0] == nl
+
+
+@pytest.mark.parametrize('bases', [b'ACGNT', b'ACGTRYKM', b'ACGTacg', b'ACGTBDH', b'ACGTIJ'], ids=lambda b: b.decode())
+def test_pack_three_bit_alphabets(ctx, bases):
+    """3-bit base alphabets: the lookup-free pack path when three bits of the characters tell the bases apart ((c >> s) & 7 for
+    some s: ACGNT, ACGTRYKM, ACGTacg ...), the table path when no shift does (ACGTIJ: I and J share every such index with a base ...);
+    fixed and variable lengths, a stray character reported, against the oracle's pack."""
+    rng = np.random.default_rng(len(bases))
+    for variable in (False, True):
+        n = 4000
+        recs = []
+        for i in range(n):
+            L = int(rng.integers(1, 120)) if variable else 101
+            seq = rng.choice(np.frombuffer(bases, np.uint8), L)
+            q = rng.integers(40, 80, L).astype(np.uint8)
+            recs.append(b'@r%d:%d\n' % (i, i % 7) + bytes(seq) + b'\n+\n' + bytes(q) + b'\n')
+        host = np.frombuffer(b''.join(recs), dtype=np.uint8)
+        d_buf = ctx.to_device(host)
+        nlines, ls = _index(ctx, d_buf)
+        st = ops.stats_new(ctx); ops.stats_accumulate(ctx, st, d_buf, ls, 0, n); hs = ops.stats_fetch(ctx, st)
+        from uq_amd import analysis
+        d = analysis.decide_from_stats(hs, notricks=True)
+        assert d['bits_per_base'] == 3 and d['bases'] == ''.join(sorted(bases.decode()))
+        p = ops.make_pack_params(d['bases'], d['qualities'], d['N_qual'], d['bits_per_base'], d['bits_per_quality'], d['variable_read_lengths'],
+                                 d['dna_bytes_per_row'], d['quality_bytes_per_row'], d['dna_max'], hs.max_record_bytes)
+        dna, qual, bad = ops.pack(ctx, d_buf, ls, 0, n, p)
+        assert ops.bad_index(bad) is None
+        hls = oracle_c.index_lines(host)
+        rd, rq, _ = oracle_c.pack(host, hls, 0, n, d['bases'], d['qualities'], d['N_qual'], d['bits_per_base'], d['bits_per_quality'],
+                                  d['variable_read_lengths'], d['dna_bytes_per_row'], d['quality_bytes_per_row'])
+        assert np.array_equal(ctx.to_numpy(dna).reshape(n, -1), rd) and np.array_equal(ctx.to_numpy(qual).reshape(n, -1), rq)
+    # a character outside the alphabet (one that shares its three bits with a base): named, not packed as that base
+    bad_host = host.copy()
+    at = int(hls[4 * 1234 + 1]) + 0
+    bad_host[at] = ord('Z') if ord('Z') not in bases else ord('X')
+    dna, qual, bad = ops.pack(ctx, ctx.to_device(bad_host), ls, 0, n, p)
+    assert ops.bad_index(bad) == 1234

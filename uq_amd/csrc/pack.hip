@@ -49,6 +49,9 @@ struct PackGeom {
     // fast path (bases == "ACGT", qualities a contiguous ASCII range below 128, at most one N-trick base)
     uint32_t q_addlo, q_addhi;   // (0x80 - qmin) and (0x80 - qmin - nq), replicated in 4 bytes
     uint32_t n_char, n_code;     // the N-trick base and its quality code, replicated in 4 bytes
+    // 3-bit bases on the fast path: (character >> h_shift) & 7 is different for every base of the alphabet (found by the host);
+    // i2c = code of each such index, c2c = character of each code, eight bytes each (what v_perm_b32 selects from)
+    uint32_t h_shift, i2c_lo, i2c_hi, c2c_lo, c2c_hi;
 };
 
 // four ACGT characters -> four 2-bit codes (A0 C1 G2 T3), one per byte
@@ -221,8 +224,15 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && NTRICK) ? 4 : 5) void pack_ti
                     uint32_t ad0, ad1, aq0, aq1;      // 4 symbols each; *0 = the more significant half
                     bool generic = !FAST;
                     if (FAST) {
-                        uint32_t c0 = acgt_codes(b_lo), c1 = acgt_codes(b_hi);
-                        const uint32_t e0 = acgt_chars(c0) ^ b_lo, e1 = acgt_chars(c1) ^ b_hi;      // non-zero byte = not ACGT
+                        uint32_t c0, c1, e0, e1;                     // codes, and (non-zero byte) = not a base of the alphabet
+                        if constexpr (BD == 2) {
+                            c0 = acgt_codes(b_lo); c1 = acgt_codes(b_hi);
+                            e0 = acgt_chars(c0) ^ b_lo; e1 = acgt_chars(c1) ^ b_hi;
+                        } else {                                     // up to eight bases told apart by three bits of their characters
+                            c0 = __builtin_amdgcn_perm(g.i2c_hi, g.i2c_lo, (b_lo >> g.h_shift) & 0x07070707u);
+                            c1 = __builtin_amdgcn_perm(g.i2c_hi, g.i2c_lo, (b_hi >> g.h_shift) & 0x07070707u);
+                            e0 = __builtin_amdgcn_perm(g.c2c_hi, g.c2c_lo, c0) ^ b_lo; e1 = __builtin_amdgcn_perm(g.c2c_hi, g.c2c_lo, c1) ^ b_hi;
+                        }
                         uint32_t u0 = q_lo + g.q_addlo, u1 = q_hi + g.q_addlo;
                         uint32_t bq0 = (q_lo | (q_lo + g.q_addhi) | ~u0) & 0x80808080u;
                         uint32_t bq1 = (q_hi | (q_hi + g.q_addhi) | ~u1) & 0x80808080u;
@@ -412,7 +422,7 @@ typedef void (*PackKernel)(const uint8_t*, const uint64_t*, uint64_t, uint64_t, 
 
 template <int BD, int BQ>
 PackKernel pick_nt(bool ntrick, bool fast) {
-    if (BD == 2 && fast) return ntrick ? pack_tile_kernel<2, BQ, true, true, false> : pack_tile_kernel<2, BQ, false, true, false>;
+    if ((BD == 2 || BD == 3) && fast) return ntrick ? pack_tile_kernel<(BD == 3 ? 3 : 2), BQ, true, true, false> : pack_tile_kernel<(BD == 3 ? 3 : 2), BQ, false, true, false>;
     return ntrick ? pack_tile_kernel<BD, BQ, true, false, false> : pack_tile_kernel<BD, BQ, false, false, false>;
 }
 
@@ -526,7 +536,8 @@ static int pack_impl(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_s
     if (P > g.G) P = g.G;
     if (P < 1) P = 1;
     g.P = P; g.magicP = magic_u32(P);
-    // fast path: bases == "ACGT", qualities one contiguous ASCII range below 128, at most one N-trick base
+    // fast path: bases == "ACGT" (2 bits) or up to eight bases that three bits of their characters tell apart (3 bits), qualities one
+    // contiguous ASCII range below 128, at most one N-trick base
     bool fast = bd == 2 && hp->dna_code['A'] == 0 && hp->dna_code['C'] == 1 && hp->dna_code['G'] == 2 && hp->dna_code['T'] == 3;
     int nbases = 0, nq = 0, qmin = 256, qmaxc = -1, ntrick_bases = 0, nchar = 0;
     for (int i = 0; i < 256; ++i) {
@@ -534,8 +545,31 @@ static int pack_impl(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_s
         if (hp->qual_code[i] >= 0) { ++nq; if (i < qmin) qmin = i; if (i > qmaxc) qmaxc = i; }
         if (hp->dna_code[i] < 0 && hp->n_qual[i] >= 0) { ++ntrick_bases; nchar = i; }
     }
-    fast = fast && nbases == 4 && nq >= 1 && qmaxc - qmin + 1 == nq && qmaxc < 128 && ntrick_bases <= 1 &&
-           (ntrick_bases == 0 || hp->n_qual[nchar] < 128);
+    g.h_shift = g.i2c_lo = g.i2c_hi = g.c2c_lo = g.c2c_hi = 0;
+    bool fast3 = false;
+    if (bd == 3 && nbases >= 1 && nbases <= 8) {
+        for (uint32_t sh = 0; sh <= 4 && !fast3; ++sh) {
+            uint8_t i2c[8], c2c[8]; bool used[8] = {false, false, false, false, false, false, false, false};
+            memset(i2c, 0, 8); memset(c2c, 0, 8);
+            bool ok = true;
+            for (int ch = 1; ch < 128 && ok; ++ch) {
+                const int code = hp->dna_code[ch];
+                if (code < 0) continue;
+                const uint32_t idx = ((uint32_t)ch >> sh) & 7u;
+                if (used[idx] || code > 7) ok = false;
+                else { used[idx] = true; i2c[idx] = (uint8_t)code; c2c[code] = (uint8_t)ch; }
+            }
+            for (int ch = 128; ch < 256 && ok; ++ch) if (hp->dna_code[ch] >= 0) ok = false;      // (the byte masks work on 7-bit characters)
+            // an index no base owns must not pass for a base: it maps to code 0, whose character then differs from the input --
+            // unless the input IS that character with another index, which cannot be (one index per character)
+            if (ok) {
+                fast3 = true; g.h_shift = sh;
+                memcpy(&g.i2c_lo, i2c, 4); memcpy(&g.i2c_hi, i2c + 4, 4); memcpy(&g.c2c_lo, c2c, 4); memcpy(&g.c2c_hi, c2c + 4, 4);
+            }
+        }
+    }
+    fast = ((fast && nbases == 4) || fast3) && nq >= 1 && qmaxc - qmin + 1 == nq && qmaxc < 128 && ntrick_bases <= 1 &&
+           (ntrick_bases == 0 || (hp->n_qual[nchar] < 128 && nchar < 128));
     if (fast)
         for (int i = qmin; i <= qmaxc; ++i) fast = fast && hp->qual_code[i] == i - qmin;
     g.q_addlo = g.q_addhi = g.n_char = g.n_code = 0;
@@ -544,7 +578,7 @@ static int pack_impl(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_s
         g.q_addhi = 0x01010101u * (uint32_t)(0x80 - qmin - nq);
         if (ntrick_bases == 1) { g.n_char = 0x01010101u * (uint32_t)nchar; g.n_code = 0x01010101u * (uint32_t)hp->n_qual[nchar]; }
     }
-    if (d_stats && (!fast || bq > 6)) return 0;  // the fused kernels exist for the lookup-free path with a bin per byte (<= 64 qualities) only
+    if (d_stats && (!fast || bd != 2 || bq > 6)) return 0;  // the fused kernels exist for the 2-bit lookup-free path with a bin per byte (<= 64 qualities) only
     const size_t lds = 16 + (size_t)g.stage_bytes + g.out_bytes + (4 * R + 4) * 4 + 3 * 512 + (d_stats ? PKS_WORDS * 4 : 0);
     UQ_REQUIRE(lds <= 160 * 1024, "uq_pack: tile needs %zu bytes of LDS", lds);
     const uint64_t tiles = (nreads + R - 1) / R;
