@@ -49,6 +49,7 @@ struct PackGeom {
     // fast path (bases == "ACGT", qualities a contiguous ASCII range below 128, at most one N-trick base)
     uint32_t q_addlo, q_addhi;   // (0x80 - qmin) and (0x80 - qmin - nq), replicated in 4 bytes
     uint32_t n_char, n_code;     // the N-trick base and its quality code, replicated in 4 bytes
+    uint32_t n_qchar;            // the quality CHARACTER that code stands for (the one the N-trick base occurs with), replicated
     // 3-bit bases on the fast path: (character >> h_shift) & 7 is different for every base of the alphabet (found by the host);
     // i2c = code of each such index, c2c = character of each code, eight bytes each (what v_perm_b32 selects from)
     uint32_t h_shift, i2c_lo, i2c_hi, c2c_lo, c2c_hi;
@@ -260,13 +261,14 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && NTRICK) ? 4 : 5) void pack_ti
                                     atomicAdd((uint32_t*)(hb + (((bin1 >> (8 * k)) & 0xFFu) * (4 * PKS_COPIES))), 1u);
                                 }
                                 if (j0 < 0) fill_pairs += (uint32_t)(-j0);
-                                if (NTRICK && (e0 | e1)) {           // the N-trick base's own pairs, by quality character
+                                if (NTRICK && (e0 | e1)) {
+                                    // the N-trick base's own pairs: the guess says it occurs with ONE quality character (that is what
+                                    // makes it an N-trick base); positions that bear it are counted in a register, byte-parallel, and a
+                                    // position with any other quality makes the guess wrong: incomplete, the exact pass decides
                                     const uint32_t m0 = nonzero_bytes(e0), m1 = nonzero_bytes(e1);
-#pragma unroll
-                                    for (int k = 0; k < 4; ++k) {
-                                        if ((m0 >> (8 * k)) & 1u) { atomicAdd(&cnt_tab[256 * PKS_COPIES + ((q_lo >> (8 * k)) & 0x7Fu)], 1u); ++n_pairs; }
-                                        if ((m1 >> (8 * k)) & 1u) { atomicAdd(&cnt_tab[256 * PKS_COPIES + ((q_hi >> (8 * k)) & 0x7Fu)], 1u); ++n_pairs; }
-                                    }
+                                    const uint32_t ne0 = nonzero_bytes(q_lo ^ g.n_qchar), ne1 = nonzero_bytes(q_hi ^ g.n_qchar);
+                                    n_pairs += (uint32_t)__popc(m0 & 0x01010101u) + (uint32_t)__popc(m1 & 0x01010101u);
+                                    if ((m0 & ne0) | (m1 & ne1)) incomplete = true;
                                 }
                             }
                         }
@@ -361,7 +363,10 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && NTRICK) ? 4 : 5) void pack_ti
         // fills were counted as (code 0, code 0), N-trick positions as (code 0, n_code): take them off their bins (any copy: the
         // flush sums the copies modulo 2^32)
         if (fill_pairs) atomicSub(&cnt_tab[lane_id() & (PKS_COPIES - 1)], fill_pairs);
-        if (NTRICK && n_pairs) atomicSub(&cnt_tab[((g.n_code & 0xFFu) * PKS_COPIES) + (lane_id() & (PKS_COPIES - 1))], n_pairs);
+        if (NTRICK && n_pairs) {
+            atomicSub(&cnt_tab[((g.n_code & 0xFFu) * PKS_COPIES) + (lane_id() & (PKS_COPIES - 1))], n_pairs);
+            atomicAdd(&cnt_tab[256 * PKS_COPIES], n_pairs);       // ... and onto the N-trick base's own counter
+        }
         __syncthreads();
         const uint32_t qmin = 0x80u - (g.q_addlo & 0xFFu);
         {
@@ -372,9 +377,9 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && NTRICK) ? 4 : 5) void pack_ti
             const uint32_t base = (0x54474341u >> (8 * (bin >> 6))) & 0xFFu;                  // "ACGT"[code]
             if (v) atomicAdd((unsigned long long*)&st->counts[base * 256 + qmin + (bin & 63u)], (unsigned long long)v);
         }
-        if (NTRICK && tid < 128) {
-            const uint32_t v = cnt_tab[256 * PKS_COPIES + tid];
-            if (v) atomicAdd((unsigned long long*)&st->counts[(g.n_char & 0xFFu) * 256 + tid], (unsigned long long)v);
+        if (NTRICK && tid == 0) {
+            const uint32_t v = cnt_tab[256 * PKS_COPIES];
+            if (v) atomicAdd((unsigned long long*)&st->counts[(g.n_char & 0xFFu) * 256 + (g.n_qchar & 0xFFu)], (unsigned long long)v);
         }
         acc.flush(st, first);
         if (incomplete) st->reserved = 1;
@@ -572,12 +577,16 @@ static int pack_impl(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_s
            (ntrick_bases == 0 || (hp->n_qual[nchar] < 128 && nchar < 128));
     if (fast)
         for (int i = qmin; i <= qmaxc; ++i) fast = fast && hp->qual_code[i] == i - qmin;
-    g.q_addlo = g.q_addhi = g.n_char = g.n_code = 0;
+    g.q_addlo = g.q_addhi = g.n_char = g.n_code = g.n_qchar = 0;
     if (fast) {
         g.q_addlo = 0x01010101u * (uint32_t)(0x80 - qmin);
         g.q_addhi = 0x01010101u * (uint32_t)(0x80 - qmin - nq);
-        if (ntrick_bases == 1) { g.n_char = 0x01010101u * (uint32_t)nchar; g.n_code = 0x01010101u * (uint32_t)hp->n_qual[nchar]; }
+        if (ntrick_bases == 1) {
+            g.n_char = 0x01010101u * (uint32_t)nchar; g.n_code = 0x01010101u * (uint32_t)hp->n_qual[nchar];
+            g.n_qchar = 0x01010101u * (uint32_t)(qmin + hp->n_qual[nchar]);       // (a code beyond the alphabet -- Q9 -- has no fused kernel: below)
+        }
     }
+    if (d_stats && ntrick_bases == 1 && hp->n_qual[nchar] >= nq) return 0;    // the N-trick code is no quality of the alphabet (Q9): exact kernels only
     if (d_stats && (!fast || bd != 2 || bq > 6)) return 0;  // the fused kernels exist for the 2-bit lookup-free path with a bin per byte (<= 64 qualities) only
     const size_t lds = 16 + (size_t)g.stage_bytes + g.out_bytes + (4 * R + 4) * 4 + 3 * 512 + (d_stats ? PKS_WORDS * 4 : 0);
     UQ_REQUIRE(lds <= 160 * 1024, "uq_pack: tile needs %zu bytes of LDS", lds);
