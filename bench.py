@@ -15,7 +15,7 @@ One step = one pass of the hot path over the shard, everything from the raw byte
     -> [N > 1: all-reduce of the statistics over RCCL, the path's only exchange without --sort]
     -> alphabet / N-trick / bit-width decisions on the host from the WHOLE shard's statistics (uq.py:448-545); the tables are
        kept iff they equal the guess, else uq_pack runs with the real ones (never on this workload).
-    (--multi-pass: round 1's step, statistics and pack as separate kernels = three reads; --one-pass: uq_encode_stream, one read.)
+    (--multi-pass: round 1's step, statistics and pack as separate kernels = three reads.)
 The QNAME passes (on the device in the CLI, tools/bench_e2e.py times them) are not part of this
 step.  `value` = FASTQ bytes of all ranks / time, MAX over ranks.
 Besides the contract fields the JSON line carries `roofline` (pack kernel, HIP-event timed inside the
@@ -35,9 +35,6 @@ sys.path.insert(0, HERE)
 
 SEED = 20261003 + 2
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-
-
-STATS_RESERVED_OFFSET = 65536 * 8 + 8 + 8 + 4 + 4 + 4      # byte offset of uq_stats.reserved (include/uqhip.h)
 
 
 def host_decide(hs, notricks=False, pad=False):
@@ -101,10 +98,6 @@ def main():
     ap.add_argument('--multi-pass', action='store_true',
                     help='round 1\'s step: census -> index -> statistics -> decisions -> pack, three reads of the stream (the default '
                          'counts the statistics inside the pack kernel: two reads)')
-    ap.add_argument('--one-pass', action='store_true',
-                    help='uq_encode_stream: census + record index + statistics + speculative pack (decisions guessed from the shard\'s first '
-                         '65536 reads, verified against the whole shard\'s statistics) in ONE read of the stream.  Fewer bytes, but on MI355X the '
-                         'fused kernel is currently slower than the four separate ones (DESIGN.md 4): not the default')
     ap.add_argument('--workload', default='cfg2', choices=['cfg2', 'cfg5-notricks', 'cfg5-ntrick'],
                     help='cfg2 = BASELINE configs[1] (the bench line the driver reads); cfg5-* = configs[4]: variable length 36-301 bp '
                          'with 1%% N, 3-bit ACGNT path (--notricks) or 2-bit N-trick path -- parity/measurement extras')
@@ -171,14 +164,13 @@ def main():
 
     def step(timed):
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-        enc = None
         spec = None
         guess = None
         census = None
         queued = None
         st = None
         ls_async = None
-        if not args.one_pass and not args.multi_pass:
+        if not args.multi_pass:
             # the census kernel is queued first, its closing scan right behind it (the line count stays on the device); the guess
             # (census / index / statistics of the shard's first 4 MB: small kernels, a read-back, the decisions on the host) runs
             # meanwhile on a second stream; the record index and the pack + statistics kernel are then queued behind the census
@@ -199,16 +191,6 @@ def main():
                 if sp is not None:
                     # one rank: the statistics' read-back is queued (and waited for) first, the line count is there by then
                     queued = (ls_cap, sp, None if use_dist else fetch(sp[3]))
-        if args.one_pass:
-            # ONE read of the stream (uq_encode_stream): census + record index + pass-1 statistics + pack with decisions guessed
-            # from the head of this shard (its first 65536 reads, statistics pass of their own -- part of the step), verified
-            # below against the statistics of the whole shard
-            g = ops.head_guess(ctx, d_buf, notricks=notricks)
-            if g is not None:
-                guess, rpb = g
-                e0.record()
-                enc = ops.encode_stream(ctx, d_buf, guess, int(fastq_bytes * rpb * 1.02) + 1024)
-                e1.record()
         hs = None
         if census is not None:
             nlines, ok = census.wait()
@@ -223,26 +205,19 @@ def main():
             elif queued is not None:                              # the queued form does not hold for this shard: the plain index, and
                 ls = ops.index_lines(ctx, d_buf, nlines)           # statistics flagged incomplete, so that EVERY rank redoes them below
                 st = queued[1][3]
-                st[STATS_RESERVED_OFFSET] = 1
+                st[ops.STATS_DTYPE.fields['reserved'][1]] = 1     # uq_stats.reserved: statistics incomplete
                 queued = None
             if st is not None:
                 hs = queued[2] if (queued is not None and queued[2] is not None) else fetch(st)     # N > 1: the all-reduce of the statistics
         if hs is None:
-            if enc is not None and enc.line_start is not None:
-                nlines, ls = enc.nlines, enc.line_start
+            if census is None: nlines = ops.count_lines(ctx, d_buf)
+            if census is not None and ls_async is not None and ok and nlines <= 4 * cap_reads:
+                ls = ls_async[:nlines + 1]                        # the queued index holds (there is no fused pack kernel for this alphabet)
             else:
-                if census is None: nlines = enc.nlines if enc is not None else ops.count_lines(ctx, d_buf)
-                if census is not None and ls_async is not None and ok and nlines <= 4 * cap_reads:
-                    ls = ls_async[:nlines + 1]                        # the queued index holds (there is no fused pack kernel for this alphabet)
-                else:
-                    ls = ops.index_lines(ctx, d_buf, nlines)          # record index
-                enc = None
+                ls = ops.index_lines(ctx, d_buf, nlines)          # record index
             nreads = nlines // 4
-            if enc is not None and enc.stats is not None:
-                st = enc.stats
-            else:
-                st = ops.stats_new(ctx)
-                ops.stats_accumulate(ctx, st, d_buf, ls, 0, nreads)
+            st = ops.stats_new(ctx)
+            ops.stats_accumulate(ctx, st, d_buf, ls, 0, nreads)
             hs = fetch(st)                                            # N > 1: the all-reduce of the statistics
         if hs.incomplete:                                         # the speculative pass met something outside its guess
             spec = None
@@ -252,11 +227,7 @@ def main():
         if hs.bad_plus is not None or hs.bad_len is not None:
             raise RuntimeError('malformed FASTQ record')
         d, p = decide_and_params(hs, nreads)
-        if enc is not None and enc.tables is not None and enc.stats is not None and ops.same_pack_params(p, enc.guess):
-            dna, qual = enc.tables
-            bad = None
-            kernel = 'encode_tile_kernel (census + record index + pass-1 statistics + pack in one pass over the stream)'
-        elif spec is not None and ops.same_pack_params(p, guess):
+        if spec is not None and ops.same_pack_params(p, guess):
             dna, qual, bad = spec[:3]
             kernel = 'pack_tile_kernel<STATS> (pack + pass-1 statistics in one read of the stream)'
         else:
@@ -359,16 +330,14 @@ def main():
     d = state['d']
     nreads = state['nreads']
     kernel = pack_events[-1][2]
-    one_pass = kernel.startswith('encode_tile_kernel')
     two_reads = kernel.startswith('pack_tile_kernel<STATS>')
     pack_ms = float(np.mean([a.elapsed_time(b) for a, b, k in pack_events if k == kernel]))
-    # SURVEY.md 8d bytes per read: the record read once + both rows written (+ the 32 B of line offsets the one-pass kernel
-    # also writes: it is the record index too)
-    algo_bytes = fastq_bytes + nreads * (d['dna_bytes_per_row'] + d['quality_bytes_per_row'] + (32 if one_pass else 0))
+    # SURVEY.md 8d bytes per read: the record read once + both rows written
+    algo_bytes = fastq_bytes + nreads * (d['dna_bytes_per_row'] + d['quality_bytes_per_row'])
     achieved = algo_bytes / 1e9 / (pack_ms / 1e3)
 
     traffic = None
-    tpath = os.path.join(HERE, 'profiles', 'encode_traffic.json' if one_pass else ('pack_stats_traffic.json' if two_reads else 'pack_traffic.json'))
+    tpath = os.path.join(HERE, 'profiles', 'pack_stats_traffic.json' if two_reads else 'pack_traffic.json')
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
@@ -381,9 +350,7 @@ def main():
         except Exception:
             traffic = None
 
-    mode = (' [ONE pass over the stream: decisions guessed from the shard\'s first 65536 reads, tables kept only because the whole '
-            'shard\'s statistics -- counted in the same pass -- gave the same decisions]' if one_pass else
-            (' [TWO reads of the stream, queued back to back (the line count stays on the device for the index and the pack kernel): census + index, then pack + statistics in one kernel with decisions guessed from the shard\'s first '
+    mode = ((' [TWO reads of the stream, queued back to back (the line count stays on the device for the index and the pack kernel): census + index, then pack + statistics in one kernel with decisions guessed from the shard\'s first '
              '8192 reads; the tables were kept because the whole shard\'s statistics gave the same decisions]' if two_reads else
              ' [three reads of the stream: census, statistics, pack]'))
     result = {

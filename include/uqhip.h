@@ -104,14 +104,6 @@ typedef struct uq_stats_compact {
 int uq_stats_fetch_compact(uq_ctx* ctx, const uq_stats* d_stats, uq_stats_compact* h_out);
 int uq_stats_accumulate(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start,
                         uint64_t first_read, uint64_t nreads, uq_stats* d_stats);
-/* uq_count_lines AND uq_stats_accumulate in ONE read of the stream ("a census that counts"): the statistics of a tile's records
- * need the line number modulo 4, which the census is only just taking -- so every 16 KiB tile takes the phase from its own content
- * (the one residue for which every 4th line starts with '@' and the lines two on with '+'), counts the records that start in it,
- * and a small kernel checks every tile's assumption against the scanned counts afterwards.  *h_nlines = the census (always);
- * *h_stats_ok = 1: d_stats (initialised by uq_stats_init) holds what uq_stats_accumulate over all nlines / 4 reads would have
- * left there; 0 (a tile without a unique phase, a record longer than ~1 KB, a malformed record, nlines % 4 != 0): d_stats is
- * unspecified -- re-initialise it and run uq_stats_accumulate on the index.  uq_index_lines reuses the census either way. */
-int uq_count_lines_stats(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uq_stats* d_stats, uint64_t* h_nlines, int* h_stats_ok);
 /* Multi-GPU: a uq_stats as ONE summable buffer of 65536 + 6 * world int64 words.  uq_stats_export writes the
  * counts and, in this rank's six slots, bad_plus / bad_len (made file-wide by adding read_offset; sign bit flipped so that
  * signed order == unsigned order), len_min, len_max, max_record_bytes and the `reserved` flag; the other ranks' slots are 0.
@@ -119,14 +111,6 @@ int uq_count_lines_stats(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uq_
  * one collective per statistics exchange. */
 int uq_stats_export(uq_ctx* ctx, const uq_stats* d_stats, uint32_t rank, uint32_t world, uint64_t read_offset, int64_t* d_words);
 int uq_stats_import(uq_ctx* ctx, const int64_t* d_words, uint32_t world, uq_stats* d_stats);
-/* Record index AND pass-1 statistics in one pass over the stream (reads the FASTQ once instead of twice):
- * equivalent to uq_index_lines(...) followed by uq_stats_accumulate(..., 0, nlines / 4, ...).  Needs
- * nlines % 4 == 0 (from uq_count_lines on the same buffer).  *h_fused = 1 when done; 0 when the input
- * is outside what the fused kernel handles (nlines % 4 != 0, or a 16 KiB tile holding more than 2048
- * newlines): d_line_start / d_stats are then unspecified and the caller runs the two calls above
- * (after uq_stats_init). */
-int uq_index_stats(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint64_t nlines, uint64_t* d_line_start,
-                   uq_stats* d_stats, int* h_fused);
 /* First occurrence of each base byte: d_first[b] = min over pairs of (read_index << 20 | position),
  * or UQ_NONE.  Only needed to order N-trick candidates as the reference's dict does (uq.py:480). */
 int uq_first_occurrence(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start,
@@ -170,29 +154,6 @@ int uq_pack_stats(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_star
 int uq_pack_stats_async(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start, uint64_t capacity_reads,
                         const uq_pack_params* h_guess, uint8_t* d_dna, uint8_t* d_qual, uint64_t* d_bad,
                         uq_stats* d_stats, int* h_fused);
-
-/* ---- index + a1 + a3 / a4 in ONE pass over the stream: newline census, record index, pass-1 statistics and pack.
- * Replaces, in a single read of the FASTQ, `wc -l` and the line iteration (uq.py:85, 132-137), the pass-1 loop
- * (uq.py:366-388, 415-425) and encoder_fixed / encoder_variable (uq.py:108-254); same outputs as uq_count_lines +
- * uq_index_lines + uq_stats_accumulate + uq_pack, byte for byte, when the flags below say so.
- * h_guess: the pack parameters to speculate with (a sample of this file, the previous file; max_record_bytes and
- * avg_record_bytes size the tiles).  max_reads: capacity of d_dna / d_qual in rows; d_line_start holds 4 * max_reads + 1
- * entries.  d_stats: initialised by uq_stats_init, or NULL to skip the statistics.  On return (synchronous):
- *   launched  0: this geometry has no one-pass kernel (anything but 2-bit A/C/G/T with one contiguous quality range, the
- *                Q9 carry case, records longer than ~1 KB): NOTHING ran, use the multi-pass entry points;
- *   nlines    newlines in the buffer (= uq_count_lines);
- *   index_ok  d_line_start[0 .. nlines] is the record index (= uq_index_lines); 0: more lines than the capacity, a tile with
- *                more than 1500 lines, or the launch gave itself up (a workgroup waited too long for its predecessors);
- *   stats_ok  d_stats is complete (= uq_stats_accumulate over all nlines / 4 reads); 0 when a record could not be seen
- *                whole (longer than the guess allowed) or a read is longer than h_guess->dna_max: run uq_stats_accumulate;
- *   tables_ok every read was packed with the guess and met no symbol or length outside it: IF the decisions derived from
- *                the statistics equal the guess, d_dna / d_qual rows [0, nlines / 4) are uq_pack's; otherwise run uq_pack. */
-typedef struct uq_encode_result {
-    uint64_t nlines;
-    int32_t launched, index_ok, stats_ok, tables_ok;
-} uq_encode_result;
-int uq_encode_stream(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, const uq_pack_params* h_guess, uint64_t max_reads,
-                     uint64_t* d_line_start, uint8_t* d_dna, uint8_t* d_qual, uq_stats* d_stats, uq_encode_result* h_out);
 
 /* ---- a9 / a11: the eight --pattern byte layouts.  Replaces numpy.rot90 + ascontiguousarray /
  * asfortranarray + the payload write of numpy.save (uq.py:263-270) and, inverse, numpy.load +

@@ -274,7 +274,7 @@ def test_cli_fuzz_against_oracle(ctx, tmp_path, seed):
         with pytest.raises((uq.UqError, qname.QnameError)):
             _run_encode(ctx, tmp_path, fq, flags)
         return
-    cfg, members, names, path = _run_encode(ctx, tmp_path, fq, flags + os.environ.get('UQ_FUZZ_FLAGS', '').split())   # e.g. --one-pass
+    cfg, members, names, path = _run_encode(ctx, tmp_path, fq, flags + os.environ.get('UQ_FUZZ_FLAGS', '').split())   # e.g. --multi-pass
     assert set(members) == set(omembers)
     for k in omembers:
         assert members[k] == omembers[k], (k, flags)
@@ -288,22 +288,20 @@ def test_cli_fuzz_against_oracle(ctx, tmp_path, seed):
     if of['sort'] is None: assert text == fq
 
 
-def test_cli_one_pass_speculation(ctx, tmp_path):
-    """The encoder packs speculatively with decisions guessed from the head of the file itself -- by default in the kernel that
-    also counts the statistics (uq_pack_stats: two reads of the stream), with --one-pass in the kernel that does everything
-    (uq_encode_stream: one read); a wrong guess falls back to the separate pack; --multi-pass never speculates.  `pack_path` says
-    whether the speculative tables were kept.  The output never depends on the path taken."""
+def test_cli_speculative_pack(ctx, tmp_path):
+    """The encoder packs speculatively with decisions guessed from the head of the file itself, in the kernel that also counts the
+    statistics (uq_pack_stats: two reads of the stream); a wrong guess falls back to the separate pack; --multi-pass never
+    speculates.  `pack_path` says whether the speculative tables were kept.  The output never depends on the path taken."""
     a = synth.fastq(20261003 + 50, 3000, 60)
     b = synth.fastq(20261003 + 51, 2500, 60)                                   # same alphabets and length as a: a's decisions hold
     c = synth.fastq(20261003 + 52, 2000, (30, 61), n_rate=2)                   # variable length, N: they do not
-    # d: the head (first 65536 reads) is ACGT only, an N turns up later: the head's guess fails, the fallback packs
+    # d: the head (first 8192 reads) is ACGT only, an N turns up later: the head's guess fails, the fallback packs
     d = synth.fastq(20261003 + 53, 70_000, 40)
     k = d.rfind(b'\n', 0, len(d) - 200)
     k = d.rfind(b'\n', 0, d.rfind(b'\n+\n', 0, k))                             # start of a SEQ line near the end
     d = d[:k + 1] + b'N' + d[k + 2:]
     want = {}
-    for mode, expect in (([], ['one-pass', 'one-pass', 'one-pass', 'one-pass', 'two-pass']),
-                         (['--one-pass'], ['one-pass', 'one-pass', 'one-pass', 'one-pass', 'two-pass']), (['--multi-pass'], ['two-pass'] * 5)):
+    for mode, expect in (([], ['speculative', 'speculative', 'speculative', 'speculative', 'plain']), (['--multi-pass'], ['plain'] * 5)):
         uq.Session.last_params = None
         paths = []
         for i, fq in enumerate((a, b, c, b, d)):

@@ -157,7 +157,7 @@ def test_stats_window_hints(ctx, case):
     assert (hs.len_min, hs.len_max) == (ref['len_min'], ref['len_max'])
 
 
-def _check_fused(ctx, host, misalign=0):
+def _check_index_stats(ctx, host, misalign=0):
     t = ctx.torch
     backing = ctx.empty(host.size + 64)
     d_buf = backing[misalign:misalign + host.size]
@@ -165,7 +165,7 @@ def _check_fused(ctx, host, misalign=0):
     nlines = ops.count_lines(ctx, d_buf)
     hls = oracle_c.index_lines(host)
     assert nlines == len(hls) - 1
-    ls, st = ops.index_and_stats(ctx, d_buf, nlines, fused=True)
+    ls, st = ops.index_and_stats(ctx, d_buf, nlines)
     assert np.array_equal(ctx.to_numpy(ls, np.uint64), hls)
     hs = ops.stats_fetch(ctx, st)
     n = nlines // 4
@@ -179,11 +179,11 @@ def _check_fused(ctx, host, misalign=0):
     (1, 5, {}, 0), (3, 7, {}, 3), (20000, 100, {}, 0), (30000, 150, {}, 9), (9000, (36, 301), dict(n_rate=1), 15),
     (4000, (1, 9), {}, 1), (700, 50, dict(n_rate=3, n_qual_exclusive=False), 0),
 ])
-def test_fused_index_stats(ctx, n, length, kw, mis):
-    _check_fused(ctx, synth.fastq_array(synth.Spec(S + 7, length, **kw), n), mis)
+def test_index_stats_against_oracle(ctx, n, length, kw, mis):
+    _check_index_stats(ctx, synth.fastq_array(synth.Spec(S + 7, length, **kw), n), mis)
 
 
-def test_fused_index_stats_hard_inputs(ctx):
+def test_index_stats_hard_inputs(ctx):
     rng = np.random.RandomState(3)
     # reads far longer than the 4 KiB halo (counted from HBM), mixed with short ones
     recs = []
@@ -191,15 +191,15 @@ def test_fused_index_stats_hard_inputs(ctx):
         L = int(rng.choice([5, 3000, 9000, 40, 17000]))
         seq = ''.join('ACGTN'[k] for k in rng.randint(0, 5, L)); q = ''.join(chr(33 + k) for k in rng.randint(0, 41, L))
         recs.append('@long:%d:%d\n%s\n+\n%s\n' % (i % 3, i, seq, q))
-    _check_fused(ctx, np.frombuffer(''.join(recs).encode(), dtype=np.uint8).copy(), 5)
+    _check_index_stats(ctx, np.frombuffer(''.join(recs).encode(), dtype=np.uint8).copy(), 5)
     # unusual bytes (outside both LDS windows), a bad '+' line and a length mismatch
     recs = [b'@r:1:1\nACGTZ\x80\xff\n+\n!~\x01\x02\xfe\xff\x7f\n', b'@r:2:2\nAC\n-\nII\n', b'@r:3:3\nACG\n+\nII\n', b'@r:4:4\nA\n+\nI\n'] * 300
-    _check_fused(ctx, np.frombuffer(b''.join(recs), dtype=np.uint8).copy())
-    # thousands of one-byte lines per tile: the fused kernel declines, the wrapper falls back to two passes
-    _check_fused(ctx, np.frombuffer(b'@\nA\n+\nI\n' * 20000, dtype=np.uint8).copy(), 2)
+    _check_index_stats(ctx, np.frombuffer(b''.join(recs), dtype=np.uint8).copy())
+    # thousands of one-byte lines per tile: the newline lists overflow, the bitmap form of the index runs
+    _check_index_stats(ctx, np.frombuffer(b'@\nA\n+\nI\n' * 20000, dtype=np.uint8).copy(), 2)
     # Phred+64 style qualities (window moves) and lower-case bases
     recs = [('@p:%d\n%s\n+\n%s\n' % (i, 'acgtn' * 8, ''.join(chr(64 + (i + k) % 41) for k in range(40)))).encode() for i in range(3000)]
-    _check_fused(ctx, np.frombuffer(b''.join(recs), dtype=np.uint8).copy(), 11)
+    _check_index_stats(ctx, np.frombuffer(b''.join(recs), dtype=np.uint8).copy(), 11)
 
 
 PACK_CASES = [
@@ -440,6 +440,8 @@ def test_chunked_census_equals_whole_buffer(ctx, offset):
     buf = big[offset:offset + src.numel()]
     nl = ops.count_lines(ctx, buf)
     ls = ops.index_lines(ctx, buf, nl)
+    hls = oracle_c.index_lines(ctx.to_numpy(buf))
+    assert nl == len(hls) - 1 and np.array_equal(ctx.to_numpy(ls, np.uint64), hls)        # the whole-buffer census against the oracle
     mis = buf.data_ptr() & 15
     tile = 16 << 10
     rng = np.random.default_rng(5)
@@ -474,66 +476,6 @@ def test_session_load_overlaps_census_with_ingest(ctx, tmp_path):
     b.load_device(ctx.bytes_to_device(fq))
     assert a.total == b.total == 20_000 and ctx.torch.equal(a.d_ls, b.d_ls)
     assert np.array_equal(ops.stats_fetch(ctx, a.d_stats).counts, ops.stats_fetch(ctx, b.d_stats).counts)
-
-
-def _census_stats_check(ctx, d_buf, expect_ok=True):
-    t = ctx.torch
-    nl = ops.count_lines(ctx, d_buf)
-    ls = ops.index_lines(ctx, d_buf, nl)
-    st = ops.stats_new(ctx)
-    if nl >= 4: ops.stats_accumulate(ctx, st, d_buf, ls, 0, nl // 4)
-    hs = ops.stats_fetch(ctx, st)
-    nl2, st2 = ops.count_lines_stats(ctx, d_buf)
-    assert nl2 == nl
-    assert t.equal(ops.index_lines(ctx, d_buf, nl2), ls), 'the census of uq_count_lines_stats does not serve uq_index_lines'
-    if expect_ok is not None: assert (st2 is not None) == expect_ok
-    if st2 is not None:
-        h2 = ops.stats_fetch(ctx, st2)
-        assert np.array_equal(h2.counts, hs.counts), 'pair counts differ'
-        assert (h2.len_min, h2.len_max, h2.max_record_bytes, h2.bad_plus, h2.bad_len) == (hs.len_min, hs.len_max, hs.max_record_bytes, None, None)
-    return st2 is not None
-
-
-@pytest.mark.parametrize('n,length,kw', [(60_000, 150, {}), (40_000, (36, 301), dict(n_rate=1)), (30_000, 100, dict(n_rate=2)),
-                                         (2_000, (1, 40), {}), (50_000, 36, {}), (7, 150, {}), (1, 400, {})],
-                         ids=['fixed150', 'var36-301', 'fixed100-N', 'tiny-reads', 'short36', 'seven', 'one'])
-def test_census_that_counts_equals_two_passes(ctx, n, length, kw):
-    """uq_count_lines_stats: line count, the census uq_index_lines expands, and the statistics equal the separate passes'."""
-    d_buf = ops.synth_fastq(ctx, synth.Spec(S + 90, length, **kw), 0, n)
-    _census_stats_check(ctx, d_buf, True)
-
-
-def test_census_that_counts_knows_what_it_cannot_vouch_for(ctx):
-    """Qualities starting with '@' or '+', lower-case / IUPAC bases, Phred+64 (exact through the slower tiers); then inputs where
-    a tile cannot settle the phase or see a record whole: the statistics are withdrawn (None), the census stays exact."""
-    t = ctx.torch
-    rng = np.random.default_rng(9)
-
-    def fq(n, bases, quals, L, name=b'@q:%d:%d'):
-        B, Q = np.frombuffer(bases, np.uint8), np.frombuffer(quals, np.uint8)
-        return b''.join(name % (i % 3, i) + b'\n' + bytes(rng.choice(B, L)) + b'\n+\n' + bytes(rng.choice(Q, L)) + b'\n' for i in range(n))
-
-    dev = lambda b: ctx.bytes_to_device(b)
-    assert _census_stats_check(ctx, dev(fq(20_000, b'ACGT', b'@+ABCDEFGHI', 90)))            # QUAL lines that begin like '@' / '+' lines
-    assert _census_stats_check(ctx, dev(fq(20_000, b'acgtnRYKM', bytes(range(64, 105)), 70)))
-    assert _census_stats_check(ctx, dev(fq(3_000, b'ACGT', b'!#5I', 900)), None) is not None   # 1.8 kB records: beyond the halo sooner or later
-    # SEQ lines that all start with '@' and QUAL lines with '+': two phases fit -> withdrawn
-    amb = b''.join(b'@r%d\n@ACGT\n+\n+III\n' % i for i in range(5000))
-    _census_stats_check(ctx, dev(amb), False)
-    # a malformed record (third line without '+'), lengths that differ, no final newline, a line count that is no multiple of 4
-    good = fq(10_000, b'ACGT', b'#5AI', 60)
-    _census_stats_check(ctx, dev(good.replace(b'\n+\n', b'\n-\n', 7000).replace(b'\n-\n', b'\n+\n', 6999)), False)
-    lines = good.split(b'\n'); lines[4 * 5000 + 3] = lines[4 * 5000 + 3][:-2]
-    _census_stats_check(ctx, dev(b'\n'.join(lines)), False)
-    _census_stats_check(ctx, dev(good[:-1]), False)
-    _census_stats_check(ctx, dev(good + b'@x\nAC\n'), False)
-    _census_stats_check(ctx, dev(good + b'@trailing garbage'), True)
-    # misaligned buffers
-    src = ops.synth_fastq(ctx, synth.Spec(S + 91, (30, 90), n_rate=1), 0, 20_000)
-    for off in (3, 8, 13):
-        big = t.empty(src.numel() + 64, dtype=t.uint8, device=ctx.device).fill_(10)
-        big[off:off + src.numel()] = src
-        _census_stats_check(ctx, big[off:off + src.numel()], True)
 
 
 @pytest.mark.parametrize('length,kw', [(150, {}), ((36, 301), dict(n_rate=1)), (100, dict(n_rate=2))], ids=['fixed150', 'var-ntrick', 'fixed100-ntrick'])
@@ -575,6 +517,21 @@ def test_queued_census_index_pack_equals_the_plain_calls(ctx, length, kw):
     nl3, ok = cen.wait()
     assert nl3 == nl and not ok and hs.incomplete
     assert t.equal(ls3[:4 * cap + 1], ls[:4 * cap + 1])
+    # lines of three bytes: more than 1024 newlines per 16 KiB tile, the census's lists overflow.  The queued index and pack
+    # kernel run before the host knows: they must stand down (ok False, statistics incomplete) without reading beyond a slot
+    # or the buffer; the plain calls (bitmap form of the index) then give the oracle's index
+    tiny = np.frombuffer(b'@a\nAC\n+\nII\n' * 30_000, dtype=np.uint8).copy()
+    backing = ctx.empty(tiny.size)                           # exactly as large as the text: nothing readable behind it
+    backing.copy_(t.from_numpy(tiny))
+    cen = ops.ChunkedCensus(ctx, backing); cen.chunk(0, backing.numel()); cen.end_async()
+    cap = 30_000 + 64
+    ls4 = ops.index_lines_async(ctx, backing, 4 * cap)
+    got = ops.pack_stats_async(ctx, backing, ls4, cap, guess)
+    hs = ops.stats_fetch(ctx, got[3])
+    nl4, ok = cen.wait()
+    assert nl4 == 120_000 and not ok and hs.incomplete
+    nl5 = ops.count_lines(ctx, backing)
+    assert nl5 == nl4 and np.array_equal(ctx.to_numpy(ops.index_lines(ctx, backing, nl5), np.uint64), oracle_c.index_lines(tiny))
     # the queued calls belong to the census that was closed last
     other = ops.synth_fastq(ctx, synth.Spec(5, 50), 0, 100)
     cen = ops.ChunkedCensus(ctx, d_buf); cen.chunk(0, d_buf.numel()); cen.end_async()

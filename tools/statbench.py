@@ -22,12 +22,3 @@ for _ in range(5):
     best = ms if best is None or ms < best else best
 print('stats_kernel: %.3f ms for %d reads (%.0f GB/s of FASTQ)' % (best, n, d_buf.numel() / 1e6 / best))
 
-# the census that counts: census + statistics in one read (uq_count_lines_stats) against the two kernels it replaces
-for name, fn in (('count_lines (census alone)', lambda: ops.count_lines(ctx, d_buf)), ('count_lines_stats (census + statistics)', lambda: ops.count_lines_stats(ctx, d_buf))):
-    best = None
-    for _ in range(6):
-        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-        e0.record(); r = fn(); e1.record(); torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1)
-        best = ms if best is None or ms < best else best
-    print('%s: %.3f ms %s' % (name, best, '' if isinstance(r, int) else '(statistics vouched for: %s)' % (r[1] is not None)))

@@ -28,10 +28,6 @@ class PackParams(C.Structure):
                 ('max_record_bytes', C.c_int32), ('dna_max', C.c_int32), ('avg_record_bytes', C.c_int32)]
 
 
-class EncodeResult(C.Structure):
-    _fields_ = [('nlines', C.c_uint64), ('launched', C.c_int32), ('index_ok', C.c_int32), ('stats_ok', C.c_int32), ('tables_ok', C.c_int32)]
-
-
 class UnpackParams(C.Structure):
     _fields_ = [('base_char', C.c_uint8 * 256), ('qual_char', C.c_uint8 * 256), ('qual_n_base', C.c_uint8 * 256),
                 ('bits_per_base', C.c_int32), ('bits_per_quality', C.c_int32), ('variable', C.c_int32),
@@ -79,7 +75,6 @@ SIGNATURES = {
     'uq_timer_start': [_vp],
     'uq_timer_stop': [_vp, _P(C.c_float)],
     'uq_count_lines': [_vp, _vp, _u64, _P(_u64)],
-    'uq_count_lines_stats': [_vp, _vp, _u64, _vp, _P(_u64), _P(_int)],
     'uq_count_lines_begin': [_vp, _vp, _u64],
     'uq_count_lines_chunk': [_vp, _vp, _u64, _u64, _u64],
     'uq_count_lines_end': [_vp, _vp, _u64, _P(_u64)],
@@ -93,12 +88,10 @@ SIGNATURES = {
     'uq_stats_accumulate': [_vp, _vp, _vp, _u64, _u64, _vp],
     'uq_stats_export': [_vp, _vp, _u32, _u32, _u64, _vp],
     'uq_stats_import': [_vp, _vp, _u32, _vp],
-    'uq_index_stats': [_vp, _vp, _u64, _u64, _vp, _vp, _P(_int)],
     'uq_first_occurrence': [_vp, _vp, _vp, _u64, _u64, _u64, _vp],
     'uq_pack': [_vp, _vp, _vp, _u64, _u64, _P(PackParams), _vp, _vp, _vp],
     'uq_pack_stats': [_vp, _vp, _vp, _u64, _u64, _P(PackParams), _vp, _vp, _vp, _vp, _P(_int)],
     'uq_pack_stats_async': [_vp, _vp, _vp, _u64, _P(PackParams), _vp, _vp, _vp, _vp, _P(_int)],
-    'uq_encode_stream': [_vp, _vp, _u64, _P(PackParams), _u64, _vp, _vp, _vp, _vp, _P(EncodeResult)],
     'uq_pattern': [_vp, _vp, _u64, _u32, _int, _vp],
     'uq_unpattern': [_vp, _vp, _u64, _u32, _int, _vp],
     'uq_argsort_rows': [_vp, _vp, _u64, _u32, _vp],

@@ -18,7 +18,6 @@
 // holds (lines shorter than 16 bytes on average) raises a flag and uq_index_lines falls back to the bitmap form.
 #include "common.h"
 #include "swar.h"
-#include "histo.h"
 
 namespace {
 constexpr int IDX_THREADS = 256;
@@ -109,23 +108,32 @@ __global__ __launch_bounds__(IDX_THREADS) void census_list_kernel(const uint4* _
 // d_async (the queued form, uq_index_lines_async): the line count is read from d_async[0] -- the census's scan, queued in front,
 // left it there -- and line_start holds `cap` + 1 entries: lines beyond are dropped and d_async[1] is raised.
 constexpr uint32_t EXP_TILES = 4;            // census tiles per wave: a tile's ~200 offsets alone are too little work for a wave's set-up
+// d_over: the census's overflow word (a tile held more newlines than its list slot).  The queued form runs before the host has
+// seen it: a tile whose count exceeds its slot is skipped (its list is not there) and d_async[1] is raised, so that every later
+// consumer of this index (uq_pack_stats_async) stands down; the plain form is only called when the host has read the word as 0.
 __global__ __launch_bounds__(IDX_THREADS) void expand_list_kernel(const uint16_t* __restrict__ list, uint32_t mis, const uint32_t* __restrict__ offsets,
                                                                    uint64_t nb, uint64_t nlines, uint64_t* __restrict__ line_start,
-                                                                   unsigned long long* __restrict__ d_async, uint64_t cap) {
+                                                                   unsigned long long* __restrict__ d_async, uint64_t cap,
+                                                                   const uint32_t* __restrict__ d_over) {
     const uint32_t lane = lane_id();
     const uint64_t tile0 = ((uint64_t)blockIdx.x * (IDX_THREADS / 64) + (threadIdx.x >> 6)) * EXP_TILES;
     if (tile0 >= nb) return;
     if (d_async) nlines = d_async[0];
     if (tile0 == 0 && lane == 0) line_start[0] = 0;
+    if (d_async && *d_over) { if (lane == 0) d_async[1] = 1ull; return; }      // some tile's list is incomplete: no index at all
     // the tiles' first ranks (and the rank behind the last one) once, a lane each
     const uint64_t tl = tile0 + lane;
     const uint64_t mine = lane <= EXP_TILES ? (tl < nb ? (uint64_t)offsets[tl] : nlines) : 0;
     for (uint32_t k = 0; k < EXP_TILES && tile0 + k < nb; ++k) {
         const uint64_t tile = tile0 + k;
         const uint64_t P = __shfl(mine, k, 64), end = __shfl(mine, k + 1, 64);
-        const uint32_t cnt = (uint32_t)(end - P);
+        uint32_t cnt = (uint32_t)(end - P);
         const uint16_t* slot = list + tile * IDX_LIST_CAP;
         const int64_t p0 = (int64_t)(tile * IDX_TILE) - (int64_t)mis + 1;
+        if (cnt > IDX_LIST_CAP) {                                              // never with a census whose overflow word is 0; keeps the reads inside the slot
+            if (d_async && lane == 0) d_async[1] = 1ull;
+            cnt = IDX_LIST_CAP;
+        }
         if (d_async && end > cap) {
             if (lane == 0) d_async[1] = 1ull;
             for (uint32_t j = lane; j < cnt; j += 64) if (P + j + 1 <= cap) line_start[P + j + 1] = (uint64_t)(p0 + slot[j]);
@@ -191,17 +199,6 @@ int run_count(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint64_t* nblo
 }
 }  // namespace
 
-// For fused.hip: make sure ctx->idx_partials holds the exclusive scan of the per-tile newline counts
-// of this buffer (reusing the census of uq_count_lines when `have_scanned`).
-int uq_index_run_census(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint64_t* nblocks_out, bool have_scanned) {
-    const uint32_t mis = (uint32_t)((uintptr_t)d_buf & 15);
-    const uint64_t nvec = (nbytes + mis + 15) / 16;
-    if (have_scanned) { *nblocks_out = (nvec * 16 + IDX_TILE - 1) / IDX_TILE; return 0; }
-    UQ_TRY(run_count(ctx, d_buf, nbytes, nblocks_out, false));
-    UQ_TRY(uq_scan_exclusive_u32(ctx, ctx->idx_partials, ctx->idx_partials, *nblocks_out, nullptr));
-    return 0;
-}
-
 static int finish_count(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint64_t nb, uint64_t* h_nlines);
 
 extern "C" int uq_count_lines(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint64_t* h_nlines) {
@@ -216,151 +213,6 @@ extern "C" int uq_count_lines(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes
     return finish_count(ctx, d_buf, nbytes, nb, h_nlines);
 }
 
-// ---- a census that counts (uq_count_lines_stats): the newline census AND the pass-1 statistics in one read of the stream.
-// The statistics need to know which lines are SEQ and QUAL lines -- the line number modulo 4 -- which depends on the newlines of
-// the whole stream in front of a tile, i.e. on the very census that is being taken.  A tile does not wait for that: it takes the
-// phase from its own content (the one residue x of its line starts for which every line x, x + 4, ... begins with '@' and every
-// line x + 2, ... with '+'; zero or several such residues: the tile gives up and so does the call), counts the records that START
-// in it (their tails come from a 1 KiB halo), and leaves its assumed phase behind; after the scan of the per-tile counts a small
-// kernel compares every tile's assumption with the truth.  The call vouches for the statistics only when every tile was right;
-// otherwise the caller runs uq_stats_accumulate on the index, exactly as before.  The census outputs (counts, newline lists) are
-// those of uq_count_lines, so uq_index_lines reuses them the same way.
-constexpr uint32_t CS_HV = 64;                               // halo vectors (1 KiB), loaded by the last wave
-constexpr uint32_t CS_ECAP = IDX_LIST_CAP + 128;             // line starts of tile + halo (+ the start of the stream)
-
-struct CsCtl { uint32_t ambiguous, incomplete, wrong_phase, pad; };
-
-__global__ __launch_bounds__(IDX_THREADS, 4) void census_stats_kernel(const uint4* __restrict__ abuf, uint32_t mis, uint64_t nbytes, uint64_t nvec,
-                                                                       uint64_t ntiles, uint32_t* __restrict__ partials, uint16_t* __restrict__ list,
-                                                                       uint32_t* __restrict__ overflow, uint8_t* __restrict__ phase_out,
-                                                                       CsCtl* __restrict__ ctl, uq_stats* __restrict__ st, uint32_t win, uint32_t P) {
-    extern __shared__ __align__(16) uint8_t smem[];
-    uint8_t* stage = smem + 16;
-    uint32_t* E = (uint32_t*)(stage + IDX_TILE + CS_HV * 16 + 32);
-    uint32_t* misc = E + CS_ECAP;                  // [0..3] wave totals, [4] halo total, [8..11] violations per residue
-    const uint32_t tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
-    Histo hz;
-    RecordAcc acc;
-    hz.init(misc + 16, st, win);
-    bool incomplete = false, ambiguous = false, over = false;
-    const uint32_t vl0 = w * (IDX_LOADS * 64) + lane;
-    uint4 v[IDX_LOADS + 1];
-    auto issue = [&](uint64_t t) {
-#pragma unroll
-        for (int u = 0; u <= IDX_LOADS; ++u) v[u] = make_uint4(0, 0, 0, 0);
-        if (t >= ntiles) return;
-        const uint64_t base = t * IDX_TILE_VECS;
-#pragma unroll
-        for (int u = 0; u < IDX_LOADS; ++u) { const uint64_t vi = base + vl0 + u * 64; if (vi < nvec) v[u] = abuf[vi]; }
-        if (w == IDX_THREADS / 64 - 1) { const uint64_t vi = base + IDX_TILE_VECS + lane; if (vi < nvec) v[IDX_LOADS] = abuf[vi]; }
-    };
-    const uint32_t rr = tid / P, pp = tid - rr * P, RP = IDX_THREADS / P;     // lane = (read rr of a batch of RP, group pp, pp + P, ...)
-    uint64_t t = blockIdx.x;
-    issue(t);
-    for (; t < ntiles; t += gridDim.x) {
-        const int64_t pos0 = (int64_t)(t * IDX_TILE) - (int64_t)mis;
-        uint32_t m[IDX_LOADS + 1];
-#pragma unroll
-        for (int u = 0; u < IDX_LOADS; ++u) m[u] = nl_mask16(v[u]) & valid_mask16(pos0 + (int64_t)(vl0 + u * 64) * 16, nbytes);
-        m[IDX_LOADS] = w == IDX_THREADS / 64 - 1 ? nl_mask16(v[IDX_LOADS]) & valid_mask16(pos0 + (int64_t)(IDX_TILE_VECS + lane) * 16, nbytes) : 0u;
-        const uint32_t c0 = __popc(m[0]), c1 = __popc(m[1]), c2 = __popc(m[2]), c3 = __popc(m[3]), c4 = __popc(m[4]);
-        const uint32_t i01 = wave_inclusive_sum(c0 | (c1 << 16)), i23 = wave_inclusive_sum(c2 | (c3 << 16)), i4 = wave_inclusive_sum(c4);
-        const uint32_t t01 = __shfl(i01, 63, 64), t23 = __shfl(i23, 63, 64), t4 = __shfl(i4, 63, 64);
-        const uint32_t T0 = t01 & 0xFFFFu, T1 = t01 >> 16, T2 = t23 & 0xFFFFu, T3 = t23 >> 16;
-        if (lane == 0) { misc[w] = T0 + T1 + T2 + T3; if (w == IDX_THREADS / 64 - 1) misc[4] = t4; }
-        if (tid < 4) misc[8 + tid] = 0;
-        __syncthreads();                                                       // B1
-        uint32_t base = 0, count = 0;
-#pragma unroll
-        for (uint32_t i = 0; i < IDX_THREADS / 64; ++i) { const uint32_t x = misc[i]; if (i < w) base += x; count += x; }
-        const uint32_t nhalo = misc[4];
-        if (tid == 0) partials[t] = count;
-        // the tile's newlines: in-tile offsets to the global list (what uq_index_lines expands), line starts to LDS
-        const uint32_t shift = t == 0 ? 1u : 0u;
-        const uint32_t ex[IDX_LOADS + 1] = {base + (i01 & 0xFFFFu) - c0, base + T0 + (i01 >> 16) - c1, base + T0 + T1 + (i23 & 0xFFFFu) - c2,
-                                            base + T0 + T1 + T2 + (i23 >> 16) - c3, count + i4 - c4};
-        uint16_t* slot = list + t * IDX_LIST_CAP;
-#pragma unroll
-        for (int u = 0; u <= IDX_LOADS; ++u) {
-            uint32_t mm = m[u], k = ex[u];
-            const uint32_t o = (u < IDX_LOADS ? vl0 + u * 64 : IDX_TILE_VECS + lane) * 16;
-            while (mm) {
-                const uint32_t b = (uint32_t)__ffs((int)mm) - 1u;
-                mm &= mm - 1;
-                if (u < IDX_LOADS) { if (k < IDX_LIST_CAP) slot[k] = (uint16_t)(o + b); else over = true; }
-                if (k + shift < CS_ECAP) E[k + shift] = o + b + 1;
-                ++k;
-            }
-        }
-        if (shift && tid == 0) E[0] = mis;
-#pragma unroll
-        for (int u = 0; u < IDX_LOADS; ++u) ((uint4*)stage)[vl0 + u * 64] = v[u];
-        if (w == IDX_THREADS / 64 - 1) ((uint4*)stage)[IDX_TILE_VECS + lane] = v[IDX_LOADS];
-        issue(t + gridDim.x);                                                  // the next tile's bytes are in flight from here on
-        __syncthreads();                                                       // B2
-        const uint32_t nown = (count + shift < CS_ECAP ? count + shift : CS_ECAP);
-        const uint32_t nent = nown + nhalo < CS_ECAP ? nown + nhalo : CS_ECAP;
-        if (count + shift + nhalo > CS_ECAP) incomplete = true;
-        // ---- the phase: residue x is possible iff every line x, x + 4, ... starts with '@' and every line x + 2, ... with '+'
-        for (uint32_t x = tid; x < nent; x += IDX_THREADS) {
-            const uint32_t o = E[x];
-            const bool in_sight = (uint64_t)(pos0 + (int64_t)o) < nbytes && o < IDX_TILE + CS_HV * 16;
-            if (in_sight) {
-                const uint8_t c = stage[o];
-                if (c != '@') atomicOr(&misc[8 + (x & 3u)], 1u);               // cannot be a record's first line
-                if (c != '+') atomicOr(&misc[8 + ((x + 2u) & 3u)], 1u);        // cannot be a record's third line
-            }
-        }
-        __syncthreads();                                                       // B3
-        const uint32_t okm = (misc[8] ? 0u : 1u) | (misc[9] ? 0u : 2u) | (misc[10] ? 0u : 4u) | (misc[11] ? 0u : 8u);
-        uint32_t x0 = 0xFFu;
-        if (nown == 0) x0 = 0xFEu;                                             // no line starts here: nothing to count, nothing to verify
-        else if (okm && !(okm & (okm - 1))) x0 = (uint32_t)__ffs((int)okm) - 1u;
-        else ambiguous = true;
-        if (tid == 0) phase_out[t] = (uint8_t)x0;
-        if (x0 < 4) {
-            uint32_t Rt = nown > x0 ? (nown - x0 + 3) >> 2 : 0u;
-            const uint32_t whole = nent >= x0 + 5 ? (nent - 5 - x0) / 4 + 1 : 0u;
-            if (whole < Rt) {
-                if ((uint64_t)(pos0 + (int64_t)(IDX_TILE + CS_HV * 16)) < nbytes) incomplete = true;      // a record's tail beyond the halo
-                Rt = whole;
-            }
-            for (uint32_t r = rr < RP ? rr : Rt; r < Rt; r += RP) {       // lane 255 of 5 x 51 has no read of its own
-                const uint32_t* me = E + x0 + 4 * r;
-                const uint32_t so = me[1], L = me[2] - so - 1, qo = me[3], Lq = me[4] - qo - 1;
-                // record number: (tile, record in tile) -- made file-wide by the host once the scan is known (only bad records need it)
-                if (pp == 0) acc.record(((uint64_t)t << 20) | r, true, L, Lq, me[4] - me[0]);
-                if (Lq != L) continue;                                         // reported through bad_len; its pairs are nobody's
-                const uint32_t G = (L + 7) >> 3;
-                for (uint32_t gg = pp; gg < G; gg += P) {
-                    const int32_t j0 = (int32_t)L - 8 * (int32_t)gg - 8;
-                    uint32_t b_lo, b_hi, q_lo, q_hi;
-                    lds_window8(stage, (int32_t)so + j0, b_lo, b_hi);
-                    lds_window8(stage, (int32_t)qo + j0, q_lo, q_hi);
-                    hz.group8(b_lo, b_hi, q_lo, q_hi, j0 < 0 ? (uint32_t)(-j0) : 0u, lane);
-                }
-            }
-        }
-    }
-    if (incomplete) ctl->incomplete = 1;
-    if (ambiguous) ctl->ambiguous = 1;
-    if (over) atomicOr(overflow, 1u);
-    __syncthreads();
-    hz.flush();
-    acc.flush(st, 0);
-}
-
-// every tile's assumed phase against the one the scanned counts give it
-__global__ __launch_bounds__(IDX_THREADS) void verify_phase_kernel(const uint8_t* __restrict__ phase, const uint32_t* __restrict__ offsets, uint64_t ntiles,
-                                                                   CsCtl* __restrict__ ctl) {
-    const uint64_t t = (uint64_t)blockIdx.x * IDX_THREADS + threadIdx.x;
-    if (t >= ntiles) return;
-    const uint32_t p = phase[t];
-    if (p >= 4) return;
-    const uint64_t line0 = t == 0 ? 0ull : (uint64_t)offsets[t] + 1;           // file-wide number of the first line that starts in the tile
-    if ((uint32_t)((0ull - line0) & 3ull) != p) ctl->wrong_phase = 1;
-}
-
 // ---- the census in pieces: a file arrives in HBM chunk by chunk; every chunk's newlines are counted and
 // listed while the next one is still crossing PCIe, so that only the scan of the per-tile counts is left when the last byte lands.
 static int finish_count(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint64_t nb, uint64_t* h_nlines) {
@@ -373,50 +225,6 @@ static int finish_count(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint
     *h_nlines = ctx->h_pinned[0];
     // the lists are only good when every tile's newlines fitted its slot; otherwise uq_index_lines runs the bitmap form
     if ((uint32_t)ctx->h_pinned[1] == 0) { ctx->idx_buf = d_buf; ctx->idx_nbytes = nbytes; ctx->idx_nlines = *h_nlines; }
-    return 0;
-}
-
-extern "C" int uq_count_lines_stats(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uq_stats* d_stats, uint64_t* h_nlines, int* h_stats_ok) {
-    UQ_REQUIRE(ctx && h_nlines && h_stats_ok && d_stats, "uq_count_lines_stats: null argument");
-    ctx->idx_buf = nullptr;
-    *h_stats_ok = 0;
-    if (nbytes == 0) { *h_nlines = 0; return 0; }
-    UQ_REQUIRE(d_buf, "uq_count_lines_stats: null buffer");
-    const uint32_t mis = (uint32_t)((uintptr_t)d_buf & 15);
-    const uint64_t nvec = (nbytes + mis + 15) / 16;
-    const uint64_t nb = (nvec * 16 + IDX_TILE - 1) / IDX_TILE;
-    UQ_REQUIRE(nb <= 0x7fffffffu, "uq_count_lines_stats: buffer too large for one launch");
-    UQ_TRY(census_buffers(ctx, nb));
-    void* ws;
-    UQ_TRY(uq_scratch(ctx, 256 + nb, &ws));
-    CsCtl* d_ctl = (CsCtl*)ws;
-    uint8_t* d_phase = (uint8_t*)ws + 256;
-    uint32_t* d_over = (uint32_t*)(ctx->idx_bitmap + nb * IDX_TILE_VECS);
-    UQ_CHECK_HIP(hipMemsetAsync(ws, 0, 256, ctx->stream));
-    UQ_CHECK_HIP(hipMemsetAsync(d_over, 0, 4, ctx->stream));
-    const size_t lds = 16 + IDX_TILE + CS_HV * 16 + 32 + CS_ECAP * 4 + 64 + HZ_WORDS * 4;
-    UQ_CHECK_HIP(hipFuncSetAttribute((const void*)census_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const uint64_t blocks = nb < (uint64_t)UQ_NUM_CU * 4 ? nb : (uint64_t)UQ_NUM_CU * 4;
-    // lanes per read: a tile holds 16 KiB / (record bytes) reads; records of ~340 B -> 48 reads -> 5 lanes each
-    const uint32_t P = 5;
-    census_stats_kernel<<<(uint32_t)blocks, IDX_THREADS, lds, ctx->stream>>>((const uint4*)(d_buf - mis), mis, nbytes, nvec, nb, ctx->idx_partials,
-                                                                            ctx->idx_bitmap, d_over, d_phase, d_ctl, d_stats, (64u << 8) | 33u, P);
-    UQ_LAUNCH_CHECK();
-    void* scr;
-    UQ_TRY(uq_scan_exclusive_u32(ctx, ctx->idx_partials, ctx->idx_partials, nb, (uint64_t*)((uint8_t*)ws + 64)));
-    verify_phase_kernel<<<(uint32_t)((nb + IDX_THREADS - 1) / IDX_THREADS), IDX_THREADS, 0, ctx->stream>>>(d_phase, ctx->idx_partials, nb, d_ctl);
-    UQ_LAUNCH_CHECK();
-    (void)scr;
-    UQ_CHECK_HIP(hipMemcpyAsync(ctx->h_pinned, ws, 128, hipMemcpyDeviceToHost, ctx->stream));
-    UQ_CHECK_HIP(hipMemcpyAsync(ctx->h_pinned + 16, d_over, 4, hipMemcpyDeviceToHost, ctx->stream));
-    UQ_CHECK_HIP(hipMemcpyAsync(ctx->h_pinned + 17, &d_stats->bad_plus, 16, hipMemcpyDeviceToHost, ctx->stream));
-    UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-    const CsCtl c = *(const CsCtl*)ctx->h_pinned;
-    *h_nlines = ctx->h_pinned[8];                                              // the scan's total sits at ws + 64
-    if ((uint32_t)ctx->h_pinned[16] == 0) { ctx->idx_buf = d_buf; ctx->idx_nbytes = nbytes; ctx->idx_nlines = *h_nlines; }
-    *h_stats_ok = !c.ambiguous && !c.incomplete && !c.wrong_phase && *h_nlines % 4 == 0 && *h_nlines > 0;
-    // a malformed record was numbered (tile, record in tile): make it file-wide -- or simply let the caller's fallback report it
-    if (*h_stats_ok && (ctx->h_pinned[17] != UQ_NONE || ctx->h_pinned[18] != UQ_NONE)) *h_stats_ok = 0;
     return 0;
 }
 
@@ -484,7 +292,8 @@ extern "C" int uq_index_lines_async(uq_ctx* ctx, const uint8_t* d_buf, uint64_t 
     const uint32_t mis = (uint32_t)((uintptr_t)d_buf & 15);
     const uint64_t nb = (((nbytes + mis + 15) / 16) * 16 + IDX_TILE - 1) / IDX_TILE;
     expand_list_kernel<<<(uint32_t)((nb + EXP_TILES * (IDX_THREADS / 64) - 1) / (EXP_TILES * (IDX_THREADS / 64))), IDX_THREADS, 0, ctx->stream>>>(ctx->idx_bitmap, mis, ctx->idx_partials,
-                                                                                                                 nb, 0, d_line_start, ctx->d_async, capacity_lines);
+                                                                                                                 nb, 0, d_line_start, ctx->d_async, capacity_lines,
+                                                                                                                 (const uint32_t*)(ctx->idx_bitmap + nb * IDX_TILE_VECS));
     UQ_LAUNCH_CHECK();
     return 0;
 }
@@ -533,7 +342,7 @@ extern "C" int uq_index_lines(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes
         nb = (nvec * 16 + IDX_TILE - 1) / IDX_TILE;
         ctx->idx_buf = nullptr;
         expand_list_kernel<<<(uint32_t)((nb + EXP_TILES * (IDX_THREADS / 64) - 1) / (EXP_TILES * (IDX_THREADS / 64))), IDX_THREADS, 0, ctx->stream>>>(ctx->idx_bitmap, mis, ctx->idx_partials,
-                                                                                                                     nb, nlines, d_line_start, nullptr, 0);
+                                                                                                                     nb, nlines, d_line_start, nullptr, 0, nullptr);
         UQ_LAUNCH_CHECK();
         return 0;
     }

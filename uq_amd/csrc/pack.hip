@@ -134,6 +134,7 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && NTRICK) ? 4 : 5) void pack_ti
     if (d_async) {                                    // the queued form (uq_pack_stats_async): the census in front left the line count on the device;
         const uint64_t have = d_async[0] / 4;         // `n` is what the tables hold
         if (have > n) incomplete = true; else n = have;
+        if (d_async[1]) { incomplete = true; n = 0; }   // the queued index in front gave up (list or capacity overflow): its entries are not line starts
     }
 
     const uint64_t R = g.R;

@@ -4,6 +4,7 @@ PyTorch is plumbing here -- it owns device memory (caching allocator) and the st
 `torch.distributed` (RCCL) carries the multi-GPU exchange.  All compute goes through the C ABI
 (`uq_amd._lib`); tensors cross it as raw device pointers.
 """
+import contextlib
 import ctypes as C
 
 import numpy as np
@@ -85,6 +86,14 @@ class Context:
     def sync(self):
         call('uq_ctx_sync', self.h)
 
+    def scope(self):
+        """Context manager under which torch allocations belong to this context's stream (the main context: already current)."""
+        return contextlib.nullcontext()
+
+    def adopt(self, tensor):
+        """Declare that `tensor` (allocated elsewhere) is about to be used on this context's stream (the main context: nothing to do)."""
+        return tensor
+
     @staticmethod
     def ptr(tensor):
         return C.c_void_p(tensor.data_ptr()) if tensor is not None else C.c_void_p(0)
@@ -92,17 +101,32 @@ class Context:
 
 class SideContext:
     """A second `uq_ctx` on the same device with a private stream of its own: small independent work (the encoder's guess from the
-    head of the file) runs and synchronises there while the main context's stream is busy with the census.  Shares the torch
-    device; tensors it allocates are used and synchronised on its own stream before they are dropped."""
+    head of the file) runs and synchronises there while the main context's stream is busy with the census.
+
+    Allocation discipline (torch's caching allocator hands a freed block back to the stream it was allocated on, without waiting
+    for any other stream): everything a SideContext computes with is allocated under `scope()` -- i.e. with the side stream as
+    torch's current stream, so the blocks belong to it -- and a tensor that comes from the main stream is handed over with
+    `adopt()` (`Tensor.record_stream`: the allocator will not reuse its block before the side stream's pending work has finished).
+    An adopted input must already be COMPLETE on the main stream (the side stream does not wait for the main one -- that is the
+    point of it); `ops.head_guess` follows both rules."""
 
     def __init__(self, ctx):
         self.torch, self.device, self.main = ctx.torch, ctx.device, ctx
+        self.stream = ctx.torch.cuda.Stream(device=ctx.device)
         h = C.c_void_p()
-        call('uq_ctx_create', int(ctx.device.index), None, C.byref(h))
+        call('uq_ctx_create', int(ctx.device.index or 0), C.c_void_p(self.stream.cuda_stream), C.byref(h))
         self.h = h
 
+    def scope(self):
+        return self.torch.cuda.stream(self.stream)
+
+    def adopt(self, tensor):
+        tensor.record_stream(self.stream)
+        return tensor
+
     def to_numpy(self, tensor, dtype=None, shape=None):
-        return self.main.to_numpy(tensor, dtype, shape)
+        with self.scope():
+            return self.main.to_numpy(tensor, dtype, shape)
 
     def sync(self):
         call('uq_ctx_sync', self.h)

@@ -66,8 +66,8 @@ class ShardedSession(Session):
             res = fn()
         except UqError as e:
             msg = str(e)
-        except (OSError, RuntimeError) as e:         # I/O, HIP / ABI errors (UqHipError is a RuntimeError)
-            msg = 'ERROR: rank %d failed while %s: %s' % (self.rank, what, e)
+        except Exception as e:                       # I/O, HIP / ABI errors (UqHipError is a RuntimeError), anything else rank-local: the
+            msg = 'ERROR: rank %d failed while %s: %s: %s' % (self.rank, what, type(e).__name__, e)    # peers must not wait in the next collective
         self.agree(msg)
         return res
 

@@ -20,15 +20,6 @@ def count_lines(ctx, buf):
     return n.value
 
 
-def count_lines_stats(ctx, buf):
-    """Newline census + pass-1 statistics in one read of the stream (uq_count_lines_stats).  Returns (nlines, d_stats): d_stats is
-    None when the pass cannot vouch for the statistics (the caller then runs stats_accumulate on the index)."""
-    st = stats_new(ctx)
-    n = C.c_uint64(); ok = C.c_int(0)
-    call('uq_count_lines_stats', ctx.h, _p(buf), buf.numel(), _p(st), C.byref(n), C.byref(ok))
-    return n.value, (st if ok.value else None)
-
-
 class ChunkedCensus:
     """uq_count_lines over a buffer that is still being filled: `chunk(lo, n)` as each piece lands, `end()` = the line count."""
 
@@ -125,22 +116,13 @@ def stats_accumulate(ctx, d_stats, buf, line_start, first_read, nreads):
     call('uq_stats_accumulate', ctx.h, _p(buf), _p(line_start), first_read, nreads, _p(d_stats))
 
 
-def index_and_stats(ctx, buf, nlines, fused=False):
-    """Record index + pass-1 statistics of the whole buffer.  Returns (line_start tensor, device uq_stats).
-    fused=True uses the one-pass kernel (uq_index_stats: one HBM read less; on MI355X it is currently
-    VALU-bound and no faster than the two kernels, so it is not the default) and falls back to the
-    two-pass form when that kernel declines the input."""
-    t = ctx.torch
-    ls = t.empty(nlines + 1, dtype=t.int64, device=ctx.device)
+def index_and_stats(ctx, buf, nlines):
+    """Record index + pass-1 statistics of the whole buffer (uq_index_lines + uq_stats_accumulate).
+    Returns (line_start tensor, device uq_stats)."""
+    ls = index_lines(ctx, buf, nlines)
     st = stats_new(ctx)
-    done = C.c_int(0)
-    if fused:
-        call('uq_index_stats', ctx.h, _p(buf), buf.numel(), nlines, _p(ls), _p(st), C.byref(done))
-    if not done.value:
-        call('uq_index_lines', ctx.h, _p(buf), buf.numel(), nlines, _p(ls))
-        call('uq_stats_init', ctx.h, _p(st))
-        if nlines >= 4:
-            call('uq_stats_accumulate', ctx.h, _p(buf), _p(ls), 0, nlines // 4, _p(st))
+    if nlines >= 4:
+        stats_accumulate(ctx, st, buf, ls, 0, nlines // 4)
     return ls, st
 
 
@@ -215,38 +197,7 @@ def pack_stats_async(ctx, buf, line_start, capacity_reads, guess, st=None):
     return (dna, qual, bad, st) if fused.value else None
 
 
-class Encoded:
-    """What uq_encode_stream left behind: nlines, line_start (or None), d_stats (or None), (dna, qual) (or None)."""
-    __slots__ = ('nlines', 'line_start', 'stats', 'tables', 'guess')
-
-
-def encode_stream(ctx, buf, guess, max_reads, with_stats=True):
-    """One pass over the FASTQ in HBM (uq_encode_stream): census + record index + pass-1 statistics + pack with the GUESSED
-    parameters.  Returns None when this geometry has no one-pass kernel (nothing ran), else an `Encoded` whose parts are
-    None where the pass could not vouch for them (the caller then runs the multi-pass entry point for that part)."""
-    from ._lib import EncodeResult
-    t = ctx.torch
-    max_reads = int(max_reads)
-    ls = t.empty(4 * max_reads + 1, dtype=t.int64, device=ctx.device)
-    dna = t.empty(max_reads * guess.dna_bytes_per_row, dtype=t.uint8, device=ctx.device)
-    qual = t.empty(max_reads * guess.quality_bytes_per_row, dtype=t.uint8, device=ctx.device)
-    st = stats_new(ctx) if with_stats else None
-    res = EncodeResult()
-    call('uq_encode_stream', ctx.h, _p(buf), buf.numel(), C.byref(guess), max_reads, _p(ls), _p(dna), _p(qual), _p(st), C.byref(res))
-    if not res.launched:
-        return None
-    e = Encoded()
-    e.nlines, e.guess = int(res.nlines), guess
-    e.line_start = ls[:e.nlines + 1] if res.index_ok else None
-    e.stats = st if (with_stats and res.stats_ok) else None
-    n = e.nlines // 4
-    e.tables = (dna[:n * guess.dna_bytes_per_row], qual[:n * guess.quality_bytes_per_row]) if res.tables_ok else None
-    return e
-
-
-HEAD_BYTES = 24 << 20          # the slice of the file the one-pass encoder's guess is taken from
-HEAD_READS = 65536
-HEAD_BYTES_SMALL = 4 << 20     # ... and the pack-and-count encoder's (8192 reads of <= 512 bytes)
+HEAD_BYTES_SMALL = 4 << 20     # the slice of the file the pack-and-count encoder's guess is taken from (8192 reads of <= 512 bytes)
 HEAD_READS_INDEXED = 8192
 
 
@@ -254,17 +205,18 @@ def head_guess(ctx, buf, notricks=False, pad=False, head_bytes=None, head_reads=
     """uq_pack_params guessed from the head of the file itself: the multi-pass statistics (uq.py:366-425) of its first
     HEAD_READS reads -> the decisions of uq.py:448-545 on that sample.  Returns (params, reads per byte estimate) or None when
     the head holds no complete record.  A guess is only ever used speculatively: the caller verifies it against the
-    statistics of the WHOLE file (uq_encode_stream counts them in the same pass)."""
+    statistics of the WHOLE file (uq_pack_stats counts them in the same pass)."""
     from . import analysis
-    head = buf[:head_bytes or HEAD_BYTES]
-    nl = count_lines(ctx, head)
-    n = min(nl // 4, head_reads or HEAD_READS)
-    if n == 0:
-        return None
-    ls = index_lines(ctx, head, nl)
-    st = stats_new(ctx)
-    stats_accumulate(ctx, st, head, ls, 0, n)
-    hs = stats_fetch(ctx, st)
+    with ctx.scope():                 # a SideContext: its tensors are allocated on ITS stream; `buf` (complete on the main one) is adopted
+        head = ctx.adopt(buf)[:head_bytes or HEAD_BYTES_SMALL]
+        nl = count_lines(ctx, head)
+        n = min(nl // 4, head_reads or HEAD_READS_INDEXED)
+        if n == 0:
+            return None
+        ls = index_lines(ctx, head, nl)
+        st = stats_new(ctx)
+        stats_accumulate(ctx, st, head, ls, 0, n)
+        hs = stats_fetch(ctx, st)
     if hs.bad_plus is not None or hs.bad_len is not None:
         return None
     d = analysis.decide_from_stats(hs, notricks=notricks, pad=pad)
@@ -278,7 +230,7 @@ def head_guess(ctx, buf, notricks=False, pad=False, head_bytes=None, head_reads=
 
 
 def head_guess_indexed(ctx, buf, line_start, nreads, notricks=False, pad=False):
-    """head_guess for a buffer whose record index exists already: the statistics of its first HEAD_READS reads -> decisions ->
+    """head_guess for a buffer whose record index exists already: the statistics of its first HEAD_READS_INDEXED reads -> decisions ->
     uq_pack_params, or None (malformed head, Q9 new-code alphabets: no speculative kernel)."""
     from . import analysis
     # 8192 reads: the statistics kernel flushes its tables once per workgroup, and a sample of 150 tiles keeps that to 150
@@ -296,40 +248,6 @@ def head_guess_indexed(ctx, buf, line_start, nreads, notricks=False, pad=False):
     return make_pack_params(d['bases'], d['qualities'], d['N_qual'], d['bits_per_base'], d['bits_per_quality'], d['variable_read_lengths'],
                             d['dna_bytes_per_row'], d['quality_bytes_per_row'], d['dna_max'], hs.max_record_bytes,
                             avg_record_bytes=buf.numel() // max(int(nreads), 1))
-
-
-def encode_one_pass(ctx, buf, guess=None, notricks=False, pad=False, reads_per_byte=None):
-    """Census + record index + pass-1 statistics (+ speculative tables) with ONE read of the stream where the input allows
-    it, else through the multi-pass entry points -- the same results either way.
-    Returns (nlines, line_start, d_stats, spec, path): d_stats = device uq_stats of all nlines // 4 reads (None when nlines
-    is no multiple of 4: the caller reports that first), spec = (guess, dna, qual) when the pass packed every read with
-    `guess` and met nothing outside it (the caller keeps the tables iff the real decisions equal the guess), else None."""
-    e = None
-    if guess is None:
-        g = head_guess(ctx, buf, notricks, pad)
-        if g is not None: guess, reads_per_byte = g
-    if guess is not None:
-        rpb = reads_per_byte or (1.0 / max(guess.avg_record_bytes, 1))
-        e = encode_stream(ctx, buf, guess, int(buf.numel() * rpb * 1.02) + 1024)
-        if e is not None and e.line_start is None and e.nlines % 4 == 0 and e.nlines:
-            e = encode_stream(ctx, buf, guess, e.nlines // 4) or e          # the row estimate was short: the census is exact now
-    if e is not None and e.line_start is not None:
-        nlines, ls, path = e.nlines, e.line_start, 'one-pass'
-    else:
-        nlines = e.nlines if e is not None else count_lines(ctx, buf)
-        ls = index_lines(ctx, buf, nlines)
-        e, path = None, 'multi-pass'
-    n = nlines // 4
-    d_stats = None
-    if nlines % 4 == 0 and n:
-        if e is not None and e.stats is not None:
-            d_stats = e.stats
-        else:
-            path = 'multi-pass' if e is None else 'one-pass index, multi-pass statistics'
-            d_stats = stats_new(ctx)
-            stats_accumulate(ctx, d_stats, buf, ls, 0, n)
-    spec = (guess,) + e.tables if (e is not None and e.tables is not None and e.stats is not None) else None
-    return nlines, ls, d_stats, spec, path
 
 
 def same_pack_params(a, b):

@@ -57,9 +57,6 @@ def build_parser():
     p.add_argument('--device', type=int, default=int(os.environ.get('LOCAL_RANK', '0')), help='GPU index (extension)')
     p.add_argument('--quiet', action='store_true', default=False, help='suppress the analysis report (extension)')
     p.add_argument('--host-qname', action='store_true', default=False, help='run the QNAME passes sequentially on the host (extension)')
-    p.add_argument('--one-pass', action='store_true', default=False,
-                   help='census, record index, statistics and a speculative pack (decisions guessed from the head of the file, verified afterwards) '
-                        'in ONE read of the stream (extension)')
     p.add_argument('--multi-pass', action='store_true', default=False,
                    help='census, record index, statistics and pack as separate passes over the stream; the default counts the statistics in the pack kernel, '
                         'packing speculatively with decisions guessed from the head of the file and verified afterwards (extension)')
@@ -129,7 +126,7 @@ class Session:
         now = time.time(); d = now - self.split; self.split = now
         return '(' + str(d / 60) + ' minutes)'
 
-    last_params = None         # uq_pack_params of the previous encode in this process: the guess of the one-pass encoder
+    last_params = None         # uq_pack_params of the previous encode in this process
 
     # ------------------------------------------------------------------ passes 1-2 (analysis)
     def load(self, path):
@@ -144,46 +141,40 @@ class Session:
         def on_chunk(d, lo, n):
             if 'c' not in census: census['c'] = ops.ChunkedCensus(ctx, d)
             census['c'].chunk(lo, n)
-        chunked = not getattr(self.args, 'one_pass', False) and self.io.chunk % (16 << 10) == 0
+        chunked = self.io.chunk % (16 << 10) == 0
         d_buf = self.io.file_to_device(path, on_chunk=on_chunk if chunked else None)
         self.load_device(d_buf, nlines=census['c'].end() if 'c' in census else None)
 
     def load_device(self, d_buf, nlines=None):
         """The same for FASTQ bytes that are already in HBM (a uint8 device tensor): newline census, record index, pass-1
         statistics -- the statistics counted by the pack kernel while it packs speculatively (see below), so the stream is read
-        twice.  --multi-pass: census -> index -> statistics -> pack as separate passes (three reads); --one-pass: all of it in ONE
-        read (uq_encode_stream; currently the slowest of the three on MI355X).  Same results whichever path."""
+        twice.  --multi-pass: census -> index -> statistics -> pack as separate passes (three reads).  Same results whichever path."""
         ops, ctx, args = self.ops, self.ctx, self.args
         self.d_buf = d_buf
         if not hasattr(self, '_host'): self.path, self._host = None, None
         self._spec, self.load_path = None, 'multi-pass'
-        one_pass = getattr(args, 'one_pass', False) and not getattr(args, 'multi_pass', False)
-        if one_pass:
-            nlines, self.d_ls, self.d_stats, spec, self.load_path = ops.encode_one_pass(ctx, self.d_buf, None, args.notricks, args.pad)
-            if spec is not None: self._spec = spec + (None,)
-        elif nlines is None:                                                     # else: the census ran chunk by chunk during the load
+        if nlines is None:                                                       # else: the census ran chunk by chunk during the load
             nlines = ops.count_lines(ctx, self.d_buf)
         if nlines % 4 != 0:
             error('ERROR: The FASTQ file provided contains' + str(nlines) + 'rows, which is not divisible by 4!')
         if nlines == 0: error('ERROR: empty input')
         self.total = nlines // 4
-        if not one_pass:
-            self.d_ls = ops.index_lines(ctx, self.d_buf, nlines)                 # record index
-            # pass-1 statistics.  Unless --multi-pass says otherwise they are counted by the PACK kernel (uq_pack_stats): it packs
-            # with decisions guessed from the first 8192 reads while it counts the (base, quality) codes it produces anyway, so
-            # the stream is read twice (census, pack) instead of three times; analyse() / _encode() keep the tables only if the
-            # decisions derived from the whole file's counts equal the guess (else uq_pack runs with the real ones), and counts
-            # the kernel could not complete (a symbol or a length outside the guess) are redone by the plain statistics pass.
-            if not getattr(args, 'multi_pass', False):
-                guess = ops.head_guess_indexed(ctx, self.d_buf, self.d_ls, self.total, args.notricks, args.pad)
-                res = ops.pack_stats(ctx, self.d_buf, self.d_ls, 0, self.total, guess) if guess is not None else None
-                if res is not None:
-                    self._spec = (guess,) + res[:3]
-                    self.d_stats = res[3]
-                    self.load_path = 'two reads (census; pack + statistics)'
-            if self._spec is None:
-                self.d_stats = ops.stats_new(ctx)
-                ops.stats_accumulate(ctx, self.d_stats, self.d_buf, self.d_ls, 0, self.total)
+        self.d_ls = ops.index_lines(ctx, self.d_buf, nlines)                 # record index
+        # pass-1 statistics.  Unless --multi-pass says otherwise they are counted by the PACK kernel (uq_pack_stats): it packs
+        # with decisions guessed from the first 8192 reads while it counts the (base, quality) codes it produces anyway, so
+        # the stream is read twice (census, pack) instead of three times; analyse() / _encode() keep the tables only if the
+        # decisions derived from the whole file's counts equal the guess (else uq_pack runs with the real ones), and counts
+        # the kernel could not complete (a symbol or a length outside the guess) are redone by the plain statistics pass.
+        if not getattr(args, 'multi_pass', False):
+            guess = ops.head_guess_indexed(ctx, self.d_buf, self.d_ls, self.total, args.notricks, args.pad)
+            res = ops.pack_stats(ctx, self.d_buf, self.d_ls, 0, self.total, guess) if guess is not None else None
+            if res is not None:
+                self._spec = (guess,) + res[:3]
+                self.d_stats = res[3]
+                self.load_path = 'two reads (census; pack + statistics)'
+        if self._spec is None:
+            self.d_stats = ops.stats_new(ctx)
+            ops.stats_accumulate(ctx, self.d_stats, self.d_buf, self.d_ls, 0, self.total)
 
     @property
     def host(self):
@@ -311,14 +302,14 @@ class Session:
                                  avg_record_bytes=self.d_buf.numel() // max(self.total, 1))
         spec = getattr(self, '_spec', None)
         self._spec = None
-        self.pack_path = 'one-pass' if (spec is not None and ops.same_pack_params(p, spec[0])) else 'two-pass'
-        if self.pack_path == 'one-pass':
+        self.pack_path = 'speculative' if (spec is not None and ops.same_pack_params(p, spec[0])) else 'plain'
+        if self.pack_path == 'speculative':
             dna, qual, bad = spec[1:]            # packed while the statistics were counted: the guess was right
         else:
             del spec
             dna, qual, bad = ops.pack(ctx, self.d_buf, self.d_ls, 0, self.total, p)
         Session.last_params = p
-        b = ops.bad_index(bad) if bad is not None else None      # the one-pass kernel withdraws its tables instead
+        b = ops.bad_index(bad) if bad is not None else None      # (the speculative kernel flags its statistics instead)
         if b is not None: error('ERROR: read %d holds a symbol with no code (internal inconsistency)' % b)
         return ((dna, self.total, d['dna_bytes_per_row']), (qual, self.total, d['quality_bytes_per_row']))
 
