@@ -16,8 +16,11 @@ One step = one pass of the hot path over the shard, everything from the raw byte
     -> alphabet / N-trick / bit-width decisions on the host from the WHOLE shard's statistics (uq.py:448-545); the tables are
        kept iff they equal the guess, else uq_pack runs with the real ones (never on this workload).
     (--multi-pass: round 1's step, statistics and pack as separate kernels = three reads.)
-The QNAME passes (on the device in the CLI, tools/bench_e2e.py times them) are not part of this
-step.  `value` = FASTQ bytes of all ranks / time, MAX over ranks.
+    -> the QNAME passes (uq.py:394-444 layout, 555-678 column typing, 717-736 column encoding) INSIDE that
+       second read: the pack kernel holds the QNAME lines in its LDS tiles anyway; a layout guessed on the device from a sample of
+       the reads is verified on every read while the fields are parsed; distinct-value counts and the column encoders are queued
+       behind it.  (N > 1: the shards are timed without the QNAME passes -- the layout belongs to the whole file.)
+`value` = FASTQ bytes of all ranks / time, MAX over ranks.
 Besides the contract fields the JSON line carries `roofline` (pack kernel, HIP-event timed inside the
 timed region on the launch stream) and `cpu_baseline` (the faithful per-base Python loops of the
 oracle on one host core, on a bounded sample of the same input; rank 0, N = 1 only).
@@ -98,6 +101,7 @@ def main():
     ap.add_argument('--multi-pass', action='store_true',
                     help='round 1\'s step: census -> index -> statistics -> decisions -> pack, three reads of the stream (the default '
                          'counts the statistics inside the pack kernel: two reads)')
+    ap.add_argument('--no-qname', action='store_true', help='leave the QNAME passes out of the timed step (round 2\'s step)')
     ap.add_argument('--workload', default='cfg2', choices=['cfg2', 'cfg5-notricks', 'cfg5-ntrick'],
                     help='cfg2 = BASELINE configs[1] (the bench line the driver reads); cfg5-* = configs[4]: variable length 36-301 bp '
                          'with 1%% N, 3-bit ACGNT path (--notricks) or 2-bit N-trick path -- parity/measurement extras')
@@ -148,6 +152,10 @@ def main():
 
     pack_events = []
     state = {}
+    # N = 1: the step is the WHOLE encode of the shard, QNAME columns included.  N > 1: the QNAME layout is a property of the whole
+    # file (line 1, common prefix): the sharded encoder (uq_amd.dist_encode) combines it over the ranks; this bench's shards are
+    # timed without it and the JSON says so.
+    qname_in_step = not use_dist and not args.no_qname
 
     def fetch(st):
         if use_dist:
@@ -170,6 +178,7 @@ def main():
         queued = None
         st = None
         ls_async = None
+        fq = None
         if not args.multi_pass:
             # the census kernel is queued first, its closing scan right behind it (the line count stays on the device); the guess
             # (census / index / statistics of the shard's first 4 MB: small kernels, a read-back, the decisions on the host) runs
@@ -185,9 +194,15 @@ def main():
                 cap_reads = int(fastq_bytes * rpb * 1.02) + 1024
                 guess.avg_record_bytes = int(1.0 / rpb)                     # tile sizing hint: the head's own records
                 ls_cap = ls_async = ops.index_lines_async(ctx, d_buf, 4 * cap_reads)
+                if qname_in_step:
+                    # the QNAME passes ride in the pack kernel: layout guessed on the device from a sample of the reads (queued here,
+                    # behind the index), verified on every read while the fields are parsed; distinct counts queued behind it
+                    fq = ops.FusedQname(ctx, cap_reads)
+                    ops.qname_guess_async(ctx, d_buf, ls_cap, fq)
                 e0.record()
-                sp = ops.pack_stats_async(ctx, d_buf, ls_cap, cap_reads, guess, st=st_q)
+                sp = ops.pack_stats_async(ctx, d_buf, ls_cap, cap_reads, guess, st=st_q, fq=fq)
                 e1.record()
+                if sp is not None and fq is not None: ops.qname_fused_finish(ctx, fq)
                 if sp is not None:
                     # one rank: the statistics' read-back is queued (and waited for) first, the line count is there by then
                     queued = (ls_cap, sp, None if use_dist else fetch(sp[3]))
@@ -236,8 +251,19 @@ def main():
             dna, qual, bad = ops.pack(ctx, d_buf, ls, 0, nreads, p)
             e1.record()
             kernel = 'pack_tile_kernel'
+        # the QNAME analysis (uq.py:394-444, 555-678, 717-736): from the pack kernel's QNAME phase when every read conformed to the
+        # guessed layout, else by the exact kernels (layout reductions, tokeniser) -- inside the timed step either way
+        qpath, qres = None, None
+        if qname_in_step:
+            from uq_amd import qname_device
+            qres = qname_device.analyse_fused(ctx, fq, nreads) if (fq is not None and spec is not None) else None
+            qpath = 'fused into the pack kernel'
+            if qres is None:
+                qres = qname_device.analyse_device(ctx, d_buf, ls, nreads)
+                qpath = 'exact kernels (layout, tokeniser)'
+            if qres is None: raise RuntimeError('the synthetic QNAMEs are outside the device subset')
         if timed: pack_events.append((e0, e1, kernel))
-        state.update(dna=dna, qual=qual, bad=bad, d=d, nreads=nreads, ls=ls, params=p)
+        state.update(dna=dna, qual=qual, bad=bad, d=d, nreads=nreads, ls=ls, params=p, qname=qres, qname_path=qpath)
 
     for _ in range(args.warmup):
         step(False)
@@ -261,21 +287,24 @@ def main():
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         total_bytes, total_reads = int(tot[0].item()), int(tot[1].item())
 
-    # The QNAME passes (uq.py:394-444, 555-678, 717-736: layout inference, column typing, column encoding) are NOT part of the
-    # timed step (the north_star's hot path is index / histogram / pack); they are timed here, after it, on the same resident
-    # shard, so that the JSON shows what the headline leaves out: qname_ms and value_with_qname = bytes / (step + qname_ms).
-    qname_ms = None
+    # For comparison, outside the timed region: the exact QNAME kernels (two traversals of the QNAME lines) on the same shard.
+    qname_exact_ms = None
     if not use_dist:
         from uq_amd import qname_device
         best = None
         for _ in range(3):
             q0 = time.perf_counter()
-            qres = qname_device.analyse_device(ctx, d_buf, state['ls'], state['nreads'])
+            qex = qname_device.analyse_device(ctx, d_buf, state['ls'], state['nreads'])
             torch.cuda.synchronize()
             q1 = time.perf_counter()
             best = (q1 - q0) if best is None or (q1 - q0) < best else best
-            if qres is None: best = None; break
-        qname_ms = None if best is None else best * 1e3
+            if qex is None: best = None; break
+        qname_exact_ms = None if best is None else best * 1e3
+        if qname_in_step and qex is not None:
+            # the step's columns against the exact path's: same layout, same column descriptions, same arrays
+            a, b = state['qname'], qex
+            if a[:4] != b[:4] or not all(torch.equal(x, y) for x, y in zip(a[4], b[4])):
+                raise RuntimeError('parity failure: the fused QNAME pass differs from the exact kernels')
     # ---- N > 1: the north_star's scaling claim is about the global --sort (BASELINE configs[3]: 200 M x 150 bp over 8 GPUs,
     # `--sort QUAL --raw DNA QUAL QNAME`), whose data-path exchange the weak-scaling step above never touches.  Timed beside it:
     # sample sort of the QUAL table over the ranks (local sort -> splitters -> all-to-all(v) of rows + file-wide indices by key
@@ -353,6 +382,7 @@ def main():
     mode = ((' [TWO reads of the stream, queued back to back (the line count stays on the device for the index and the pack kernel): census + index, then pack + statistics in one kernel with decisions guessed from the shard\'s first '
              '8192 reads; the tables were kept because the whole shard\'s statistics gave the same decisions]' if two_reads else
              ' [three reads of the stream: census, statistics, pack]'))
+    qmode = ' + QNAME layout / typing / column encoding (%s)' % state.get('qname_path') if qname_in_step else ' (QNAME passes not in the step)'
     result = {
         'metric': 'FASTQ encode MB/s (150bp synthetic; bit-exact tables vs reference)',
         'value': round(total_bytes / 1e6 / (dt / args.steps), 1), 'unit': 'MB/s',
@@ -360,11 +390,11 @@ def main():
         'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic',
         'reads_per_s': round((total_reads if total_reads is not None else nreads) / (dt / args.steps), 1),
-        'qname_ms': None if qname_ms is None else round(qname_ms, 3),
-        'value_with_qname': None if qname_ms is None else round(total_bytes / 1e6 / (dt / args.steps + qname_ms / 1e3), 1),
+        'qname': {'in_step': bool(qname_in_step), 'path': state.get('qname_path'),
+                  'exact_kernels_ms': None if qname_exact_ms is None else round(qname_exact_ms, 3)},
         'config': {'workload': ('BASELINE configs[1]: %d x %dbp synth-v1 FASTQ per GPU (%.3f GB), --sort None --raw DNA QUAL QNAME '
-                                '--pattern 0.1 0.1; step = census + index + stats + decisions + %d-bit DNA / %d-bit QUAL pack%s'
-                                % (nreads, args.length, fastq_bytes / 1e9, d['bits_per_base'], d['bits_per_quality'], mode)) if args.workload == 'cfg2' else
+                                '--pattern 0.1 0.1; step = census + index + stats + decisions + %d-bit DNA / %d-bit QUAL pack%s%s'
+                                % (nreads, args.length, fastq_bytes / 1e9, d['bits_per_base'], d['bits_per_quality'], mode, qmode)) if args.workload == 'cfg2' else
                                ('BASELINE configs[4] (%s): %d x 36-301bp synth-v1 FASTQ with 1%% N per GPU (%.3f GB); step = census + index + '
                                 'stats + decisions + %d-bit DNA / %d-bit QUAL variable-length pack%s'
                                 % (args.workload, nreads, fastq_bytes / 1e9, d['bits_per_base'], d['bits_per_quality'], mode)),

@@ -293,6 +293,56 @@ int uq_int_prefix_distinct(uq_ctx* ctx, const int64_t* d_val, uint64_t n, int64_
                            const uint64_t* h_thresholds, int nthresholds, uint64_t* h_counts);
 int uq_encode_int(uq_ctx* ctx, const int64_t* d_val, uint64_t n, int64_t sub, int itemsize, void* d_out);
 
+/* ---- f1 INSIDE a3 / a4: the QNAME passes in the pack kernel's read of the stream (uq.py:394-444 layout inference, 555-565 field
+ * split, 717-736 int() of the fields).  The pack kernel already holds every record's QNAME line in LDS; with a uq_qname_fused it
+ * also splits each line at the separators, parses the fields and writes them as uint32 columns -- against a layout GUESSED on
+ * the device from a sample of the file's own reads, and VERIFIED for every read in the same pass:
+ *   uq_qname_guess[_async]  line 1 of the file and the layout reductions of uq_qname_layout (min lcp / lcs, entry / lastviol per
+ *       character of line 1) over a stratified pseudo-random sample of ~4096 reads -> prefix / suffix lengths and the ordered separators, left in
+ *       *d_q (ok = 1), or ok = 0 when the guess declines (no separator, regex metacharacters, > UQ_QF_MAXC columns, a first line
+ *       beyond 255 bytes, ...): the pack kernel then leaves the QNAME lines alone and the caller runs uq_qname_layout / _tokenise.
+ *   uq_pack_stats_qname[_async]  = uq_pack_stats[_async] + per read: the line starts with line1[:plen] and ends with
+ *       line1[l1len - slen:], its middle holds exactly the separators in order, every field is the canonical decimal of a value
+ *       below 10^9 (digits only, no sign, no leading zero), the line is no proper prefix / suffix of line 1; d_vals[c * pitch + r]
+ *       = value of field c of read r.  Anything else raises d_q->flags (bit0 separators, bit1 line > 255 bytes, bit2 > 9 digits,
+ *       bit3 line shorter than prefix + suffix, bit4 field not a canonical decimal, bit5 / bit6 prefix / suffix mismatch, bit7
+ *       proper prefix / suffix of line 1 (or possibly so), bit8 a tile was not visited).  With flags == 0 and nreads == the number
+ *       of reads the layout IS the reference's: the sample attains the minima (so min lcp / lcs over the file are plen / slen), no
+ *       guessed separator is ever violated, and every other character of line 1 was seen violated at or after its entry in the
+ *       sample (which bounds the file's entry from above and its last violation from below).
+ *   uq_qname_fused_finish  queued behind it: per column the number of distinct values among reads [0, T] at the checkpoints
+ *       T = 10000 * 2^k <= nreads - 1 and T = nreads - 1 (uq.py:586-602, 634-638; canonical decimals: distinct strings = distinct
+ *       values) -- over the whole column for ranges <= 4096, over the checkpoints below 2^21 otherwise (uq_int_prefix_distinct's
+ *       rule); undetermined[c] = 1: range beyond 2^20, not counted.
+ *   uq_qname_fused_fetch  the structure on the host (synchronises).  uq_encode_u32: d_out[i] = (unsigned itemsize)(d_val[i] - sub).
+ * Exact by construction; the caller falls back to uq_qname_layout / uq_qname_tokenise on any flag. */
+#define UQ_QF_MAXC 8
+#define UQ_QF_MAXT 24
+typedef struct uq_qname_fused {
+    uint32_t ok, plen, slen, nsep, l1len;
+    uint32_t flags;                         /* raised by the pack kernel */
+    uint32_t sample_step, nth;
+    uint8_t line1[256];
+    uint8_t seps[32];
+    uint8_t inset[256];
+    uint32_t vmin[UQ_QF_MAXC], vmax[UQ_QF_MAXC];
+    uint32_t undetermined[UQ_QF_MAXC];
+    uint64_t nreads;                        /* reads the pack kernel visited */
+    uint64_t thresholds[UQ_QF_MAXT];
+    uint64_t counts[UQ_QF_MAXC][UQ_QF_MAXT];
+} uq_qname_fused;
+int uq_qname_guess(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start, uint64_t nreads, uq_qname_fused* d_q);
+int uq_qname_guess_async(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start, uq_qname_fused* d_q);
+int uq_pack_stats_qname(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start, uint64_t first_read, uint64_t nreads,
+                        const uq_pack_params* h_guess, uint8_t* d_dna, uint8_t* d_qual, uint64_t* d_bad, uq_stats* d_stats,
+                        uq_qname_fused* d_q, uint32_t* d_vals, uint64_t vals_pitch, int* h_fused);
+int uq_pack_stats_qname_async(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start, uint64_t capacity_reads,
+                              const uq_pack_params* h_guess, uint8_t* d_dna, uint8_t* d_qual, uint64_t* d_bad, uq_stats* d_stats,
+                              uq_qname_fused* d_q, uint32_t* d_vals, uint64_t vals_pitch, int* h_fused);
+int uq_qname_fused_finish(uq_ctx* ctx, uq_qname_fused* d_q, const uint32_t* d_vals, uint64_t vals_pitch);
+int uq_qname_fused_fetch(uq_ctx* ctx, const uq_qname_fused* d_q, uq_qname_fused* h_out);
+int uq_encode_u32(uq_ctx* ctx, const uint32_t* d_val, uint64_t n, uint32_t sub, int itemsize, void* d_out);
+
 /* ---- f3: FASTQ text assembled on the device.  Replaces the decoder's exec-compiled convert_qname
  * (uq.py:1010-1026) and its four prints per read (uq.py:1042-1045).  Inputs: the fixed-pitch text and
  * lengths uq_unpack produced, and the QNAME columns (device arrays, one value per read, little-endian

@@ -12,7 +12,10 @@ pytestmark = pytest.mark.gpu
 
 
 def _fastq(names):
-    return b''.join(n + b'\nACGT\n+\nIIII\n' for n in names)
+    # (qualities that vary per base: with one quality for all of them every base would be an N-trick base, and the pack kernel the
+    # fused QNAME pass rides in has no speculative form for the new quality codes of Q9)
+    quals = (b'FGHI', b'GHIF', b'HIFG', b'IFGH')
+    return b''.join(n + b'\nACGT\n+\n' + quals[i & 3] + b'\n' for i, n in enumerate(names))
 
 
 def _oracle(fq):
@@ -48,8 +51,46 @@ def _device(ctx, fq):
     return ('ok', pre, suf, sep, cols, [ctx.to_numpy(a, np.dtype(c['dtype'])) for a, c in zip(arrs, cols)])
 
 
-def _check(ctx, fq, must_answer=False):
+FUSED = True            # tests/test_qname_device_cpu.py (numpy stand-ins, no pack kernel) switches the fused checks off
+FUSED_TALLY = {'ok': 0, 'declined': 0}
+
+
+def _fused(ctx, fq):
+    """The QNAME passes inside the pack kernel (uq_qname_guess -> uq_pack_stats_qname -> uq_qname_fused_finish ->
+    qname_device.analyse_fused): ('ok', ...) or ('declined',) -- the fused pass never refuses on its own, it stands down."""
+    buf, ls, n = INDEX(ctx, fq)
+    guess = ops.head_guess_indexed(ctx, buf, ls, n) if n else None
+    if guess is None:
+        return ('declined',)
+    fq_dev = ops.FusedQname(ctx, n)
+    ops.qname_guess(ctx, buf, ls, n, fq_dev)
+    if ops.pack_stats(ctx, buf, ls, 0, n, guess, fq=fq_dev) is None:
+        return ('declined',)
+    ops.qname_fused_finish(ctx, fq_dev)
+    got = qname_device.analyse_fused(ctx, fq_dev, n)
+    if got is None:
+        return ('declined',)
+    pre, suf, sep, cols, arrs = got
+    return ('ok', pre, suf, sep, cols, [ctx.to_numpy(a, np.dtype(c['dtype'])) for a, c in zip(arrs, cols)])
+
+
+def _check_fused(ctx, fq, want, must_answer=False):
+    """An answer of the fused pass must be the oracle's answer (so the oracle must HAVE one); anything else it declines."""
+    got = _fused(ctx, fq)
+    FUSED_TALLY[got[0]] += 1
+    if got[0] == 'declined':
+        assert not must_answer, 'the fused QNAME pass declined an input it is meant to handle'
+        return
+    assert want[0] == 'ok', ('the fused pass answered where the reference refuses', got[1:5], want)
+    assert got[1:4] == want[1:4], (got[1:4], want[1:4])
+    assert got[4] == want[4], (got[4], want[4])
+    for a, b in zip(got[5], want[5]):
+        assert a.dtype == b.dtype and np.array_equal(a, b)
+
+
+def _check(ctx, fq, must_answer=False, fused_must_answer=False):
     want, got = _oracle(fq), _device(ctx, fq)
+    if FUSED: _check_fused(ctx, fq, want, fused_must_answer)
     if got[0] == 'declined':
         assert not must_answer, 'device path declined an input it is meant to handle'
         return 'declined'
@@ -64,7 +105,7 @@ def _check(ctx, fq, must_answer=False):
 
 def test_synthetic_illumina_names(ctx):
     for fq in (synth.fastq(5, 3000, 50), synth.fastq(6, 25000, 8)):
-        assert _check(ctx, fq, must_answer=True) == 'ok'
+        assert _check(ctx, fq, must_answer=True, fused_must_answer=True) == 'ok'
     for n in (1, 2, 3, 11):
         _check(ctx, synth.fastq(7, n, 20), must_answer=True)      # tiny files: same answer or same refusal
 
@@ -93,7 +134,7 @@ def test_mapping_columns_and_suffix(ctx):
 def test_long_integer_fields(ctx):
     # SRA-style read numbers beyond 8 digits: 8-byte key falls back to the value (canonical integers)
     names = [b'@SRR1.%d/%d' % ((i * 7919317) % 900000000 + 100000000, i % 2 + 1) for i in range(12000)]
-    assert _check(ctx, _fastq(names), must_answer=True) == 'ok'
+    assert _check(ctx, _fastq(names), must_answer=True, fused_must_answer=True) == 'ok'
     # ... but a column of long numbers that stays a mapping needs the strings themselves: host path
     names = [b'@r:%d:%d' % ([100000000000, 5][i % 2], i) for i in range(200)]
     assert _device(ctx, _fastq(names))[0] == 'declined'
@@ -162,10 +203,69 @@ def _random_family(rng, n):
 def test_random_grammars_differential(ctx):
     rng = np.random.default_rng(20261003)
     tally = {'ok': 0, 'error': 0, 'declined': 0}
+    FUSED_TALLY.update(ok=0, declined=0)
     for case in range(120):
         n = int(rng.integers(2, 400))
         tally[_check(ctx, _fastq(_random_family(rng, n)))] += 1
     assert tally['ok'] >= 40, tally           # the device path answers a solid share of random grammars
+
+
+def test_fused_pass_random_decimal_grammars(ctx):
+    """Random grammars whose fields are all plain decimals (what sequencers write): the fused pass answers nearly all of them --
+    and every answer is the oracle's."""
+    rng = np.random.default_rng(77)
+    FUSED_TALLY.update(ok=0, declined=0)
+    seps_pool = ':_/#=;, '
+    for case in range(60):
+        n = int(rng.integers(2, 3000))
+        nf = int(rng.integers(2, 7))
+        seps = [seps_pool[int(rng.integers(0, len(seps_pool)))] for _ in range(nf - 1)]
+        kinds = [['lane', 'tile', 'coord', 'serial', 'wide'][int(rng.integers(0, 5))] for _ in range(nf)]
+        prefix = [b'@', b'@RUN7:', b'@M0123_45 '][int(rng.integers(0, 3))]
+        suffix = [b'', b'/1', b' end'][int(rng.integers(0, 3))]
+        period = int(rng.integers(1, 5))
+        names = []
+        for i in range(n):
+            f = []
+            for k in kinds:
+                if k == 'lane': f.append(b'%d' % (1 + i % period))
+                elif k == 'tile': f.append(b'%d' % (1101 + int(rng.integers(0, 64))))
+                elif k == 'coord': f.append(b'%d' % int(rng.integers(1000, 30000)))
+                elif k == 'serial': f.append(b'%d' % i)
+                else: f.append(b'%d' % int(rng.integers(0, 999999999)))
+            name = prefix
+            for j, x in enumerate(f):
+                name += x
+                if j < nf - 1: name += seps[j].encode()
+            names.append(name + suffix)
+        _check(ctx, _fastq(names))
+    assert FUSED_TALLY['ok'] >= 40, FUSED_TALLY
+
+
+def test_fused_pass_demotion_and_offsets(ctx):
+    """The fused pass on columns that exercise every typing branch it answers: mapping -> integers by the 10 000 / 20 000 / final
+    checkpoints, small mappings that turn into integers with and without an offset, wide ranges judged on the checkpoints below
+    2^21, and the cases it must hand back (a mapping whose values are too far apart, a value range beyond 2^20 that no
+    checkpoint demotes)."""
+    n = 23000
+    names = [b'@q:%d:%d:%d:%d' % ((i % 1001) * 3, (i % 1000 if i <= 10000 else i % 2001) * 1000, 1101 + i % 64, i % 4) for i in range(n)]
+    assert _check(ctx, _fastq(names), must_answer=True, fused_must_answer=True) == 'ok'
+    n = 15000
+    names = [b'@q:%d:%d' % (i % 7, (i % 1000) if i < 12000 else i) for i in range(n)]
+    assert _check(ctx, _fastq(names), must_answer=True, fused_must_answer=True) == 'ok'
+    names = [b'@r_%d_%d' % ([5, 70000, 12345678, 31][i % 4], i % 3) for i in range(400)]          # stays a mapping of strings
+    assert _check(ctx, _fastq(names), must_answer=True) == 'ok' and _fused(ctx, _fastq(names))[0] == 'declined'
+    names = [b'@r_%d_%d' % ((i * 999331) % 3000000, i % 3) for i in range(30000)]                  # range 3 M > 2^20 slots
+    assert _check(ctx, _fastq(names), must_answer=True) == 'ok'
+    names = [b'@r_%d_%d' % (i, 250 + i % 10) for i in range(70000)]                                # u4 / offset columns
+    assert _check(ctx, _fastq(names), must_answer=True, fused_must_answer=True) == 'ok'
+    # reads that break the layout late in the file: the fused pass must notice each of them
+    base = [b'@r_%d_%d' % (i % 50, i) for i in range(20000)]
+    for bad in (b'@r_7_x9', b'@r_7_007', b'@r_7', b'@r_7_8_9', b'@q_7_8', b'@r_7_+8', b'@r_7_', b'@r_7_12345678901'):
+        names = list(base); names[17000] = bad
+        want = _oracle(_fastq(names))
+        _check_fused(ctx, _fastq(names), want)
+        assert _fused(ctx, _fastq(names))[0] == 'declined', bad
 
 
 def test_mutated_names_differential(ctx):
@@ -202,12 +302,13 @@ def test_cli_uses_device_qname_path(ctx, tmp_path):
     fq = synth.fastq(99, 4000, 40)
     inp = tmp_path / 'in.fastq'; inp.write_bytes(fq)
     outs = {}
-    for flag in ([], ['--host-qname']):
-        out = tmp_path / ('o%d.uQ' % len(flag))
+    for k, flag in enumerate(([], ['--exact-qname'], ['--host-qname'])):
+        out = tmp_path / ('o%d.uQ' % k)
         args = uq.build_parser().parse_args(['-i', str(inp), '-o', str(out), '--quiet'] + flag)
         uq.validate_args(args)
         s = uq.Session(args, ctx=ctx)
         s.encode()
-        outs[len(flag)] = (s.qname_path, O.read_tar(str(out)))
-    assert outs[0][0] == 'device' and outs[1][0] == 'host-native'
-    assert outs[0][1][0] == outs[1][1][0] and outs[0][1][1] == outs[1][1][1]
+        outs[k] = (s.qname_path, O.read_tar(str(out)))
+    assert [outs[k][0] for k in range(3)] == ['fused', 'device', 'host-native']
+    for k in (1, 2):
+        assert outs[0][1][0] == outs[k][1][0] and outs[0][1][1] == outs[k][1][1]

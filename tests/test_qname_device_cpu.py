@@ -19,6 +19,7 @@ def fake(monkeypatch):
         ls = oracle_c.index_lines(host)
         return torch.from_numpy(host), torch.from_numpy(ls.view(np.int64).copy()), (len(ls) - 1) // 4
     monkeypatch.setattr(T, 'INDEX', index)
+    monkeypatch.setattr(T, 'FUSED', False)
     monkeypatch.setattr(qname_device, 'ops', F)
     return F.FakeCtx()
 

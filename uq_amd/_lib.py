@@ -50,6 +50,14 @@ class QnameColsResult(C.Structure):
                 ('any_long', C.c_uint32 * 32), ('flags', C.c_uint32), ('reserved', C.c_uint32)]
 
 
+class QnameFused(C.Structure):
+    _fields_ = [('ok', C.c_uint32), ('plen', C.c_uint32), ('slen', C.c_uint32), ('nsep', C.c_uint32), ('l1len', C.c_uint32),
+                ('flags', C.c_uint32), ('sample_step', C.c_uint32), ('nth', C.c_uint32),
+                ('line1', C.c_uint8 * 256), ('seps', C.c_uint8 * 32), ('inset', C.c_uint8 * 256),
+                ('vmin', C.c_uint32 * 8), ('vmax', C.c_uint32 * 8), ('undetermined', C.c_uint32 * 8),
+                ('nreads', C.c_uint64), ('thresholds', C.c_uint64 * 24), ('counts', (C.c_uint64 * 24) * 8)]
+
+
 class SynthSpec(C.Structure):
     _fields_ = [('seed', C.c_uint64), ('len_lo', C.c_int32), ('len_hi', C.c_int32), ('n_rate', C.c_int32),
                 ('n_qual_exclusive', C.c_int32), ('dup', C.c_int32), ('dup_templates', C.c_int32),
@@ -113,6 +121,13 @@ SIGNATURES = {
     'uq_prefix_distinct': [_vp, _vp, _int, _vp, _u64, _P(_u64), _int, _P(_u64)],
     'uq_int_prefix_distinct': [_vp, _vp, _u64, C.c_int64, _u64, _u64, _P(_u64), _int, _P(_u64)],
     'uq_encode_int': [_vp, _vp, _u64, C.c_int64, _int, _vp],
+    'uq_qname_guess': [_vp, _vp, _vp, _u64, _vp],
+    'uq_qname_guess_async': [_vp, _vp, _vp, _vp],
+    'uq_pack_stats_qname': [_vp, _vp, _vp, _u64, _u64, _P(PackParams), _vp, _vp, _vp, _vp, _vp, _vp, _u64, _P(_int)],
+    'uq_pack_stats_qname_async': [_vp, _vp, _vp, _u64, _P(PackParams), _vp, _vp, _vp, _vp, _vp, _vp, _u64, _P(_int)],
+    'uq_qname_fused_finish': [_vp, _vp, _vp, _u64],
+    'uq_qname_fused_fetch': [_vp, _vp, _P(QnameFused)],
+    'uq_encode_u32': [_vp, _vp, _u64, _u32, _int, _vp],
     'uq_emit_fastq': [_vp, _P(EmitParams), _P(_vp), _P(_vp), _P(_vp), _vp, _vp, _vp, _u64, _vp, _vp, _u64, _P(_u64)],
     'uq_debug_scribble_lds': [_vp, C.c_uint32],
     'uq_decode_fastq': [_vp, _P(EmitParams), _P(UnpackParams), _P(_vp), _P(_vp), _P(_vp), _vp, _vp, _u64, _vp, _vp, _vp, _vp, _u64, _P(_u64), _P(_u64)],

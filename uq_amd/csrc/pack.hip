@@ -88,6 +88,65 @@ __device__ __noinline__ void store_tile(uint8_t* gdst, const uint8_t* lsrc, uint
     }
 }
 
+// ---- the QNAME phase of the fused pack + statistics kernel (uq_pack_stats_qname; SURVEY.md 8 row f1 inside rows a3 / a4).
+// The tile's QNAME lines are in the stage already; the lanes of ONE wave take a read each, check the line against the guessed
+// layout (qname_fused.hip: prefix = line1[:plen], suffix = line1[l1len - slen:], ordered separators) and parse its fields
+// (uq.py:560-565 split, 724-726 int()): value of field c of read `row` -> vals[c * pitch + row].  Whatever does not conform
+// raises a flag (include/uqhip.h lists them); the host then runs the exact passes of qname_dev.hip instead.
+struct QnLds {
+    uint8_t line1[256];
+    uint8_t inset[256];
+    uint8_t seps[32];
+    uint32_t vmin[UQ_QF_MAXC], vmax[UQ_QF_MAXC];
+    uint32_t flags, on, plen, slen, nsep, l1len, pad0, pad1;
+};
+
+__device__ __forceinline__ void qname_tile(const uint8_t* stage, const uint32_t* meta, uint32_t q, QnLds* s, uint32_t* __restrict__ vals, uint64_t pitch,
+                                        uint64_t row) {
+    const uint32_t qs = meta[4 * q], ql = meta[4 * q + 1] - qs - 1;
+    const uint32_t plen = s->plen, slen = s->slen, nsep = s->nsep, l1len = s->l1len;
+    uint32_t f = 0;
+    if (ql > 255) f = 2;
+    else if (ql < plen + slen) f = 8;
+    else {
+        const uint8_t* p = stage + qs;
+        for (uint32_t j = 0; j < plen; ++j) if (p[j] != s->line1[j]) f |= 32u;
+        for (uint32_t j = 0; j < slen; ++j) if (p[ql - slen + j] != s->line1[l1len - slen + j]) f |= 64u;
+        const uint32_t end = ql - slen;
+        uint32_t col = 0, mag = 0, nd = 0;
+        bool eq = true, lead0 = false;                      // eq: the line equals line1[:pos] so far (it does up to plen when bit5 stays down)
+        auto close = [&]() {
+            if (nd > 9) f |= 4u;
+            else if (nd == 0 || (lead0 && nd > 1)) f |= 16u;
+            if (col < UQ_QF_MAXC) {
+                vals[col * pitch + row] = mag;
+                if (mag < s->vmin[col]) atomicMin(&s->vmin[col], mag);
+                if (mag > s->vmax[col]) atomicMax(&s->vmax[col], mag);
+            }
+        };
+        for (uint32_t pos = plen; pos < end; ++pos) {
+            const uint32_t b = p[pos];
+            eq = eq && pos < l1len && b == s->line1[pos];
+            if (s->inset[b]) {
+                if (col >= nsep || b != s->seps[col]) f |= 1u;
+                close();
+                ++col; mag = 0; nd = 0; lead0 = false;
+            } else {
+                const uint32_t d = b - '0';
+                if (d > 9) f |= 16u;
+                if (nd == 0) lead0 = d == 0;
+                mag = mag * 10 + d; ++nd;
+            }
+        }
+        if (col != nsep) f |= 1u;
+        close();
+        for (uint32_t pos = end; pos < ql; ++pos) eq = eq && pos < l1len && p[pos] == s->line1[pos];
+        if (ql < l1len && eq) f |= 128u;                                          // a proper prefix of line 1
+        if (ql < l1len && s->line1[l1len - ql] == s->line1[0]) f |= 128u;         // could be a proper suffix of it: the exact pass decides
+    }
+    if (f) atomicOr(&s->flags, f);
+}
+
 constexpr int PK_NV = 5;   // 16-byte loads per lane per tile: a tile spans at most PK_NV * 256 * 16 = 20 KiB
 constexpr int PK_NV_STATS = 4;   // the fused pack + statistics kernel keeps a few KiB of LDS for its count table: 16 KiB tiles, same occupancy
 // Its counts are taken on the CODES the lookup-free conversion has just produced (bin = base code << 6 | quality code: two
@@ -112,7 +171,8 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && NTRICK) ? 4 : 5) void pack_ti
                                                                uint64_t n, PackLut lut, PackGeom g,
                                                                uint8_t* __restrict__ dna, uint8_t* __restrict__ qual,
                                                                unsigned long long* __restrict__ bad,
-                                                               uq_stats* __restrict__ st, const unsigned long long* __restrict__ d_async) {
+                                                               uq_stats* __restrict__ st, const unsigned long long* __restrict__ d_async,
+                                                               uq_qname_fused* __restrict__ qf, uint32_t* __restrict__ qvals, uint64_t qpitch) {
     constexpr int NV = STATS ? PK_NV_STATS : PK_NV;
     extern __shared__ __align__(16) uint8_t smem[];
     uint8_t* stage = smem + 16;                       // reads of up to 8 bytes below offset 0 stay in bounds
@@ -131,6 +191,15 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && NTRICK) ? 4 : 5) void pack_ti
     uint32_t* cnt_tab = (uint32_t*)(l_nq + 256);                 // [256 bins][PKS_COPIES], then [128] N-trick base by quality character
     uint32_t fill_pairs = 0, n_pairs = 0;                        // pairs counted in bin 0 / bin n_code that were fills / N-trick positions
     if (STATS) for (uint32_t i = tid; i < PKS_WORDS; i += PK_THREADS) cnt_tab[i] = 0;       // the first tile's barrier orders it
+    QnLds* qn = (QnLds*)(cnt_tab + PKS_WORDS);                   // the QNAME phase's state (uq_pack_stats_qname only)
+    bool qn_on = false;
+    if (STATS && qf) {
+        qn_on = qf->ok != 0;                                     // the guess kernels in front may have declined: the lines are left alone
+        qn->line1[tid] = qf->line1[tid]; qn->inset[tid] = qf->inset[tid];
+        if (tid < 32) qn->seps[tid] = qf->seps[tid];
+        if (tid < UQ_QF_MAXC) { qn->vmin[tid] = 0xFFFFFFFFu; qn->vmax[tid] = 0; }
+        if (tid == 0) { qn->flags = 0; qn->plen = qf->plen; qn->slen = qf->slen; qn->nsep = qf->nsep; qn->l1len = qf->l1len; }
+    }
     if (d_async) {                                    // the queued form (uq_pack_stats_async): the census in front left the line count on the device;
         const uint64_t have = d_async[0] / 4;         // `n` is what the tables hold
         if (have > n) incomplete = true; else n = have;
@@ -188,10 +257,14 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && NTRICK) ? 4 : 5) void pack_ti
         } else {
             if (tid == 0) bad_tile = bad_tile < r0 ? bad_tile : r0;
             incomplete = true;
+            if (STATS && qn_on && tid == 0) atomicOr(&qf->flags, 256u);
         }
         __syncthreads();
         const bool ok = cur.ok;
         between();
+        // the QNAME lines of the tile: one wave (the last: it has the fewest lanes busy in phase B), a lane per read
+        if (STATS && qn_on && ok && tid >= PK_THREADS - 64 && tid - (PK_THREADS - 64) < Rt)
+            qname_tile(stage, meta, tid - (PK_THREADS - 64), qn, qvals, qpitch, r0 + (tid - (PK_THREADS - 64)));
         if (ok) {
             // ---- B: P lanes per read; a lane owns groups of 8 consecutive symbols, both streams:
             //         characters -> codes -> bits (8 symbols of b bits = b whole bytes)
@@ -384,6 +457,11 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && NTRICK) ? 4 : 5) void pack_ti
         }
         acc.flush(st, first);
         if (incomplete) st->reserved = 1;
+        if (qf) {                                            // (the barrier above also closes the last tile's QNAME phase)
+            if (qn_on && tid < UQ_QF_MAXC && qn->vmin[tid] <= qn->vmax[tid]) { atomicMin(&qf->vmin[tid], qn->vmin[tid]); atomicMax(&qf->vmax[tid], qn->vmax[tid]); }
+            if (qn_on && tid == 0 && qn->flags) atomicOr(&qf->flags, qn->flags);
+            if (blockIdx.x == 0 && tid == 0) qf->nreads = n;
+        }
     }
 }
 
@@ -424,7 +502,7 @@ __global__ __launch_bounds__(256) void pack_carry_kernel(const uint8_t* __restri
 }
 
 typedef void (*PackKernel)(const uint8_t*, const uint64_t*, uint64_t, uint64_t, PackLut, PackGeom, uint8_t*, uint8_t*, unsigned long long*,
-                           uq_stats*, const unsigned long long*);
+                           uq_stats*, const unsigned long long*, uq_qname_fused*, uint32_t*, uint64_t);
 
 template <int BD, int BQ>
 PackKernel pick_nt(bool ntrick, bool fast) {
@@ -461,7 +539,8 @@ PackKernel pick_kernel(int bd, int bq, bool ntrick, bool fast) {
 // (*h_fused = 1); if not, nothing is launched and *h_fused = 0.
 static int pack_impl(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start, uint64_t first_read,
                      uint64_t nreads, const uq_pack_params* hp, uint8_t* d_dna, uint8_t* d_qual, uint64_t* d_bad,
-                     uq_stats* d_stats, int* h_fused, const unsigned long long* d_async = nullptr) {
+                     uq_stats* d_stats, int* h_fused, const unsigned long long* d_async = nullptr, uq_qname_fused* d_q = nullptr,
+                     uint32_t* d_vals = nullptr, uint64_t vals_pitch = 0) {
     UQ_REQUIRE(ctx && d_buf && d_line_start && hp && d_dna && d_qual && d_bad, "uq_pack: null argument");
     if (h_fused) *h_fused = 0;
     UQ_REQUIRE(hp->bits_per_base >= 1 && hp->bits_per_base <= 8 && hp->bits_per_quality >= 1 && hp->bits_per_quality <= 8,
@@ -589,7 +668,7 @@ static int pack_impl(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_s
     }
     if (d_stats && ntrick_bases == 1 && hp->n_qual[nchar] >= nq) return 0;    // the N-trick code is no quality of the alphabet (Q9): exact kernels only
     if (d_stats && (!fast || bd != 2 || bq > 6)) return 0;  // the fused kernels exist for the 2-bit lookup-free path with a bin per byte (<= 64 qualities) only
-    const size_t lds = 16 + (size_t)g.stage_bytes + g.out_bytes + (4 * R + 4) * 4 + 3 * 512 + (d_stats ? PKS_WORDS * 4 : 0);
+    const size_t lds = 16 + (size_t)g.stage_bytes + g.out_bytes + (4 * R + 4) * 4 + 3 * 512 + (d_stats ? PKS_WORDS * 4 + sizeof(QnLds) : 0);
     UQ_REQUIRE(lds <= 160 * 1024, "uq_pack: tile needs %zu bytes of LDS", lds);
     const uint64_t tiles = (nreads + R - 1) / R;
     uint32_t per_cu = (uint32_t)((160 * 1024) / lds);
@@ -599,7 +678,7 @@ static int pack_impl(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_s
     PackKernel k = d_stats ? pick_stats_kernel((int)bq, ntrick) : pick_kernel((int)bd, (int)bq, ntrick, fast);
     if (lds > 48 * 1024) UQ_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     k<<<(uint32_t)blocks, PK_THREADS, lds, ctx->stream>>>(d_buf, d_line_start, first_read, nreads, lut, g, d_dna, d_qual,
-                                                         (unsigned long long*)d_bad, d_stats, d_async);
+                                                         (unsigned long long*)d_bad, d_stats, d_async, d_q, d_vals, vals_pitch);
     UQ_LAUNCH_CHECK();
     if (h_fused) *h_fused = 1;
     return 0;
@@ -625,5 +704,23 @@ extern "C" int uq_pack_stats_async(uq_ctx* ctx, const uint8_t* d_buf, const uint
     UQ_REQUIRE(d_stats && h_fused, "uq_pack_stats_async: null argument");
     UQ_REQUIRE(ctx && ctx->async_buf == d_buf, "uq_pack_stats_async: not the buffer of the last uq_count_lines_end_async");
     UQ_TRY(pack_impl(ctx, d_buf, d_line_start, 0, capacity_reads, h_guess, d_dna, d_qual, d_bad, d_stats, h_fused, ctx->d_async));
+    return uq_async_read_back(ctx);
+}
+
+// uq_pack_stats / uq_pack_stats_async with the QNAME phase (qname_fused.hip made the guess in *d_q): d_vals holds UQ_QF_MAXC columns
+// of vals_pitch uint32 each.  *h_fused = 0: this geometry has no fused kernel, nothing ran (d_q->nreads stays 0).
+extern "C" int uq_pack_stats_qname(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start, uint64_t first_read, uint64_t nreads,
+                                   const uq_pack_params* h_guess, uint8_t* d_dna, uint8_t* d_qual, uint64_t* d_bad, uq_stats* d_stats,
+                                   uq_qname_fused* d_q, uint32_t* d_vals, uint64_t vals_pitch, int* h_fused) {
+    UQ_REQUIRE(d_stats && h_fused && d_q && d_vals && vals_pitch >= nreads, "uq_pack_stats_qname: null argument or columns shorter than the reads");
+    return pack_impl(ctx, d_buf, d_line_start, first_read, nreads, h_guess, d_dna, d_qual, d_bad, d_stats, h_fused, nullptr, d_q, d_vals, vals_pitch);
+}
+
+extern "C" int uq_pack_stats_qname_async(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start, uint64_t capacity_reads,
+                                         const uq_pack_params* h_guess, uint8_t* d_dna, uint8_t* d_qual, uint64_t* d_bad, uq_stats* d_stats,
+                                         uq_qname_fused* d_q, uint32_t* d_vals, uint64_t vals_pitch, int* h_fused) {
+    UQ_REQUIRE(d_stats && h_fused && d_q && d_vals && vals_pitch >= capacity_reads, "uq_pack_stats_qname_async: null argument or columns shorter than the capacity");
+    UQ_REQUIRE(ctx && ctx->async_buf == d_buf, "uq_pack_stats_qname_async: not the buffer of the last uq_count_lines_end_async");
+    UQ_TRY(pack_impl(ctx, d_buf, d_line_start, 0, capacity_reads, h_guess, d_dna, d_qual, d_bad, d_stats, h_fused, ctx->d_async, d_q, d_vals, vals_pitch));
     return uq_async_read_back(ctx);
 }

@@ -1,0 +1,333 @@
+// qname_fused.hip -- what surrounds the QNAME phase of the pack kernel (pack.hip, `qname_tile`): the layout GUESS made on the
+// device in front of it and the distinct-value counts behind it (SURVEY.md 8 row f1 fused into rows a3 / a4).
+//
+// The reference infers prefix, suffix and separators in one sequential loop over all QNAME lines (uq.py:394-444), splits every line
+// at the separators (uq.py:555-565) and int()s the fields (uq.py:717-736).  qname_dev.hip does that as two traversals of the QNAME
+// lines (layout reductions, then the tokeniser) with a host decision in between.  Here the layout is guessed from a SAMPLE:
+//   qname_sample_kernel   builds line 1's character table in every workgroup and runs qname_dev.hip's layout reductions (min lcp /
+//                         lcs with line 1, entry / last violation per character of line 1) over a stratified sample of the reads;
+//   qname_guess_kernel    one lane: uq.py:428-444 on those numbers -> prefix / suffix lengths, ordered separators -> uq_qname_fused;
+// the pack kernel then verifies the guess on EVERY read while it tokenises (so nothing is assumed: see include/uqhip.h for why a
+// clean pass proves the layout is the reference's), and
+//   qf_first_seen_kernel / qf_count_kernel   count, per column of uint32 values, the distinct values among reads [0, T] at the
+//                         checkpoints of uq.py:586-602 (first occurrence per value by atomic minima; no sort).
+// Nothing here waits for the host: the read count is taken from the queued census (ctx->d_async) or from the structure itself.
+#include "common.h"
+
+namespace {
+constexpr int QF_THREADS = 256;
+constexpr int QF_MAXCH = 64;
+constexpr uint32_t QF_SAMPLES = 4096;
+constexpr uint32_t QF_ROW = 64, QF_STRIDE = QF_ROW + 4;     // per-lane staging row (as qname_dev.hip)
+constexpr uint32_t QF_FT = 1u << 20;                        // first-occurrence slots per column
+constexpr uint32_t QF_SMALL = 4096;                         // ranges counted over the whole column, through private LDS tables
+constexpr uint64_t QF_PREFIX = 1ull << 21;                  // checkpoints a wide-range column is judged on (qname_device.INT_PREFIX)
+
+struct DevLine1 {
+    uint8_t text[256];
+    uint8_t slot[256];              // character -> candidate slot, 0xFF = not in line 1
+    uint8_t ch[QF_MAXCH];
+    uint16_t cnt[QF_MAXCH];         // occurrences in line 1
+    uint16_t lastpos[QF_MAXCH];     // last position in line 1
+    uint32_t len, nch, bad, pad;    // bad: no usable line 1 (empty buffer, not '@...', longer than 255 bytes, more than 64 distinct characters)
+};
+
+__device__ __forceinline__ void stage_line(uint8_t* row, const uint8_t* q, uint32_t ql, const uint8_t* buf_end) {
+    for (uint32_t c = 0; c < ql; c += 16) {
+        if (q + c + 16 <= buf_end) {
+            uint4 v;
+            __builtin_memcpy(&v, q + c, 16);
+            uint32_t* d = (uint32_t*)(row + c);
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        } else {
+            for (uint32_t b = c; b < ql; ++b) row[b] = q[b];
+        }
+    }
+}
+
+// n: reads in the buffer (d_async: taken from the queued census).  `lay` was initialised by the host side of the call.
+__global__ __launch_bounds__(QF_THREADS) void qname_sample_kernel(const uint8_t* __restrict__ buf, const uint64_t* __restrict__ ls, uint64_t n,
+                                                                   const unsigned long long* __restrict__ d_async, uq_qname_layout_result* __restrict__ lay,
+                                                                   DevLine1* __restrict__ l1_out, uint32_t* __restrict__ step_out) {
+    __shared__ uint8_t cnt[QF_MAXCH * QF_THREADS];
+    __shared__ __align__(16) uint8_t stage[QF_THREADS * QF_STRIDE];
+    __shared__ DevLine1 l1;
+    __shared__ unsigned long long s_entry[QF_MAXCH], s_viol[QF_MAXCH];
+    __shared__ uint32_t s_lcp, s_lcs, s_flags;
+    const uint32_t tid = threadIdx.x;
+    if (d_async) n = d_async[1] ? 0 : d_async[0] / 4;
+    // ---- line 1 and its character table (every workgroup builds its own copy: 255 bytes, one lane)
+    uint32_t len = 0;
+    if (n) { const uint64_t e = ls[1]; len = e >= 1 && e <= 256 ? (uint32_t)(e - 1) : 0xFFFFFFFFu; }
+    l1.text[tid] = (len != 0xFFFFFFFFu && tid < len) ? buf[tid] : 0;
+    l1.slot[tid] = 0xFF;
+    if (tid < QF_MAXCH) { l1.ch[tid] = 0; l1.cnt[tid] = 0; l1.lastpos[tid] = 0; s_entry[tid] = UQ_NONE; s_viol[tid] = 0; }
+    if (tid == 0) { s_lcp = 0xFFFFFFFFu; s_lcs = 0xFFFFFFFFu; s_flags = 0; }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t nch = 0, bad = (len == 0 || len == 0xFFFFFFFFu || l1.text[0] != '@') ? 1u : 0u;
+        if (!bad)
+            for (uint32_t p = 0; p < len; ++p) {
+                const uint8_t c = l1.text[p];
+                if (l1.slot[c] == 0xFF) {
+                    if (nch == QF_MAXCH) { bad = 1; break; }
+                    l1.slot[c] = (uint8_t)nch; l1.ch[nch] = c; ++nch;
+                }
+                l1.cnt[l1.slot[c]] += 1; l1.lastpos[l1.slot[c]] = (uint16_t)p;
+            }
+        l1.len = bad ? 0 : len; l1.nch = nch; l1.bad = bad; l1.pad = 0;
+    }
+    __syncthreads();
+    const uint32_t step = (uint32_t)(n / QF_SAMPLES > 1 ? n / QF_SAMPLES : 1);
+    if (blockIdx.x == 0) {
+        for (uint32_t i = tid; i < sizeof(DevLine1) / 4; i += QF_THREADS) ((uint32_t*)l1_out)[i] = ((const uint32_t*)&l1)[i];
+        if (tid == 0) *step_out = step;
+    }
+    if (l1.bad) return;
+    for (uint32_t k = 0; k < l1.nch; ++k) cnt[k * QF_THREADS + tid] = 0;
+    const uint8_t* buf_end = buf + ls[4 * n];
+    uint32_t my_lcp = 0xFFFFFFFFu, my_lcs = 0xFFFFFFFFu;
+    // sample = one record out of every `step` consecutive ones, at a pseudo-random place in its stratum (a fixed stride would
+    // alias with periodic names: interleaved mates, lanes that cycle); record 0 is line 1 itself
+    for (uint64_t k = (uint64_t)blockIdx.x * QF_THREADS + tid; k * step < n; k += (uint64_t)gridDim.x * QF_THREADS) {
+        uint64_t h = (k + 0x9E3779B97F4A7C15ull) * 0xBF58476D1CE4E5B9ull;
+        h ^= h >> 29; h *= 0x94D049BB133111EBull; h ^= h >> 32;
+        const uint64_t i = k * step + h % step;
+        if (i == 0 || i >= n) continue;
+        const uint8_t* q = buf + ls[4 * i];
+        const uint32_t ql = (uint32_t)(ls[4 * i + 1] - ls[4 * i] - 1);
+        if (ql > 255) { atomicOr(&s_flags, 2u); continue; }
+        const uint8_t* row = stage + tid * QF_STRIDE;
+        const bool staged = ql <= QF_ROW;
+        if (staged) stage_line(stage + tid * QF_STRIDE, q, ql, buf_end);
+        auto at = [&](uint32_t j) -> uint32_t { return staged ? row[j] : q[j]; };
+        const uint32_t m = ql < l1.len ? ql : l1.len;
+        uint32_t lcp = 0;
+        while (lcp < m && at(lcp) == l1.text[lcp]) ++lcp;
+        uint32_t lcs = 0;
+        while (lcs < m && at(ql - 1 - lcs) == l1.text[l1.len - 1 - lcs]) ++lcs;
+        if ((lcp == ql && ql < l1.len) || (lcs == ql && ql < l1.len)) atomicOr(&s_flags, 1u);
+        if (lcp < my_lcp) my_lcp = lcp;
+        if (lcs < my_lcs) my_lcs = lcs;
+        for (uint32_t j = 0; j < ql; ++j) {
+            const uint32_t sl = l1.slot[at(j)];
+            if (sl != 0xFFu) cnt[sl * QF_THREADS + tid] += 1;
+        }
+        for (uint32_t c = 0; c < l1.nch; ++c) {
+            const uint32_t have = cnt[c * QF_THREADS + tid];
+            cnt[c * QF_THREADS + tid] = 0;
+            if (lcp <= l1.lastpos[c] && (unsigned long long)i < s_entry[c]) atomicMin(&s_entry[c], (unsigned long long)i);
+            if (have != l1.cnt[c] && (unsigned long long)i > s_viol[c]) atomicMax(&s_viol[c], (unsigned long long)i);
+        }
+    }
+    my_lcp = wave_min(my_lcp); my_lcs = wave_min(my_lcs);
+    if (lane_id() == 0) { atomicMin(&s_lcp, my_lcp); atomicMin(&s_lcs, my_lcs); }
+    __syncthreads();
+    if (tid < l1.nch) {
+        if (s_entry[tid] != UQ_NONE) atomicMin((unsigned long long*)&lay->entry[tid], s_entry[tid]);
+        if (s_viol[tid]) atomicMax((unsigned long long*)&lay->lastviol[tid], s_viol[tid]);
+    }
+    if (tid == 0) {
+        atomicMin(&lay->min_lcp, s_lcp); atomicMin(&lay->min_lcs, s_lcs);
+        if (s_flags) atomicOr(&lay->flags, s_flags);
+    }
+}
+
+__device__ bool regex_special(uint8_t c) {
+    const char* s = ".^$*+?{}[]\\|()-";
+    for (int i = 0; s[i]; ++i) if ((uint8_t)s[i] == c) return true;
+    return false;
+}
+
+// uq.py:428-444 on the sample's reductions -> the guess.  One lane.
+__global__ void qname_guess_kernel(const DevLine1* __restrict__ l1, const uq_qname_layout_result* __restrict__ lay, const uint32_t* __restrict__ step,
+                                   uq_qname_fused* __restrict__ q) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    q->ok = 0; q->plen = q->slen = q->nsep = q->l1len = 0; q->flags = 0; q->sample_step = *step; q->nth = 0; q->nreads = 0;
+    for (int i = 0; i < 256; ++i) { q->line1[i] = 0; q->inset[i] = 0; }
+    for (int i = 0; i < 32; ++i) q->seps[i] = 0;
+    for (int c = 0; c < UQ_QF_MAXC; ++c) {
+        q->vmin[c] = 0xFFFFFFFFu; q->vmax[c] = 0; q->undetermined[c] = 0;
+        for (int k = 0; k < UQ_QF_MAXT; ++k) q->counts[c][k] = 0;
+    }
+    for (int k = 0; k < UQ_QF_MAXT; ++k) q->thresholds[k] = 0;
+    if (l1->bad || lay->flags) return;
+    const uint32_t len = l1->len;
+    // min_lcp / min_lcs start at line 1's length: with no sampled read (a file of one record) plen + slen > len declines below
+    const uint32_t plen = lay->min_lcp < len ? lay->min_lcp : len, slen = lay->min_lcs < len ? lay->min_lcs : len;
+    if (plen == 0 || plen + slen > len) return;               // every QNAME starts with '@': an empty prefix is no FASTQ the fused pass takes
+    bool is_sep[QF_MAXCH];
+    uint32_t nsepch = 0;
+    for (uint32_t k = 0; k < l1->nch; ++k) {
+        is_sep[k] = false;
+        if (lay->entry[k] == UQ_NONE || lay->lastviol[k] >= lay->entry[k]) continue;
+        const uint8_t c = l1->ch[k];
+        int mid = 0;                                          // l1[plen:].count(c) - suffix.count(c)
+        for (uint32_t p = plen; p < len - slen; ++p) mid += l1->text[p] == c;
+        if (mid == 0) continue;
+        if (regex_special(c)) return;                         // '[seps]+' and '(.*)'.join(seps) are regexes in the reference: the host's `re` path
+        is_sep[k] = true; ++nsepch;
+    }
+    if (nsepch == 0) return;                                  // (the reference refuses such files: the exact path words the error)
+    // separators = the separator characters of l1[plen : len - 1 - slen] in order (Q14: the slice drops one more character)
+    uint32_t nsep = 0;
+    const uint32_t end = len - slen >= 1 ? len - slen - 1 : 0;
+    for (uint32_t p = plen; p < end; ++p) {
+        const uint8_t c = l1->text[p];
+        if (l1->slot[c] != 0xFF && is_sep[l1->slot[c]]) {
+            if (nsep == UQ_QF_MAXC - 1) return;
+            q->seps[nsep++] = c;
+        }
+    }
+    if (nsep == 0) return;
+    for (uint32_t k = 0; k < l1->nch; ++k) if (is_sep[k]) q->inset[l1->ch[k]] = 1;
+    for (uint32_t p = 0; p < len; ++p) q->line1[p] = l1->text[p];
+    q->plen = plen; q->slen = slen; q->nsep = nsep; q->l1len = len;
+    q->ok = 1;
+}
+
+// ---- distinct values per checkpoint, queued behind the pack kernel
+struct Checkpoints { uint64_t t[UQ_QF_MAXT]; uint32_t nth, nhead; };
+__device__ __forceinline__ Checkpoints checkpoints(uint64_t n) {
+    Checkpoints c; c.nth = 0; c.nhead = 0;
+    if (n == 0) return c;
+    for (uint64_t t = 10000; t <= n - 1 && c.nth < UQ_QF_MAXT - 1; t *= 2) c.t[c.nth++] = t;
+    if (c.nth == 0 || c.t[c.nth - 1] != n - 1) c.t[c.nth++] = n - 1;
+    for (uint32_t k = 0; k < c.nth; ++k) if (c.t[k] < QF_PREFIX) c.nhead = k + 1;
+    return c;
+}
+
+// first[col][v - vmin] = lowest read holding value v: over all reads for ranges <= QF_SMALL (a private LDS table per workgroup: a
+// column of four lanes would otherwise be ten million atomics on four addresses), over reads [0, last checkpoint below 2^21] else.
+__global__ __launch_bounds__(QF_THREADS) void qf_first_seen_kernel(uq_qname_fused* __restrict__ q, const uint32_t* __restrict__ vals, uint64_t pitch,
+                                                                    uint32_t* __restrict__ first) {
+    __shared__ uint32_t s_first[QF_SMALL];
+    const uint32_t col = blockIdx.y;
+    if (!q->ok || q->flags || col > q->nsep) return;
+    const uint64_t n = q->nreads;
+    const uint32_t vmin = q->vmin[col], vmax = q->vmax[col];
+    if (n == 0 || vmin > vmax) return;
+    const uint64_t range = (uint64_t)vmax - vmin + 1;
+    if (range > QF_FT) { if (blockIdx.x == 0 && threadIdx.x == 0) q->undetermined[col] = 1; return; }
+    const bool small = range <= QF_SMALL;
+    const Checkpoints cp = checkpoints(n);
+    const uint64_t upto = small ? n : cp.t[cp.nhead - 1] + 1;          // nhead >= 1: the first checkpoint is below 2^21
+    const uint32_t* v = vals + col * pitch;
+    uint32_t* f = first + (size_t)col * QF_FT;
+    if (small) {
+        for (uint32_t i = threadIdx.x; i < (uint32_t)range; i += QF_THREADS) s_first[i] = 0xFFFFFFFFu;
+        __syncthreads();
+    }
+    // a workgroup takes a CONTIGUOUS slice of the reads: the first lane to see a value in a slice usually settles it
+    const uint64_t per = (upto + gridDim.x - 1) / gridDim.x;
+    const uint64_t lo = (uint64_t)blockIdx.x * per, hi = lo + per < upto ? lo + per : upto;
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += QF_THREADS) {
+        const uint32_t slot = v[i] - vmin;
+        if (slot >= range) continue;
+        if (small) { if ((uint32_t)i < s_first[slot]) atomicMin(&s_first[slot], (uint32_t)i); }
+        else if ((uint32_t)i < f[slot]) atomicMin(&f[slot], (uint32_t)i);
+    }
+    if (small) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < (uint32_t)range; i += QF_THREADS)
+            if (s_first[i] != 0xFFFFFFFFu && s_first[i] < f[i]) atomicMin(&f[i], s_first[i]);
+    }
+}
+
+__global__ __launch_bounds__(QF_THREADS) void qf_count_kernel(uq_qname_fused* __restrict__ q, const uint32_t* __restrict__ first) {
+    __shared__ uint32_t s_cnt[UQ_QF_MAXT];
+    const uint32_t col = blockIdx.y;
+    if (!q->ok || q->flags || col > q->nsep) return;
+    const uint64_t n = q->nreads;
+    const Checkpoints cp = checkpoints(n);
+    if (col == 0 && blockIdx.x == 0 && threadIdx.x == 0) { q->nth = cp.nth; for (uint32_t k = 0; k < cp.nth; ++k) q->thresholds[k] = cp.t[k]; }
+    const uint32_t vmin = q->vmin[col], vmax = q->vmax[col];
+    if (n == 0 || vmin > vmax) return;
+    const uint64_t range = (uint64_t)vmax - vmin + 1;
+    if (range > QF_FT) return;
+    const uint32_t nth = range <= QF_SMALL ? cp.nth : cp.nhead;
+    if (threadIdx.x < UQ_QF_MAXT) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t* f = first + (size_t)col * QF_FT;
+    for (uint64_t j = (uint64_t)blockIdx.x * QF_THREADS + threadIdx.x; j < range; j += (uint64_t)gridDim.x * QF_THREADS) {
+        const uint32_t at = f[j];
+        if (at == 0xFFFFFFFFu) continue;
+        for (uint32_t k = 0; k < nth; ++k)
+            if (at <= cp.t[k]) atomicAdd(&s_cnt[k], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < nth && s_cnt[threadIdx.x]) atomicAdd((unsigned long long*)&q->counts[col][threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
+}
+
+template <typename T>
+__global__ void encode_u32_kernel(const uint32_t* __restrict__ val, uint64_t n, uint32_t sub, T* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * QF_THREADS + threadIdx.x;
+    if (i < n) out[i] = (T)(val[i] - sub);
+}
+
+int guess_impl(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start, uint64_t nreads, const unsigned long long* d_async, uq_qname_fused* d_q) {
+    UQ_REQUIRE(ctx && d_buf && d_line_start && d_q, "uq_qname_guess: null argument");
+    ScratchPlan sp;
+    const size_t o_lay = sp.add(sizeof(uq_qname_layout_result)), o_l1 = sp.add(sizeof(DevLine1)), o_step = sp.add(16);
+    void* scr;
+    UQ_TRY(uq_scratch(ctx, sp.off, &scr));
+    uint8_t* base = (uint8_t*)scr;
+    uq_qname_layout_result* d_lay = (uq_qname_layout_result*)(base + o_lay);
+    // initial values of the reductions: min_lcp = min_lcs = 0xFFFFFFFF (clamped to line 1's length by the guess kernel), entry = none
+    UQ_CHECK_HIP(hipMemsetAsync(d_lay, 0, sizeof(*d_lay), ctx->stream));
+    UQ_CHECK_HIP(hipMemsetAsync(&d_lay->min_lcp, 0xFF, 8, ctx->stream));
+    UQ_CHECK_HIP(hipMemsetAsync(d_lay->entry, 0xFF, sizeof(d_lay->entry), ctx->stream));
+    const uint32_t grid = QF_SAMPLES / QF_THREADS;
+    qname_sample_kernel<<<grid, QF_THREADS, 0, ctx->stream>>>(d_buf, d_line_start, nreads, d_async, d_lay, (DevLine1*)(base + o_l1), (uint32_t*)(base + o_step));
+    UQ_LAUNCH_CHECK();
+    qname_guess_kernel<<<1, 64, 0, ctx->stream>>>((const DevLine1*)(base + o_l1), d_lay, (const uint32_t*)(base + o_step), d_q);
+    UQ_LAUNCH_CHECK();
+    return 0;
+}
+}  // namespace
+
+extern "C" int uq_qname_guess(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start, uint64_t nreads, uq_qname_fused* d_q) {
+    return guess_impl(ctx, d_buf, d_line_start, nreads, nullptr, d_q);
+}
+
+extern "C" int uq_qname_guess_async(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start, uq_qname_fused* d_q) {
+    UQ_REQUIRE(ctx && ctx->async_buf == d_buf, "uq_qname_guess_async: not the buffer of the last uq_count_lines_end_async");
+    return guess_impl(ctx, d_buf, d_line_start, 0, ctx->d_async, d_q);
+}
+
+extern "C" int uq_qname_fused_finish(uq_ctx* ctx, uq_qname_fused* d_q, const uint32_t* d_vals, uint64_t vals_pitch) {
+    UQ_REQUIRE(ctx && d_q && d_vals, "uq_qname_fused_finish: null argument");
+    void* scr;
+    const size_t bytes = (size_t)UQ_QF_MAXC * QF_FT * sizeof(uint32_t);
+    UQ_TRY(uq_scratch(ctx, bytes, &scr));
+    UQ_CHECK_HIP(hipMemsetAsync(scr, 0xFF, bytes, ctx->stream));
+    qf_first_seen_kernel<<<dim3(UQ_NUM_CU * 2, UQ_QF_MAXC), QF_THREADS, 0, ctx->stream>>>(d_q, d_vals, vals_pitch, (uint32_t*)scr);
+    UQ_LAUNCH_CHECK();
+    qf_count_kernel<<<dim3(64, UQ_QF_MAXC), QF_THREADS, 0, ctx->stream>>>(d_q, (const uint32_t*)scr);
+    UQ_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int uq_qname_fused_fetch(uq_ctx* ctx, const uq_qname_fused* d_q, uq_qname_fused* h_out) {
+    UQ_REQUIRE(ctx && d_q && h_out, "uq_qname_fused_fetch: null argument");
+    static_assert(sizeof(uq_qname_fused) % 4 == 0 && sizeof(uq_qname_fused) <= 3200 * 8, "read back through the pinned staging");
+    UQ_TRY(uq_read_back(ctx, ctx->h_pinned, d_q, sizeof(uq_qname_fused)));
+    UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(h_out, ctx->h_pinned, sizeof(uq_qname_fused));
+    return 0;
+}
+
+extern "C" int uq_encode_u32(uq_ctx* ctx, const uint32_t* d_val, uint64_t n, uint32_t sub, int itemsize, void* d_out) {
+    UQ_REQUIRE(ctx && (n == 0 || (d_val && d_out)), "uq_encode_u32: null argument");
+    if (n == 0) return 0;
+    const uint32_t blocks = (uint32_t)((n + QF_THREADS - 1) / QF_THREADS);
+    switch (itemsize) {
+        case 1: encode_u32_kernel<uint8_t><<<blocks, QF_THREADS, 0, ctx->stream>>>(d_val, n, sub, (uint8_t*)d_out); break;
+        case 2: encode_u32_kernel<uint16_t><<<blocks, QF_THREADS, 0, ctx->stream>>>(d_val, n, sub, (uint16_t*)d_out); break;
+        case 4: encode_u32_kernel<uint32_t><<<blocks, QF_THREADS, 0, ctx->stream>>>(d_val, n, sub, (uint32_t*)d_out); break;
+        case 8: encode_u32_kernel<uint64_t><<<blocks, QF_THREADS, 0, ctx->stream>>>(d_val, n, sub, (uint64_t*)d_out); break;
+        default: UQ_REQUIRE(false, "uq_encode_u32: itemsize %d not in {1,2,4,8}", itemsize);
+    }
+    UQ_LAUNCH_CHECK();
+    return 0;
+}

@@ -170,20 +170,25 @@ def pack(ctx, buf, line_start, first_read, nreads, params, dna=None, qual=None):
     return dna, qual, bad
 
 
-def pack_stats(ctx, buf, line_start, first_read, nreads, guess):
+def pack_stats(ctx, buf, line_start, first_read, nreads, guess, fq=None):
     """One pass: pack with the GUESSED parameters and accumulate uq_stats of the same reads (uq_pack_stats).
-    Returns (dna, qual, bad, d_stats) or None when there is no fused kernel for this geometry."""
+    Returns (dna, qual, bad, d_stats) or None when there is no fused kernel for this geometry.
+    `fq`: a FusedQname whose guess has been queued (qname_guess): the kernel also tokenises the QNAME lines (uq_pack_stats_qname)."""
     t = ctx.torch
     dna = t.empty(nreads * guess.dna_bytes_per_row, dtype=t.uint8, device=ctx.device)
     qual = t.empty(nreads * guess.quality_bytes_per_row, dtype=t.uint8, device=ctx.device)
     bad = t.empty(1, dtype=t.int64, device=ctx.device)
     st = stats_new(ctx)
     fused = C.c_int(0)
-    call('uq_pack_stats', ctx.h, _p(buf), _p(line_start), first_read, nreads, C.byref(guess), _p(dna), _p(qual), _p(bad), _p(st), C.byref(fused))
+    if fq is None:
+        call('uq_pack_stats', ctx.h, _p(buf), _p(line_start), first_read, nreads, C.byref(guess), _p(dna), _p(qual), _p(bad), _p(st), C.byref(fused))
+    else:
+        call('uq_pack_stats_qname', ctx.h, _p(buf), _p(line_start), first_read, nreads, C.byref(guess), _p(dna), _p(qual), _p(bad), _p(st),
+             _p(fq.q), _p(fq.vals), fq.pitch, C.byref(fused))
     return (dna, qual, bad, st) if fused.value else None
 
 
-def pack_stats_async(ctx, buf, line_start, capacity_reads, guess, st=None):
+def pack_stats_async(ctx, buf, line_start, capacity_reads, guess, st=None, fq=None):
     """pack_stats of every read of `buf` behind ChunkedCensus.end_async() + index_lines_async: tables of capacity_reads rows (the
     caller narrows them once wait() has told it the count; `st`: a stats_new() made earlier, so that its initialisation is not queued
     between the index and the pack kernel).  Returns (dna, qual, bad, d_stats) or None (no fused kernel)."""
@@ -193,8 +198,60 @@ def pack_stats_async(ctx, buf, line_start, capacity_reads, guess, st=None):
     bad = t.empty(1, dtype=t.int64, device=ctx.device)
     if st is None: st = stats_new(ctx)
     fused = C.c_int(0)
-    call('uq_pack_stats_async', ctx.h, _p(buf), _p(line_start), capacity_reads, C.byref(guess), _p(dna), _p(qual), _p(bad), _p(st), C.byref(fused))
+    if fq is None:
+        call('uq_pack_stats_async', ctx.h, _p(buf), _p(line_start), capacity_reads, C.byref(guess), _p(dna), _p(qual), _p(bad), _p(st), C.byref(fused))
+    else:
+        call('uq_pack_stats_qname_async', ctx.h, _p(buf), _p(line_start), capacity_reads, C.byref(guess), _p(dna), _p(qual), _p(bad), _p(st),
+             _p(fq.q), _p(fq.vals), fq.pitch, C.byref(fused))
     return (dna, qual, bad, st) if fused.value else None
+
+
+# ------------------------------------------------------------------ the QNAME passes inside the pack kernel
+QF_MAXC = 8
+
+
+class FusedQname:
+    """Device side of the fused QNAME pass (include/uqhip.h, uq_qname_fused): `q` = the structure in HBM, `vals` = QF_MAXC columns
+    of `pitch` uint32 field values.  Order of calls: qname_guess[_async] -> pack_stats[_async](fq=...) -> qname_fused_finish ->
+    qname_fused_fetch (the only one that waits for the device)."""
+
+    def __init__(self, ctx, capacity_reads):
+        from ._lib import QnameFused
+        t = ctx.torch
+        self.pitch = int(capacity_reads)
+        self.q = t.empty(C.sizeof(QnameFused), dtype=t.uint8, device=ctx.device)
+        self.vals = t.empty(QF_MAXC * self.pitch, dtype=t.int32, device=ctx.device)
+
+    def column(self, c, n):
+        return self.vals[c * self.pitch:c * self.pitch + n]
+
+
+def qname_guess(ctx, buf, line_start, nreads, fq):
+    call('uq_qname_guess', ctx.h, _p(buf), _p(line_start), int(nreads), _p(fq.q))
+
+
+def qname_guess_async(ctx, buf, line_start, fq):
+    """The layout guess behind ChunkedCensus.end_async() + index_lines_async (the read count is taken on the device)."""
+    call('uq_qname_guess_async', ctx.h, _p(buf), _p(line_start), _p(fq.q))
+
+
+def qname_fused_finish(ctx, fq):
+    """Queue the distinct-value counts of the columns behind the pack kernel (no host wait)."""
+    call('uq_qname_fused_finish', ctx.h, _p(fq.q), _p(fq.vals), fq.pitch)
+
+
+def qname_fused_fetch(ctx, fq):
+    from ._lib import QnameFused
+    out = QnameFused()
+    call('uq_qname_fused_fetch', ctx.h, _p(fq.q), C.byref(out))
+    return out
+
+
+def encode_u32(ctx, val, n, sub, itemsize):
+    t = ctx.torch
+    out = t.empty(n, dtype=getattr(t, _NARROW_DT[itemsize]), device=ctx.device)
+    call('uq_encode_u32', ctx.h, _p(val), int(n), int(sub), itemsize, _p(out))
+    return out
 
 
 HEAD_BYTES_SMALL = 4 << 20     # the slice of the file the pack-and-count encoder's guess is taken from (8192 reads of <= 512 bytes)

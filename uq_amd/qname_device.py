@@ -34,6 +34,18 @@ def _ladder(x):
     return None, None
 
 
+def _thresholds(n):
+    """The reads after which the reference re-examines its column formats (uq.py:586-602: 10 000, 20 000, 40 000, ...) and the last one
+    (uq.py:634-638), as 0-based read numbers."""
+    thresholds = []
+    t = 10000
+    while t <= n - 1:
+        thresholds.append(t); t *= 2
+    if not thresholds or thresholds[-1] != n - 1:
+        thresholds.append(n - 1)
+    return thresholds
+
+
 def _fetch_bytes(ctx, d_buf, lo, hi):
     return ctx.to_numpy(d_buf[lo:hi]).tobytes()
 
@@ -146,12 +158,7 @@ def type_and_encode_device(ctx, d_buf, d_ls, nreads, prefix, suffix, separators,
         first_nonint = _min_u64(shard, first_nonint)
     if flags:
         return None
-    thresholds = []
-    t = 10000
-    while t <= n - 1:
-        thresholds.append(t); t *= 2
-    if not thresholds or thresholds[-1] != n - 1:
-        thresholds.append(n - 1)
+    thresholds = _thresholds(n)
     columns, arrays = [], []
     for c in range(ncols):
         if long_bad[c]:
@@ -212,6 +219,64 @@ def type_and_encode_device(ctx, d_buf, d_ls, nreads, prefix, suffix, separators,
         columns.append(col)
         vals[c] = strs[c] = None                            # release this column's staging as we go
     return columns, arrays
+
+
+def analyse_fused(ctx, fq, nreads):
+    """The QNAME analysis from what the pack kernel's QNAME phase left behind (ops.FusedQname after pack_stats(fq=...) and
+    qname_fused_finish): (prefix, suffix, separators, columns, device column tensors), or None when the fused pass cannot vouch for
+    it -- the guess declined, a read did not conform (any flag), a column needs the sorted map or the sort-based distinct counts --
+    and the caller runs analyse_device.  One host wait (the fetch); the column encoders are queued behind it."""
+    r = ops.qname_fused_fetch(ctx, fq)
+    n = int(nreads)
+    if not r.ok or r.flags or n == 0 or int(r.nreads) != n:
+        return None
+    l1 = bytes(r.line1[:r.l1len]).decode('latin-1')
+    prefix = l1[:r.plen]
+    suffix = l1[r.l1len - r.slen:] if r.slen else ''
+    separators = bytes(r.seps[:r.nsep]).decode('latin-1')
+    thresholds = _thresholds(n)
+    if [int(x) for x in r.thresholds[:r.nth]] != thresholds:
+        return None
+    columns, arrays = [], []
+    for c in range(r.nsep + 1):
+        vmin, vmax = int(r.vmin[c]), int(r.vmax[c])
+        col = {'name': 'QNAME_%d' % (c + 1), 'format': 'mapping'}
+        # every field is the canonical decimal of its value (the kernel verified it): distinct strings = distinct values, counted per
+        # checkpoint from first occurrences -- over the whole column for small ranges, else over the checkpoints below INT_PREFIX,
+        # where the `len(map) > entries_read / 10` rule fires at once or the values are sorted (type_and_encode_device's rule)
+        counts = None
+        if not r.undetermined[c] and vmax - vmin + 1 <= INT_RANGE_SMALL:
+            ths, counts = thresholds, [int(x) for x in r.counts[c][:len(thresholds)]]
+            nu = counts[-1]
+        elif not r.undetermined[c]:
+            ths = [T for T in thresholds if T < INT_PREFIX]
+            counts = [int(x) for x in r.counts[c][:len(ths)]]
+            if any(cnt > T // 10 for T, cnt in zip(ths, counts)): nu = None
+            elif len(ths) == len(thresholds): nu = counts[-1]
+            else: counts = None
+        if counts is None:                                  # a stable sort of the 4-byte values (any order will do for counting)
+            perm, _, skey, _, nu = ops.unique_rows(ctx, fq.column(c, n).view(ctx.torch.uint8), n, 4, want_key=False, want_unique=False)
+            ths, counts = thresholds, ops.prefix_distinct(ctx, perm, skey, n, thresholds)
+            del perm, skey
+        for T, cnt in zip(ths, counts):
+            if cnt > T // 10:                               # check_format(): mapping -> integers
+                col['format'] = 'integers'
+                break
+        if col['format'] == 'mapping':
+            lim, dt = _ladder(nu)
+            col['dtype'] = dt
+            if vmax - vmin > lim:
+                return None                                 # stays a mapping: the sorted map of its strings comes from the exact path
+            col['format'] = 'integers'; col['max'] = vmax; col['min'] = vmin
+            col['offset'] = bool(vmax > lim)
+        else:
+            col['min'] = vmin; col['max'] = vmax
+            lim, dt = _ladder(vmax - vmin)
+            col['dtype'] = dt
+            col['offset'] = bool(vmax > lim)
+        arrays.append(ops.encode_u32(ctx, fq.column(c, n), n, vmin if col['offset'] else 0, np.dtype(col['dtype']).itemsize))
+        columns.append(col)
+    return prefix, suffix, separators, columns, arrays
 
 
 def analyse_device(ctx, d_buf, d_ls, nreads, shard=None):

@@ -57,6 +57,8 @@ def build_parser():
     p.add_argument('--device', type=int, default=int(os.environ.get('LOCAL_RANK', '0')), help='GPU index (extension)')
     p.add_argument('--quiet', action='store_true', default=False, help='suppress the analysis report (extension)')
     p.add_argument('--host-qname', action='store_true', default=False, help='run the QNAME passes sequentially on the host (extension)')
+    p.add_argument('--exact-qname', action='store_true', default=False,
+                   help='run the QNAME passes as kernels of their own (layout, then tokeniser) instead of inside the pack kernel (extension)')
     p.add_argument('--multi-pass', action='store_true', default=False,
                    help='census, record index, statistics and pack as separate passes over the stream; the default counts the statistics in the pack kernel, '
                         'packing speculatively with decisions guessed from the head of the file and verified afterwards (extension)')
@@ -165,13 +167,24 @@ class Session:
         # the stream is read twice (census, pack) instead of three times; analyse() / _encode() keep the tables only if the
         # decisions derived from the whole file's counts equal the guess (else uq_pack runs with the real ones), and counts
         # the kernel could not complete (a symbol or a length outside the guess) are redone by the plain statistics pass.
+        # The same kernel takes the QNAME passes along (uq.py:394-444, 555-565, 717-736): the lines are in its LDS tiles anyway.  A
+        # layout guessed on the device from a sample of the reads is verified on every read while the fields are parsed
+        # (uq_qname_guess, uq_pack_stats_qname); analyse_qname() uses the result when no read raised a flag, else the exact passes.
+        self._fq = None
         if not getattr(args, 'multi_pass', False):
             guess = ops.head_guess_indexed(ctx, self.d_buf, self.d_ls, self.total, args.notricks, args.pad)
-            res = ops.pack_stats(ctx, self.d_buf, self.d_ls, 0, self.total, guess) if guess is not None else None
+            fq = None
+            if guess is not None and not getattr(args, 'host_qname', False) and not getattr(args, 'exact_qname', False):
+                fq = ops.FusedQname(ctx, self.total)
+                ops.qname_guess(ctx, self.d_buf, self.d_ls, self.total, fq)
+            res = ops.pack_stats(ctx, self.d_buf, self.d_ls, 0, self.total, guess, fq=fq) if guess is not None else None
             if res is not None:
                 self._spec = (guess,) + res[:3]
                 self.d_stats = res[3]
                 self.load_path = 'two reads (census; pack + statistics)'
+                if fq is not None:
+                    ops.qname_fused_finish(ctx, fq)
+                    self._fq = fq
         if self._spec is None:
             self.d_stats = ops.stats_new(ctx)
             ops.stats_accumulate(ctx, self.d_stats, self.d_buf, self.d_ls, 0, self.total)
@@ -206,8 +219,13 @@ class Session:
         """QNAME passes 1 / 2 / 4: per-read work on the device (qname_device), or -- for QNAMEs outside the
         subset that path reproduces exactly, and with --host-qname -- sequentially on the host."""
         from . import qname, qname_device
-        self.qname_path = 'device'
-        res = None if getattr(self.args, 'host_qname', False) else qname_device.analyse_device(self.ctx, self.d_buf, self.d_ls, self.total)
+        self.qname_path = 'fused'
+        fq, self._fq = getattr(self, '_fq', None), None
+        res = qname_device.analyse_fused(self.ctx, fq, self.total) if fq is not None else None
+        del fq
+        if res is None:
+            self.qname_path = 'device'
+            res = None if getattr(self.args, 'host_qname', False) else qname_device.analyse_device(self.ctx, self.d_buf, self.d_ls, self.total)
         if res is None:
             self.qname_path = 'host-native'
             h_ls = self.ctx.to_numpy(self.d_ls, np.uint64)
