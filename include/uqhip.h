@@ -312,8 +312,10 @@ int uq_encode_int(uq_ctx* ctx, const int64_t* d_val, uint64_t n, int64_t sub, in
  *       sample (which bounds the file's entry from above and its last violation from below).
  *   uq_qname_fused_finish  queued behind it: per column the number of distinct values among reads [0, T] at the checkpoints
  *       T = 10000 * 2^k <= nreads - 1 and T = nreads - 1 (uq.py:586-602, 634-638; canonical decimals: distinct strings = distinct
- *       values) -- over the whole column for ranges <= 4096, over the checkpoints below 2^21 otherwise (uq_int_prefix_distinct's
- *       rule); undetermined[c] = 1: range beyond 2^20, not counted.
+ *       values).  Value ranges <= 4096: all checkpoints, from first occurrences per value.  Wider ranges (up to 2^20): checkpoint by
+ *       checkpoint over the first three, counts[c][k] filled up to the first k with counts[c][k] > T_k / 10 (the reference demotes
+ *       the column to `integers` there and later counts do not matter) or for all of them when the file has no more;
+ *       undetermined[c] = 1: not decided here (range beyond 2^20, or no checkpoint among the first three fires): sort the column.
  *   uq_qname_fused_fetch  the structure on the host (synchronises).  uq_encode_u32: d_out[i] = (unsigned itemsize)(d_val[i] - sub).
  * Exact by construction; the caller falls back to uq_qname_layout / uq_qname_tokenise on any flag. */
 #define UQ_QF_MAXC 8
@@ -342,6 +344,8 @@ int uq_pack_stats_qname_async(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t*
 int uq_qname_fused_finish(uq_ctx* ctx, uq_qname_fused* d_q, const uint32_t* d_vals, uint64_t vals_pitch);
 int uq_qname_fused_fetch(uq_ctx* ctx, const uq_qname_fused* d_q, uq_qname_fused* h_out);
 int uq_encode_u32(uq_ctx* ctx, const uint32_t* d_val, uint64_t n, uint32_t sub, int itemsize, void* d_out);
+int uq_encode_u32_columns(uq_ctx* ctx, const uint32_t* d_vals, uint64_t vals_pitch, uint64_t n, int ncols, const uint32_t* h_sub,
+                          const int* h_itemsize, void* const* h_d_outs);       /* uq_encode_u32 of the first ncols columns of a fused pass, one launch */
 
 /* ---- f3: FASTQ text assembled on the device.  Replaces the decoder's exec-compiled convert_qname
  * (uq.py:1010-1026) and its four prints per read (uq.py:1042-1045).  Inputs: the fixed-pitch text and

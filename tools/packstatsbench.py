@@ -34,3 +34,13 @@ ok = res is not None and torch.equal(res[0], dna) and torch.equal(res[1], qual)
 h2 = ops.stats_fetch(ctx, res[3]) if res is not None else None
 same = h2 is not None and not h2.incomplete and np.array_equal(h2.counts, hs.counts) and (h2.len_min, h2.len_max, h2.max_record_bytes) == (hs.len_min, hs.len_max, hs.max_record_bytes)
 print('stats %.3f ms + pack %.3f ms = %.3f ms; pack_stats %.3f ms (tables identical: %s, statistics identical: %s)' % (t_s, t_p, t_s + t_p, t_f, ok, same))
+
+# ... and with the QNAME phase (uq_pack_stats_qname): the guess is made once, outside the timing
+fq = ops.FusedQname(ctx, n)
+ops.qname_guess(ctx, d_buf, ls, n, fq)
+st_pre = [ops.stats_new(ctx) for _ in range(8)]
+def fused():
+    return ops.pack_stats(ctx, d_buf, ls, 0, n, p, fq=fq)
+t_q, resq = timed(fused)
+okq = resq is not None and torch.equal(resq[0], dna) and torch.equal(resq[1], qual)
+print('pack_stats + QNAME phase %.3f ms (tables identical: %s)%s' % (t_q, okq, ''.join(' %s=%s' % (k, v) for k, v in os.environ.items() if k.startswith('UQ_'))))

@@ -128,6 +128,7 @@ SIGNATURES = {
     'uq_qname_fused_finish': [_vp, _vp, _vp, _u64],
     'uq_qname_fused_fetch': [_vp, _vp, _P(QnameFused)],
     'uq_encode_u32': [_vp, _vp, _u64, _u32, _int, _vp],
+    'uq_encode_u32_columns': [_vp, _vp, _u64, _u64, _int, _P(_u32), _P(_int), _P(_vp)],
     'uq_emit_fastq': [_vp, _P(EmitParams), _P(_vp), _P(_vp), _P(_vp), _vp, _vp, _vp, _u64, _vp, _vp, _u64, _P(_u64)],
     'uq_debug_scribble_lds': [_vp, C.c_uint32],
     'uq_decode_fastq': [_vp, _P(EmitParams), _P(UnpackParams), _P(_vp), _P(_vp), _P(_vp), _vp, _vp, _u64, _vp, _vp, _vp, _vp, _u64, _P(_u64), _P(_u64)],

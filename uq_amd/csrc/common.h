@@ -23,12 +23,14 @@ struct uq_ctx {
     uint16_t* idx_bitmap;   // newline bitmap of that buffer: one u16 per 16-byte vector (index.hip)
     uint64_t* h_pinned;     // small pinned host staging (64 KiB).  Who uses which part (uint64 index): [0, 3200) whatever the running call reads
                             // back (scalars, uq_stats_compact, QNAME reductions); [4096, 5120) the radix sort's digit census; [8000, 8003) the
-                            // queued census's line count and flags, which must survive the calls queued behind it (uq_count_lines_wait)
+                            // queued census's line count and flags, which must survive the calls queued behind it (uq_count_lines_wait); [5200, 5520) the
+                            // fused QNAME pass's structure (uq_qname_fused_finish -> uq_qname_fused_fetch)
     uint64_t* d_pinned;     // the same memory as the device sees it (uq_read_back)
     void* scan_ws; size_t scan_ws_bytes;   // partial sums of the hierarchical scans
     // the queued form of the census (uq_count_lines_end_async): the line count stays on the device for the kernels queued behind it
     unsigned long long* d_async;           // [0] line count  [1] line_start capacity exceeded
     const uint8_t* async_buf; uint64_t async_nbytes; bool async_read;
+    const void* qf_sent;                   // the uq_qname_fused whose read-back uq_qname_fused_finish has queued ([5200, 5520) of h_pinned)
 };
 
 void uq_set_error(const char* fmt, ...);

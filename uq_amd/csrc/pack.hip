@@ -53,6 +53,7 @@ struct PackGeom {
     // 3-bit bases on the fast path: (character >> h_shift) & 7 is different for every base of the alphabet (found by the host);
     // i2c = code of each such index, c2c = character of each code, eight bytes each (what v_perm_b32 selects from)
     uint32_t h_shift, i2c_lo, i2c_hi, c2c_lo, c2c_hi;
+    uint32_t variable_dbg;   // EXPERIMENT
 };
 
 // four ACGT characters -> four 2-bit codes (A0 C1 G2 T3), one per byte
@@ -94,54 +95,126 @@ __device__ __noinline__ void store_tile(uint8_t* gdst, const uint8_t* lsrc, uint
 // (uq.py:560-565 split, 724-726 int()): value of field c of read `row` -> vals[c * pitch + row].  Whatever does not conform
 // raises a flag (include/uqhip.h lists them); the host then runs the exact passes of qname_dev.hip instead.
 struct QnLds {
-    uint8_t line1[256];
+    uint8_t line1[256 + 16];        // zero padded: windows may read past the line
     uint8_t inset[256];
     uint8_t seps[32];
     uint32_t vmin[UQ_QF_MAXC], vmax[UQ_QF_MAXC];
-    uint32_t flags, on, plen, slen, nsep, l1len, pad0, pad1;
+    uint32_t flags, on, plen, slen, nsep, l1len;
+    uint32_t sepset;                // the (at most four) distinct separator characters, one per byte (unused bytes repeat the first)
+    uint32_t seps_lo, seps_hi;      // seps[0..7] as two dwords
+    uint32_t pow10[10];
 };
 
+// high bit of every byte of w that equals the byte replicated in c4
+__device__ __forceinline__ uint32_t eq_bytes(uint32_t w, uint32_t c4) {
+    const uint32_t x = w ^ c4;
+    return ~((((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x)) & 0x80808080u;
+}
+// high bit of every byte of w that is NOT an ASCII digit
+__device__ __forceinline__ uint32_t nondigit_bytes(uint32_t w) {
+    const uint32_t lo7 = w & 0x7F7F7F7Fu;
+    return (~(lo7 + 0x50505050u) | (lo7 + 0x46464646u) | w) & 0x80808080u;
+}
+// 0xFF in bytes k < n of a dword (n >= 4: all)
+__device__ __forceinline__ uint32_t low_bytes(uint32_t n) { return n >= 4 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu << (8 * n)); }
+
+// 12 consecutive bytes at LDS byte offset `o` (any alignment, may be slightly negative) as three dwords
+__device__ __forceinline__ void lds_window12(const uint8_t* base, int32_t o, uint32_t& w0, uint32_t& w1, uint32_t& w2) {
+    const uint32_t* p = (const uint32_t*)(base + (o & ~3));
+    const uint32_t a = p[0], b = p[1], c = p[2], d = p[3];
+    const uint32_t sh = (uint32_t)o & 3u;
+    w0 = __builtin_amdgcn_alignbyte(b, a, sh);
+    w1 = __builtin_amdgcn_alignbyte(c, b, sh);
+    w2 = __builtin_amdgcn_alignbyte(d, c, sh);
+}
+
+// Two steps, both without a branch per byte.  (1) The middle of the line is scanned eight bytes at a time: separators and non-digits
+// are found byte-parallel, the separators' positions and characters are collected (a short loop per window, one turn per
+// separator).  (2) Field by field -- every lane of the wave closes field c at the same time, so the column stores are coalesced --
+// the twelve bytes that end where the field ends are fetched, the field's digits kept, the value built with nine multiply-adds.
+// (A loop over the bytes that closed a field wherever a lane met a separator diverged at nearly every byte: ~1 200 instructions
+// per tile for the wave, the long pole of the tile; this form: ~500.)
 __device__ __forceinline__ void qname_tile(const uint8_t* stage, const uint32_t* meta, uint32_t q, QnLds* s, uint32_t* __restrict__ vals, uint64_t pitch,
-                                        uint64_t row) {
+                                           uint64_t row) {
     const uint32_t qs = meta[4 * q], ql = meta[4 * q + 1] - qs - 1;
     const uint32_t plen = s->plen, slen = s->slen, nsep = s->nsep, l1len = s->l1len;
     uint32_t f = 0;
     if (ql > 255) f = 2;
     else if (ql < plen + slen) f = 8;
     else {
-        const uint8_t* p = stage + qs;
-        for (uint32_t j = 0; j < plen; ++j) if (p[j] != s->line1[j]) f |= 32u;
-        for (uint32_t j = 0; j < slen; ++j) if (p[ql - slen + j] != s->line1[l1len - slen + j]) f |= 64u;
+        // prefix and suffix: eight bytes at a time against line 1's (the line-1 side is the same address for every lane: a broadcast)
+        for (uint32_t j = 0; j < plen; j += 8) {
+            uint32_t a0, a1;
+            lds_window8(stage, (int32_t)(qs + j), a0, a1);
+            const uint32_t l0 = *(const uint32_t*)(s->line1 + j), l1 = *(const uint32_t*)(s->line1 + j + 4);
+            const uint32_t left = plen - j;
+            if (((a0 ^ l0) & low_bytes(left)) | ((a1 ^ l1) & (left > 4 ? low_bytes(left - 4) : 0u))) f |= 32u;
+        }
+        for (uint32_t j = 0; j < slen; j += 8) {
+            uint32_t a0, a1, l0, l1;
+            lds_window8(stage, (int32_t)(qs + ql - slen + j), a0, a1);
+            lds_window8(s->line1, (int32_t)(l1len - slen + j), l0, l1);
+            const uint32_t left = slen - j;
+            if (((a0 ^ l0) & low_bytes(left)) | ((a1 ^ l1) & (left > 4 ? low_bytes(left - 4) : 0u))) f |= 64u;
+        }
+        // (1) separators of the middle [plen, end): positions (relative to the line) and characters, eight of each at most
         const uint32_t end = ql - slen;
-        uint32_t col = 0, mag = 0, nd = 0;
-        bool eq = true, lead0 = false;                      // eq: the line equals line1[:pos] so far (it does up to plen when bit5 stays down)
-        auto close = [&]() {
-            if (nd > 9) f |= 4u;
-            else if (nd == 0 || (lead0 && nd > 1)) f |= 16u;
-            if (col < UQ_QF_MAXC) {
-                vals[col * pitch + row] = mag;
-                if (mag < s->vmin[col]) atomicMin(&s->vmin[col], mag);
-                if (mag > s->vmax[col]) atomicMax(&s->vmax[col], mag);
-            }
-        };
-        for (uint32_t pos = plen; pos < end; ++pos) {
-            const uint32_t b = p[pos];
-            eq = eq && pos < l1len && b == s->line1[pos];
-            if (s->inset[b]) {
-                if (col >= nsep || b != s->seps[col]) f |= 1u;
-                close();
-                ++col; mag = 0; nd = 0; lead0 = false;
-            } else {
-                const uint32_t d = b - '0';
-                if (d > 9) f |= 16u;
-                if (nd == 0) lead0 = d == 0;
-                mag = mag * 10 + d; ++nd;
+        const uint32_t sepset = s->sepset;
+        const uint32_t c0 = 0x01010101u * (sepset & 0xFFu), c1 = 0x01010101u * ((sepset >> 8) & 0xFFu), c2 = 0x01010101u * ((sepset >> 16) & 0xFFu),
+                       c3 = 0x01010101u * (sepset >> 24);
+        unsigned long long epos = 0, eseq = 0;
+        uint32_t found = 0, differs = 0, bad = 0;
+        for (uint32_t w = plen; w < ql; w += 8) {
+            uint32_t a0, a1, l0, l1;
+            lds_window8(stage, (int32_t)(qs + w), a0, a1);
+            lds_window8(s->line1, (int32_t)w, l0, l1);
+            const uint32_t inl = ql - w;                                   // bytes of the line in this window (>= 1)
+            differs |= ((a0 ^ l0) & low_bytes(inl)) | ((a1 ^ l1) & (inl > 4 ? low_bytes(inl - 4) : 0u));   // (equal to line 1 so far?)
+            if (w >= end) continue;
+            const uint32_t inm = end - w;                                  // ... of the middle
+            const uint32_t v0 = low_bytes(inm), v1 = inm > 4 ? low_bytes(inm - 4) : 0u;
+            const uint32_t sm0 = (eq_bytes(a0, c0) | eq_bytes(a0, c1) | eq_bytes(a0, c2) | eq_bytes(a0, c3)) & v0;
+            const uint32_t sm1 = (eq_bytes(a1, c0) | eq_bytes(a1, c1) | eq_bytes(a1, c2) | eq_bytes(a1, c3)) & v1;
+            bad |= (nondigit_bytes(a0) & ~sm0 & v0) | (nondigit_bytes(a1) & ~sm1 & v1);
+            unsigned long long m = (unsigned long long)sm0 | ((unsigned long long)sm1 << 32);
+            const unsigned long long bytes = (unsigned long long)a0 | ((unsigned long long)a1 << 32);
+            while (m) {
+                const uint32_t k = ((uint32_t)__ffsll((long long)m) - 1u) >> 3;      // byte of the window
+                m &= m - 1;
+                if (found < 8) {
+                    epos |= (unsigned long long)(w + k) << (8 * found);
+                    eseq |= ((bytes >> (8 * k)) & 0xFFull) << (8 * found);
+                }
+                ++found;
             }
         }
-        if (col != nsep) f |= 1u;
-        close();
-        for (uint32_t pos = end; pos < ql; ++pos) eq = eq && pos < l1len && p[pos] == s->line1[pos];
-        if (ql < l1len && eq) f |= 128u;                                          // a proper prefix of line 1
+        if (bad) f |= 16u;
+        const unsigned long long want = (unsigned long long)s->seps_lo | ((unsigned long long)s->seps_hi << 32);
+        if (found != nsep || eseq != want) f |= 1u;
+        // (2) the fields: field c = [start, stop) with stop = the c-th separator (or the end of the middle)
+        uint32_t start = plen;
+        for (uint32_t c = 0; c <= nsep && c < UQ_QF_MAXC; ++c) {
+            uint32_t stop = c == nsep ? end : (uint32_t)(epos >> (8 * c)) & 0xFFu;
+            if (stop < start || stop > end) stop = start;                  // (only with bit0 up: keeps the window inside the line)
+            const uint32_t nd = stop - start;
+            uint32_t w0, w1, w2;
+            lds_window12(stage, (int32_t)(qs + stop) - 12, w0, w1, w2);    // bytes [stop - 12, stop)
+            const uint32_t keep = nd > 9 ? 9u : nd;                       // digits wanted: the last `keep` of the twelve bytes
+            // per dword: digits of the bytes that belong to the field, zero in the others (leading zeros add nothing below)
+            const uint32_t k2 = low_bytes(keep >= 4 ? 0u : 4u - keep), k1 = keep <= 4 ? 0xFFFFFFFFu : (keep >= 8 ? 0u : low_bytes(8u - keep)),
+                           k0 = keep <= 8 ? 0xFFFFFFFFu : low_bytes(12u - keep);
+            const uint32_t d0 = w0 & 0x0F0F0F0Fu & ~k0, d1 = w1 & 0x0F0F0F0Fu & ~k1, d2 = w2 & 0x0F0F0F0Fu & ~k2;    // ('0'..'9' = 0x30..0x39)
+            uint32_t mag = d0 >> 24;                                       // byte 3: the ninth digit from the end
+            mag = mag * 10 + (d1 & 0xFFu); mag = mag * 10 + ((d1 >> 8) & 0xFFu); mag = mag * 10 + ((d1 >> 16) & 0xFFu); mag = mag * 10 + (d1 >> 24);
+            mag = mag * 10 + (d2 & 0xFFu); mag = mag * 10 + ((d2 >> 8) & 0xFFu); mag = mag * 10 + ((d2 >> 16) & 0xFFu); mag = mag * 10 + (d2 >> 24);
+            if (nd > 9) f |= 4u;
+            else if (nd == 0 || (nd > 1 && mag < s->pow10[nd - 1])) f |= 16u;        // empty, or a leading zero ('007')
+            vals[c * pitch + row] = mag;
+            if (mag < s->vmin[c]) atomicMin(&s->vmin[c], mag);
+            if (mag > s->vmax[c]) atomicMax(&s->vmax[c], mag);
+            start = stop + 1;
+        }
+        if (ql < l1len && !differs && !(f & 32u)) f |= 128u;                      // a proper prefix of line 1
         if (ql < l1len && s->line1[l1len - ql] == s->line1[0]) f |= 128u;         // could be a proper suffix of it: the exact pass decides
     }
     if (f) atomicOr(&s->flags, f);
@@ -165,8 +238,13 @@ constexpr uint32_t PKS_WORDS = 256 * PKS_COPIES + 128;
 // encode: the caller packs with GUESSED decisions while counting, then checks the guess against the counts
 // (uq_pack_stats).  `st->reserved` is raised when the counts are incomplete (a record longer than the guess
 // allowed for, or malformed): the caller then runs the plain statistics pass.
-template <int BD, int BQ, bool NTRICK, bool FAST, bool STATS>
-__global__ __launch_bounds__(PK_THREADS, (STATS && NTRICK) ? 4 : 5) void pack_tile_kernel(const uint8_t* __restrict__ buf,
+// QN (uq_pack_stats_qname): the last wave of the workgroup takes the tile's QNAME lines (qname_tile) while the other three share the
+// packing -- two kinds of work side by side between the tile's two barriers.  (One wave doing both while three wait at the barrier
+// was the long pole of every tile: 2.10 ms against 1.38 ms without the QNAME phase; a fifth wave for the QNAME lines leaves the CU
+// with workgroups of five waves, of which it places three at a time where four of four waves fit: 2.0 - 2.5 ms.)  Built for four
+// workgroups per CU: the parser's registers come on top of a tile in flight.
+template <int BD, int BQ, bool NTRICK, bool FAST, bool STATS, bool QN>
+__global__ __launch_bounds__(PK_THREADS, (STATS && (NTRICK || QN)) ? 4 : 5) void pack_tile_kernel(const uint8_t* __restrict__ buf,
                                                                const uint64_t* __restrict__ ls, uint64_t first,
                                                                uint64_t n, PackLut lut, PackGeom g,
                                                                uint8_t* __restrict__ dna, uint8_t* __restrict__ qual,
@@ -193,12 +271,26 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && NTRICK) ? 4 : 5) void pack_ti
     if (STATS) for (uint32_t i = tid; i < PKS_WORDS; i += PK_THREADS) cnt_tab[i] = 0;       // the first tile's barrier orders it
     QnLds* qn = (QnLds*)(cnt_tab + PKS_WORDS);                   // the QNAME phase's state (uq_pack_stats_qname only)
     bool qn_on = false;
-    if (STATS && qf) {
-        qn_on = qf->ok != 0;                                     // the guess kernels in front may have declined: the lines are left alone
+    if (STATS && QN) qn_on = qf->ok != 0;                        // the guess kernels in front may have declined: the lines are left alone
+    if (STATS && QN) {
         qn->line1[tid] = qf->line1[tid]; qn->inset[tid] = qf->inset[tid];
+        if (tid < 16) qn->line1[256 + tid] = 0;
         if (tid < 32) qn->seps[tid] = qf->seps[tid];
         if (tid < UQ_QF_MAXC) { qn->vmin[tid] = 0xFFFFFFFFu; qn->vmax[tid] = 0; }
-        if (tid == 0) { qn->flags = 0; qn->plen = qf->plen; qn->slen = qf->slen; qn->nsep = qf->nsep; qn->l1len = qf->l1len; }
+        if (tid == 0) {
+            qn->flags = 0; qn->plen = qf->plen; qn->slen = qf->slen; qn->nsep = qf->nsep; qn->l1len = qf->l1len;
+            uint32_t set = 0x01010101u * qf->seps[0], nset = 1, lo = 0, hi = 0;       // (the guess kernel allows at most four distinct separators)
+            for (uint32_t k = 0; k < qf->nsep && k < 8; ++k) {
+                const uint32_t c = qf->seps[k];
+                if (k < 4) lo |= c << (8 * k); else hi |= c << (8 * (k - 4));
+                bool seen = false;
+                for (uint32_t m = 0; m < nset; ++m) seen = seen || ((set >> (8 * m)) & 0xFFu) == c;
+                if (!seen && nset < 4) { set = (set & ~(0xFFu << (8 * nset))) | (c << (8 * nset)); ++nset; }
+            }
+            qn->sepset = set; qn->seps_lo = lo; qn->seps_hi = hi;
+            uint32_t pw = 1;
+            for (uint32_t k = 0; k < 10; ++k) { qn->pow10[k] = pw; pw *= 10; }
+        }
     }
     if (d_async) {                                    // the queued form (uq_pack_stats_async): the census in front left the line count on the device;
         const uint64_t have = d_async[0] / 4;         // `n` is what the tables hold
@@ -257,13 +349,13 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && NTRICK) ? 4 : 5) void pack_ti
         } else {
             if (tid == 0) bad_tile = bad_tile < r0 ? bad_tile : r0;
             incomplete = true;
-            if (STATS && qn_on && tid == 0) atomicOr(&qf->flags, 256u);
+            if (STATS && QN && qn_on && tid == 0) atomicOr(&qf->flags, 256u);
         }
         __syncthreads();
         const bool ok = cur.ok;
         between();
-        // the QNAME lines of the tile: one wave (the last: it has the fewest lanes busy in phase B), a lane per read
-        if (STATS && qn_on && ok && tid >= PK_THREADS - 64 && tid - (PK_THREADS - 64) < Rt)
+        // the QNAME lines of the tile: the last wave, a lane per read (its lanes have no part in phase B: P is sized for three waves)
+        if (STATS && QN && qn_on && !(g.variable_dbg & 1) && ok && tid >= PK_THREADS - 64 && tid - (PK_THREADS - 64) < Rt)
             qname_tile(stage, meta, tid - (PK_THREADS - 64), qn, qvals, qpitch, r0 + (tid - (PK_THREADS - 64)));
         if (ok) {
             // ---- B: P lanes per read; a lane owns groups of 8 consecutive symbols, both streams:
@@ -329,6 +421,7 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && NTRICK) ? 4 : 5) void pack_ti
                             else {
                                 const uint32_t bin0 = (c0 << 6) | x0, bin1 = (c1 << 6) | x1;        // BQ <= 6: a bin per byte
                                 uint8_t* hb = (uint8_t*)cnt_tab + ((lane_id() & (PKS_COPIES - 1)) << 2);
+                                if (!(g.variable_dbg & 2))
 #pragma unroll
                                 for (int k = 0; k < 4; ++k) {
                                     atomicAdd((uint32_t*)(hb + (((bin0 >> (8 * k)) & 0xFFu) * (4 * PKS_COPIES))), 1u);
@@ -381,7 +474,8 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && NTRICK) ? 4 : 5) void pack_ti
                     // byte index counts from the row's LAST byte; only the top group can stick out of the row
                     uint8_t* od = orow_d - BD * gg;
                     uint8_t* oq = orow_q - BQ * gg;
-                    if (gg + 1 < g.G) {
+                    if (g.variable_dbg & 4) { if (gg == 0) { od[0] = (uint8_t)vd; oq[0] = (uint8_t)vq; } }
+                    else if (gg + 1 < g.G) {
                         // byte stores: unaligned ds_write_b32 / b16 pieces are accepted by gfx950 but slower (1.11 -> 1.27 ms)
 #pragma unroll
                         for (int i = 0; i < BD; ++i) od[-i] = (uint8_t)(vd >> (8 * i));
@@ -457,7 +551,7 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && NTRICK) ? 4 : 5) void pack_ti
         }
         acc.flush(st, first);
         if (incomplete) st->reserved = 1;
-        if (qf) {                                            // (the barrier above also closes the last tile's QNAME phase)
+        if (QN) {                                            // (the barrier above also closes the last tile's QNAME phase)
             if (qn_on && tid < UQ_QF_MAXC && qn->vmin[tid] <= qn->vmax[tid]) { atomicMin(&qf->vmin[tid], qn->vmin[tid]); atomicMax(&qf->vmax[tid], qn->vmax[tid]); }
             if (qn_on && tid == 0 && qn->flags) atomicOr(&qf->flags, qn->flags);
             if (blockIdx.x == 0 && tid == 0) qf->nreads = n;
@@ -506,16 +600,18 @@ typedef void (*PackKernel)(const uint8_t*, const uint64_t*, uint64_t, uint64_t, 
 
 template <int BD, int BQ>
 PackKernel pick_nt(bool ntrick, bool fast) {
-    if ((BD == 2 || BD == 3) && fast) return ntrick ? pack_tile_kernel<(BD == 3 ? 3 : 2), BQ, true, true, false> : pack_tile_kernel<(BD == 3 ? 3 : 2), BQ, false, true, false>;
-    return ntrick ? pack_tile_kernel<BD, BQ, true, false, false> : pack_tile_kernel<BD, BQ, false, false, false>;
+    if ((BD == 2 || BD == 3) && fast) return ntrick ? pack_tile_kernel<(BD == 3 ? 3 : 2), BQ, true, true, false, false> : pack_tile_kernel<(BD == 3 ? 3 : 2), BQ, false, true, false, false>;
+    return ntrick ? pack_tile_kernel<BD, BQ, true, false, false, false> : pack_tile_kernel<BD, BQ, false, false, false, false>;
 }
 
 // the fused pack + statistics kernels exist for the lookup-free path only (2-bit A/C/G/T, contiguous qualities)
-PackKernel pick_stats_kernel(int bq, bool ntrick) {
-#define UQ_PS(B) case B: return ntrick ? pack_tile_kernel<2, B, true, true, true> : pack_tile_kernel<2, B, false, true, true>;
-    switch (bq) { UQ_PS(1) UQ_PS(2) UQ_PS(3) UQ_PS(4) UQ_PS(5) default: return ntrick ? pack_tile_kernel<2, 6, true, true, true> : pack_tile_kernel<2, 6, false, true, true>; }
+template <bool QN>
+PackKernel pick_stats_kernel_q(int bq, bool ntrick) {
+#define UQ_PS(B) case B: return ntrick ? pack_tile_kernel<2, B, true, true, true, QN> : pack_tile_kernel<2, B, false, true, true, QN>;
+    switch (bq) { UQ_PS(1) UQ_PS(2) UQ_PS(3) UQ_PS(4) UQ_PS(5) default: return ntrick ? pack_tile_kernel<2, 6, true, true, true, QN> : pack_tile_kernel<2, 6, false, true, true, QN>; }
 #undef UQ_PS
 }
+PackKernel pick_stats_kernel(int bq, bool ntrick, bool qn) { return qn ? pick_stats_kernel_q<true>(bq, ntrick) : pick_stats_kernel_q<false>(bq, ntrick); }
 
 template <int BD>
 PackKernel pick_bq(int bq, bool ntrick, bool fast) {
@@ -617,10 +713,10 @@ static int pack_impl(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_s
     g.stage_bytes = stage_cap + 32;
     g.out_bytes = (((R * Cd + 15) & ~15u) + R * Cq + 15) & ~15u;
     // phase B: P lanes per read
-    uint32_t P = PK_THREADS / R;
+    uint32_t P = (d_q ? PK_THREADS - 64 : PK_THREADS) / R;        // (QN: the last wave parses QNAME lines instead)
     if (P > g.G) P = g.G;
     if (P < 1) P = 1;
-    g.P = P; g.magicP = magic_u32(P);
+    g.P = P; g.magicP = magic_u32(P); g.variable_dbg = (getenv("UQ_QN_OFF") ? 1 : 0) | (getenv("UQ_NO_ATOM") ? 2 : 0) | (getenv("UQ_NO_ROWW") ? 4 : 0);
     // fast path: bases == "ACGT" (2 bits) or up to eight bases that three bits of their characters tell apart (3 bits), qualities one
     // contiguous ASCII range below 128, at most one N-trick base
     bool fast = bd == 2 && hp->dna_code['A'] == 0 && hp->dna_code['C'] == 1 && hp->dna_code['G'] == 2 && hp->dna_code['T'] == 3;
@@ -671,12 +767,31 @@ static int pack_impl(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_s
     const size_t lds = 16 + (size_t)g.stage_bytes + g.out_bytes + (4 * R + 4) * 4 + 3 * 512 + (d_stats ? PKS_WORDS * 4 + sizeof(QnLds) : 0);
     UQ_REQUIRE(lds <= 160 * 1024, "uq_pack: tile needs %zu bytes of LDS", lds);
     const uint64_t tiles = (nreads + R - 1) / R;
+    PackKernel k = d_stats ? pick_stats_kernel((int)bq, ntrick, d_q != nullptr) : pick_kernel((int)bd, (int)bq, ntrick, fast);
+    if (lds > 48 * 1024) UQ_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // persistent workgroups: exactly as many as are resident at once (LDS and registers both limit that: a grid sized from the LDS
+    // alone would leave the kernels built for four waves per SIMD with a second, quarter-full round of workgroups)
     uint32_t per_cu = (uint32_t)((160 * 1024) / lds);
+    {
+        // (computed from the kernel's register count: hipOccupancyMaxActiveBlocksPerMultiprocessor is one workgroup per CU high for
+        // kernels with 97-112 SGPRs on this ROCm -- MI355X_MICROARCH.md, Correctness boundaries -- which these are)
+        static PackKernel cached_k = nullptr; static int cached_regs = 0;
+        if (cached_k != k) {
+            hipFuncAttributes fa;
+            UQ_CHECK_HIP(hipFuncGetAttributes(&fa, (const void*)k));
+            cached_k = k; cached_regs = fa.numRegs;
+        }
+        const uint32_t alloc = ((uint32_t)(cached_regs > 0 ? cached_regs : 128) + 7) & ~7u;          // VGPRs are handed out in eights
+        uint32_t waves_per_simd = 512 / alloc; if (waves_per_simd > 8) waves_per_simd = 8; if (waves_per_simd < 1) waves_per_simd = 1;
+        const uint32_t waves_per_wg = PK_THREADS / 64;
+        const uint32_t by_regs = 4 * waves_per_simd / waves_per_wg;
+        if (by_regs >= 1 && by_regs < per_cu) per_cu = by_regs;
+    }
+    if (getenv("UQ_DBG_GRID")) fprintf(stderr, "pack grid: per_cu %u lds %zu qn %d\n", per_cu, lds, d_q != nullptr);
+    if (getenv("UQ_PER_CU")) per_cu = (uint32_t)atoi(getenv("UQ_PER_CU"));
     if (per_cu > 6) per_cu = 6;
     if (per_cu < 1) per_cu = 1;
     const uint64_t blocks = tiles < (uint64_t)UQ_NUM_CU * per_cu ? tiles : (uint64_t)UQ_NUM_CU * per_cu;
-    PackKernel k = d_stats ? pick_stats_kernel((int)bq, ntrick) : pick_kernel((int)bd, (int)bq, ntrick, fast);
-    if (lds > 48 * 1024) UQ_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     k<<<(uint32_t)blocks, PK_THREADS, lds, ctx->stream>>>(d_buf, d_line_start, first_read, nreads, lut, g, d_dna, d_qual,
                                                          (unsigned long long*)d_bad, d_stats, d_async, d_q, d_vals, vals_pitch);
     UQ_LAUNCH_CHECK();

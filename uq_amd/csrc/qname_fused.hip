@@ -19,8 +19,10 @@ constexpr int QF_THREADS = 256;
 constexpr int QF_MAXCH = 64;
 constexpr uint32_t QF_SAMPLES = 4096;
 constexpr uint32_t QF_ROW = 64, QF_STRIDE = QF_ROW + 4;     // per-lane staging row (as qname_dev.hip)
-constexpr uint32_t QF_FT = 1u << 20;                        // first-occurrence slots per column
+constexpr uint32_t QF_FT = 1u << 20;                        // widest value range whose distinct values are counted here (a bitmap in LDS)
 constexpr uint32_t QF_SMALL = 4096;                         // ranges counted over the whole column, through private LDS tables
+constexpr size_t QF_PINNED_AT = 5200;                        // uq_qname_fused's place in ctx->h_pinned (uint64 index; common.h lists the others)
+static_assert(sizeof(uq_qname_fused) % 4 == 0 && QF_PINNED_AT * 8 + sizeof(uq_qname_fused) <= 8000 * 8, "the structure's slot in the pinned staging");
 constexpr uint64_t QF_PREFIX = 1ull << 21;                  // checkpoints a wide-range column is judged on (qname_device.INT_PREFIX)
 
 struct DevLine1 {
@@ -140,17 +142,24 @@ __device__ bool regex_special(uint8_t c) {
 }
 
 // uq.py:428-444 on the sample's reductions -> the guess.  One lane.
-__global__ void qname_guess_kernel(const DevLine1* __restrict__ l1, const uq_qname_layout_result* __restrict__ lay, const uint32_t* __restrict__ step,
+__global__ void qname_guess_kernel(const DevLine1* __restrict__ g_l1, const uq_qname_layout_result* __restrict__ g_lay, const uint32_t* __restrict__ step,
                                    uq_qname_fused* __restrict__ q) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // the inputs are copied to LDS first: lane 0's loops below are serial, and a dependent global load costs ten LDS reads
+    __shared__ DevLine1 s_l1;
+    __shared__ uq_qname_layout_result s_lay;
+    for (uint32_t i = threadIdx.x; i < sizeof(DevLine1) / 4; i += 64) ((uint32_t*)&s_l1)[i] = ((const uint32_t*)g_l1)[i];
+    for (uint32_t i = threadIdx.x; i < sizeof(uq_qname_layout_result) / 4; i += 64) ((uint32_t*)&s_lay)[i] = ((const uint32_t*)g_lay)[i];
+    __syncthreads();
+    const DevLine1* l1 = &s_l1;
+    const uq_qname_layout_result* lay = &s_lay;
+    const uint32_t t = threadIdx.x;                           // one wave
+    for (uint32_t i = t; i < 256; i += 64) { q->line1[i] = i < l1->len ? l1->text[i] : 0; q->inset[i] = 0; }
+    if (t < 32) q->seps[t] = 0;
+    if (t < UQ_QF_MAXC) { q->vmin[t] = 0xFFFFFFFFu; q->vmax[t] = 0; q->undetermined[t] = 0; }
+    for (uint32_t i = t; i < UQ_QF_MAXC * UQ_QF_MAXT; i += 64) (&q->counts[0][0])[i] = 0;
+    if (t < UQ_QF_MAXT) q->thresholds[t] = 0;
+    if (t != 0) return;
     q->ok = 0; q->plen = q->slen = q->nsep = q->l1len = 0; q->flags = 0; q->sample_step = *step; q->nth = 0; q->nreads = 0;
-    for (int i = 0; i < 256; ++i) { q->line1[i] = 0; q->inset[i] = 0; }
-    for (int i = 0; i < 32; ++i) q->seps[i] = 0;
-    for (int c = 0; c < UQ_QF_MAXC; ++c) {
-        q->vmin[c] = 0xFFFFFFFFu; q->vmax[c] = 0; q->undetermined[c] = 0;
-        for (int k = 0; k < UQ_QF_MAXT; ++k) q->counts[c][k] = 0;
-    }
-    for (int k = 0; k < UQ_QF_MAXT; ++k) q->thresholds[k] = 0;
     if (l1->bad || lay->flags) return;
     const uint32_t len = l1->len;
     // min_lcp / min_lcs start at line 1's length: with no sampled read (a file of one record) plen + slen > len declines below
@@ -179,9 +188,9 @@ __global__ void qname_guess_kernel(const DevLine1* __restrict__ l1, const uq_qna
             q->seps[nsep++] = c;
         }
     }
-    if (nsep == 0) return;
+    if (nsep == 0 || nsepch > 4) return;                      // (the pack kernel tests a window against four separator characters)
+    __builtin_amdgcn_s_waitcnt(0);                            // (the other lanes' zeroes of inset[] are stores of this same wave: in order)
     for (uint32_t k = 0; k < l1->nch; ++k) if (is_sep[k]) q->inset[l1->ch[k]] = 1;
-    for (uint32_t p = 0; p < len; ++p) q->line1[p] = l1->text[p];
     q->plen = plen; q->slen = slen; q->nsep = nsep; q->l1len = len;
     q->ok = 1;
 }
@@ -197,8 +206,8 @@ __device__ __forceinline__ Checkpoints checkpoints(uint64_t n) {
     return c;
 }
 
-// first[col][v - vmin] = lowest read holding value v: over all reads for ranges <= QF_SMALL (a private LDS table per workgroup: a
-// column of four lanes would otherwise be ten million atomics on four addresses), over reads [0, last checkpoint below 2^21] else.
+// first[col][v - vmin] = lowest read holding value v, for columns whose range is at most QF_SMALL: over all reads, through a private
+// LDS table per workgroup (a column of four lanes would otherwise be ten million atomics on four addresses).
 __global__ __launch_bounds__(QF_THREADS) void qf_first_seen_kernel(uq_qname_fused* __restrict__ q, const uint32_t* __restrict__ vals, uint64_t pitch,
                                                                     uint32_t* __restrict__ first) {
     __shared__ uint32_t s_first[QF_SMALL];
@@ -208,30 +217,80 @@ __global__ __launch_bounds__(QF_THREADS) void qf_first_seen_kernel(uq_qname_fuse
     const uint32_t vmin = q->vmin[col], vmax = q->vmax[col];
     if (n == 0 || vmin > vmax) return;
     const uint64_t range = (uint64_t)vmax - vmin + 1;
-    if (range > QF_FT) { if (blockIdx.x == 0 && threadIdx.x == 0) q->undetermined[col] = 1; return; }
-    const bool small = range <= QF_SMALL;
-    const Checkpoints cp = checkpoints(n);
-    const uint64_t upto = small ? n : cp.t[cp.nhead - 1] + 1;          // nhead >= 1: the first checkpoint is below 2^21
+    if (range > QF_SMALL) return;                                       // qf_wide_kernel's
     const uint32_t* v = vals + col * pitch;
-    uint32_t* f = first + (size_t)col * QF_FT;
-    if (small) {
-        for (uint32_t i = threadIdx.x; i < (uint32_t)range; i += QF_THREADS) s_first[i] = 0xFFFFFFFFu;
+    uint32_t* f = first + (size_t)col * QF_SMALL;
+    for (uint32_t i = threadIdx.x; i < (uint32_t)range; i += QF_THREADS) s_first[i] = 0xFFFFFFFFu;
+    __syncthreads();
+    // a workgroup takes a CONTIGUOUS slice of the reads (the first lane to see a value in a slice usually settles it), a lane four
+    // consecutive values per step, two steps requested before the first is looked at
+    const uint64_t per = (((n + gridDim.x - 1) / gridDim.x) + 3) & ~uint64_t(3);
+    const uint64_t lo = (uint64_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    auto see = [&](uint32_t val, uint64_t i) {
+        const uint32_t slot = val - vmin;
+        if (slot < range && (uint32_t)i < s_first[slot]) atomicMin(&s_first[slot], (uint32_t)i);
+    };
+    const bool vec = (((uintptr_t)v) & 15) == 0;             // column c starts at c * pitch values: 16-byte aligned when the pitch is a multiple of 4
+    uint64_t i = lo + 4 * (uint64_t)threadIdx.x;
+    if (vec) {
+        for (; i + 4 * QF_THREADS + 4 <= hi; i += 8 * QF_THREADS) {
+            const uint4 a = *(const uint4*)(v + i), b = *(const uint4*)(v + i + 4 * QF_THREADS);
+            see(a.x, i); see(a.y, i + 1); see(a.z, i + 2); see(a.w, i + 3);
+            const uint64_t j = i + 4 * QF_THREADS;
+            see(b.x, j); see(b.y, j + 1); see(b.z, j + 2); see(b.w, j + 3);
+        }
+    }
+    for (; i < hi; i += 4 * QF_THREADS)
+        for (uint32_t k = 0; k < 4 && i + k < hi; ++k) see(v[i + k], i + k);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < (uint32_t)range; i += QF_THREADS)
+        if (s_first[i] != 0xFFFFFFFFu && s_first[i] < f[i]) atomicMin(&f[i], s_first[i]);
+}
+
+// Wide ranges (QF_SMALL < range <= QF_FT): the rule `distinct among reads [0, T] > T / 10` is evaluated checkpoint by checkpoint,
+// T = 10 000, 20 000, 40 000 (those below 2^21 among the first QF_WIDE_CP), by ONE workgroup with the value set as a bitmap in LDS:
+// flow-cell coordinates fire at the first one.  counts[col][k] is written up to the checkpoint that fires (the host needs no more:
+// the column becomes `integers`), or for all of them when that is every checkpoint of the file; otherwise undetermined[col] = 1 and
+// the host sorts the column.  (A first-occurrence table over the first two million reads, as uq_int_prefix_distinct keeps it, is
+// two million contended global atomics: 0.1 ms for a decision the first 10 001 reads already give.)
+constexpr uint32_t QF_WIDE_CP = 3;
+__global__ __launch_bounds__(QF_THREADS) void qf_wide_kernel(uq_qname_fused* __restrict__ q, const uint32_t* __restrict__ vals, uint64_t pitch) {
+    extern __shared__ uint32_t bits[];                                  // QF_FT / 32 words
+    __shared__ uint32_t s_count;
+    const uint32_t col = blockIdx.x;
+    if (!q->ok || q->flags || col > q->nsep) return;
+    const uint64_t n = q->nreads;
+    const uint32_t vmin = q->vmin[col], vmax = q->vmax[col];
+    if (n == 0 || vmin > vmax) return;
+    const uint64_t range = (uint64_t)vmax - vmin + 1;
+    if (range <= QF_SMALL) return;
+    if (range > QF_FT) { if (threadIdx.x == 0) q->undetermined[col] = 1; return; }
+    const Checkpoints cp = checkpoints(n);
+    const uint32_t* v = vals + col * pitch;
+    for (uint32_t i = threadIdx.x; i < (uint32_t)((range + 31) / 32); i += QF_THREADS) bits[i] = 0;
+    if (threadIdx.x == 0) s_count = 0;
+    __syncthreads();
+    uint64_t done = 0;                                                  // reads [0, done) are in the set
+    bool fired = false;
+    uint32_t k = 0;
+    for (; k < cp.nth && k < QF_WIDE_CP && cp.t[k] < QF_PREFIX; ++k) {
+        uint32_t fresh = 0;
+        for (uint64_t i = done + threadIdx.x; i <= cp.t[k]; i += QF_THREADS) {
+            const uint32_t slot = v[i] - vmin;
+            if (slot >= range) continue;
+            const uint32_t bit = 1u << (slot & 31);
+            if (!(atomicOr(&bits[slot >> 5], bit) & bit)) ++fresh;
+        }
+        done = cp.t[k] + 1;
+        fresh = wave_sum(fresh);
+        if (lane_id() == 0 && fresh) atomicAdd(&s_count, fresh);
+        __syncthreads();
+        const uint32_t cnt = s_count;
+        if (threadIdx.x == 0) q->counts[col][k] = cnt;
+        if (cnt > cp.t[k] / 10) { fired = true; break; }
         __syncthreads();
     }
-    // a workgroup takes a CONTIGUOUS slice of the reads: the first lane to see a value in a slice usually settles it
-    const uint64_t per = (upto + gridDim.x - 1) / gridDim.x;
-    const uint64_t lo = (uint64_t)blockIdx.x * per, hi = lo + per < upto ? lo + per : upto;
-    for (uint64_t i = lo + threadIdx.x; i < hi; i += QF_THREADS) {
-        const uint32_t slot = v[i] - vmin;
-        if (slot >= range) continue;
-        if (small) { if ((uint32_t)i < s_first[slot]) atomicMin(&s_first[slot], (uint32_t)i); }
-        else if ((uint32_t)i < f[slot]) atomicMin(&f[slot], (uint32_t)i);
-    }
-    if (small) {
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < (uint32_t)range; i += QF_THREADS)
-            if (s_first[i] != 0xFFFFFFFFu && s_first[i] < f[i]) atomicMin(&f[i], s_first[i]);
-    }
+    if (!fired && k < cp.nth && threadIdx.x == 0) q->undetermined[col] = 1;      // checkpoints left that were not evaluated
 }
 
 __global__ __launch_bounds__(QF_THREADS) void qf_count_kernel(uq_qname_fused* __restrict__ q, const uint32_t* __restrict__ first) {
@@ -244,11 +303,11 @@ __global__ __launch_bounds__(QF_THREADS) void qf_count_kernel(uq_qname_fused* __
     const uint32_t vmin = q->vmin[col], vmax = q->vmax[col];
     if (n == 0 || vmin > vmax) return;
     const uint64_t range = (uint64_t)vmax - vmin + 1;
-    if (range > QF_FT) return;
-    const uint32_t nth = range <= QF_SMALL ? cp.nth : cp.nhead;
+    if (range > QF_SMALL) return;
+    const uint32_t nth = cp.nth;
     if (threadIdx.x < UQ_QF_MAXT) s_cnt[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t* f = first + (size_t)col * QF_FT;
+    const uint32_t* f = first + (size_t)col * QF_SMALL;
     for (uint64_t j = (uint64_t)blockIdx.x * QF_THREADS + threadIdx.x; j < range; j += (uint64_t)gridDim.x * QF_THREADS) {
         const uint32_t at = f[j];
         if (at == 0xFFFFFFFFu) continue;
@@ -298,22 +357,75 @@ extern "C" int uq_qname_guess_async(uq_ctx* ctx, const uint8_t* d_buf, const uin
 extern "C" int uq_qname_fused_finish(uq_ctx* ctx, uq_qname_fused* d_q, const uint32_t* d_vals, uint64_t vals_pitch) {
     UQ_REQUIRE(ctx && d_q && d_vals, "uq_qname_fused_finish: null argument");
     void* scr;
-    const size_t bytes = (size_t)UQ_QF_MAXC * QF_FT * sizeof(uint32_t);
+    const size_t bytes = (size_t)UQ_QF_MAXC * QF_SMALL * sizeof(uint32_t);
     UQ_TRY(uq_scratch(ctx, bytes, &scr));
     UQ_CHECK_HIP(hipMemsetAsync(scr, 0xFF, bytes, ctx->stream));
-    qf_first_seen_kernel<<<dim3(UQ_NUM_CU * 2, UQ_QF_MAXC), QF_THREADS, 0, ctx->stream>>>(d_q, d_vals, vals_pitch, (uint32_t*)scr);
+    qf_first_seen_kernel<<<dim3(UQ_NUM_CU * 4, UQ_QF_MAXC), QF_THREADS, 0, ctx->stream>>>(d_q, d_vals, vals_pitch, (uint32_t*)scr);
     UQ_LAUNCH_CHECK();
-    qf_count_kernel<<<dim3(64, UQ_QF_MAXC), QF_THREADS, 0, ctx->stream>>>(d_q, (const uint32_t*)scr);
+    qf_count_kernel<<<dim3(4, UQ_QF_MAXC), QF_THREADS, 0, ctx->stream>>>(d_q, (const uint32_t*)scr);
     UQ_LAUNCH_CHECK();
+    static bool attr_set = false;
+    if (!attr_set) { UQ_CHECK_HIP(hipFuncSetAttribute((const void*)qf_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(QF_FT / 8))); attr_set = true; }
+    qf_wide_kernel<<<UQ_QF_MAXC, QF_THREADS, QF_FT / 8, ctx->stream>>>(d_q, d_vals, vals_pitch);
+    UQ_LAUNCH_CHECK();
+    // the structure is sent on its way to the host right away (a region of the pinned staging that nothing else uses):
+    // uq_qname_fused_fetch then only waits -- a read-back queued by the fetch itself would start a host round trip later
+    UQ_TRY(uq_read_back(ctx, ctx->h_pinned + QF_PINNED_AT, d_q, sizeof(uq_qname_fused)));
+    ctx->qf_sent = d_q;
     return 0;
 }
 
 extern "C" int uq_qname_fused_fetch(uq_ctx* ctx, const uq_qname_fused* d_q, uq_qname_fused* h_out) {
     UQ_REQUIRE(ctx && d_q && h_out, "uq_qname_fused_fetch: null argument");
-    static_assert(sizeof(uq_qname_fused) % 4 == 0 && sizeof(uq_qname_fused) <= 3200 * 8, "read back through the pinned staging");
-    UQ_TRY(uq_read_back(ctx, ctx->h_pinned, d_q, sizeof(uq_qname_fused)));
+    if (ctx->qf_sent != d_q) UQ_TRY(uq_read_back(ctx, ctx->h_pinned + QF_PINNED_AT, d_q, sizeof(uq_qname_fused)));    // (no finish in front)
+    ctx->qf_sent = nullptr;
     UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-    memcpy(h_out, ctx->h_pinned, sizeof(uq_qname_fused));
+    memcpy(h_out, ctx->h_pinned + QF_PINNED_AT, sizeof(uq_qname_fused));
+    return 0;
+}
+
+// the columns of a fused pass in ONE launch: column c = d_vals + c * pitch -> h_outs[c] (itemsize h_itemsize[c], minus h_sub[c])
+struct EncCols { const uint32_t* in[UQ_QF_MAXC]; void* out[UQ_QF_MAXC]; uint32_t sub[UQ_QF_MAXC]; uint32_t isz[UQ_QF_MAXC]; };
+__global__ __launch_bounds__(QF_THREADS) void encode_cols_kernel(EncCols e, uint64_t n) {
+    const uint32_t c = blockIdx.y;
+    const uint32_t* __restrict__ in = e.in[c];
+    const uint32_t sub = e.sub[c], isz = e.isz[c];
+    // four values per lane: 16-byte loads; the stores are 4 / 8 / 16 bytes wide
+    const uint64_t i = ((uint64_t)blockIdx.x * QF_THREADS + threadIdx.x) * 4;
+    if (i >= n) return;
+    uint32_t v[4];
+    if (i + 4 <= n && ((uintptr_t)in & 15) == 0) { const uint4 a = *(const uint4*)(in + i); v[0] = a.x - sub; v[1] = a.y - sub; v[2] = a.z - sub; v[3] = a.w - sub; }
+    else for (uint32_t k = 0; k < 4; ++k) v[k] = i + k < n ? in[i + k] - sub : 0;
+    const uint32_t m = (uint32_t)(n - i < 4 ? n - i : 4);
+    if (isz == 1) {
+        uint8_t* o = (uint8_t*)e.out[c] + i;
+        if (m == 4 && ((uintptr_t)o & 3) == 0) *(uint32_t*)o = (v[0] & 0xFFu) | ((v[1] & 0xFFu) << 8) | ((v[2] & 0xFFu) << 16) | (v[3] << 24);
+        else for (uint32_t k = 0; k < m; ++k) o[k] = (uint8_t)v[k];
+    } else if (isz == 2) {
+        uint16_t* o = (uint16_t*)e.out[c] + i;
+        if (m == 4 && ((uintptr_t)o & 7) == 0) *(uint2*)o = make_uint2((v[0] & 0xFFFFu) | (v[1] << 16), (v[2] & 0xFFFFu) | (v[3] << 16));
+        else for (uint32_t k = 0; k < m; ++k) o[k] = (uint16_t)v[k];
+    } else if (isz == 4) {
+        uint32_t* o = (uint32_t*)e.out[c] + i;
+        for (uint32_t k = 0; k < m; ++k) o[k] = v[k];
+    } else {
+        uint64_t* o = (uint64_t*)e.out[c] + i;
+        for (uint32_t k = 0; k < m; ++k) o[k] = v[k];
+    }
+}
+
+extern "C" int uq_encode_u32_columns(uq_ctx* ctx, const uint32_t* d_vals, uint64_t vals_pitch, uint64_t n, int ncols, const uint32_t* h_sub,
+                                     const int* h_itemsize, void* const* h_d_outs) {
+    UQ_REQUIRE(ctx && (n == 0 || (d_vals && h_sub && h_itemsize && h_d_outs)) && ncols >= 0 && ncols <= UQ_QF_MAXC, "uq_encode_u32_columns: bad argument");
+    if (n == 0 || ncols == 0) return 0;
+    EncCols e;
+    memset(&e, 0, sizeof(e));
+    for (int c = 0; c < ncols; ++c) {
+        UQ_REQUIRE(h_itemsize[c] == 1 || h_itemsize[c] == 2 || h_itemsize[c] == 4 || h_itemsize[c] == 8, "uq_encode_u32_columns: itemsize %d not in {1,2,4,8}", h_itemsize[c]);
+        e.in[c] = d_vals + (size_t)c * vals_pitch; e.out[c] = h_d_outs[c]; e.sub[c] = h_sub[c]; e.isz[c] = (uint32_t)h_itemsize[c];
+    }
+    encode_cols_kernel<<<dim3((uint32_t)((n + 4 * QF_THREADS - 1) / (4 * QF_THREADS)), (uint32_t)ncols), QF_THREADS, 0, ctx->stream>>>(e, n);
+    UQ_LAUNCH_CHECK();
     return 0;
 }
 

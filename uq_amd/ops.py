@@ -218,7 +218,7 @@ class FusedQname:
     def __init__(self, ctx, capacity_reads):
         from ._lib import QnameFused
         t = ctx.torch
-        self.pitch = int(capacity_reads)
+        self.pitch = (int(capacity_reads) + 3) & ~3        # columns start 16-byte aligned
         self.q = t.empty(C.sizeof(QnameFused), dtype=t.uint8, device=ctx.device)
         self.vals = t.empty(QF_MAXC * self.pitch, dtype=t.int32, device=ctx.device)
 
@@ -245,6 +245,16 @@ def qname_fused_fetch(ctx, fq):
     out = QnameFused()
     call('uq_qname_fused_fetch', ctx.h, _p(fq.q), C.byref(out))
     return out
+
+
+def encode_u32_columns(ctx, fq, n, subs, itemsizes):
+    """The first len(subs) columns of a fused pass narrowed to their dtypes in one launch (uq_encode_u32_columns)."""
+    t = ctx.torch
+    k = len(subs)
+    outs = [t.empty(n, dtype=getattr(t, _NARROW_DT[isz]), device=ctx.device) for isz in itemsizes]
+    call('uq_encode_u32_columns', ctx.h, _p(fq.vals), fq.pitch, int(n), k, (C.c_uint32 * k)(*[int(x) for x in subs]),
+         (C.c_int * k)(*[int(x) for x in itemsizes]), (C.c_void_p * k)(*[o.data_ptr() for o in outs]))
+    return outs
 
 
 def encode_u32(ctx, val, n, sub, itemsize):

@@ -274,8 +274,8 @@ def analyse_fused(ctx, fq, nreads):
             lim, dt = _ladder(vmax - vmin)
             col['dtype'] = dt
             col['offset'] = bool(vmax > lim)
-        arrays.append(ops.encode_u32(ctx, fq.column(c, n), n, vmin if col['offset'] else 0, np.dtype(col['dtype']).itemsize))
         columns.append(col)
+    arrays = ops.encode_u32_columns(ctx, fq, n, [c['min'] if c['offset'] else 0 for c in columns], [np.dtype(c['dtype']).itemsize for c in columns])
     return prefix, suffix, separators, columns, arrays
 
 
