@@ -293,6 +293,20 @@ int uq_int_prefix_distinct(uq_ctx* ctx, const int64_t* d_val, uint64_t n, int64_
                            const uint64_t* h_thresholds, int nthresholds, uint64_t* h_counts);
 int uq_encode_int(uq_ctx* ctx, const int64_t* d_val, uint64_t n, int64_t sub, int itemsize, void* d_out);
 
+/* ---- e: row routing of the multi-GPU table builds (the reference is one process, these stand in for "all rows are in one
+ * numpy array" of uq.py:767-851).  uq_partition_rows: d_dest[r] = rank that row r of an UNSORTED shard goes to in a sample sort, from
+ * nsplit = world - 1 splitter rows in ascending order: the number of splitters below the row; a value that e >= 2 splitters share (a
+ * tie group heavier than a rank's share) is dealt to those e ranks by file position, d_dest = lb + floor((row_index_base + r) * e /
+ * total_rows), which keeps the concatenation of the ranks the stable order.  uq_owner_of_rows: d_owner[j] = rank whose record range
+ * [h_shard_starts[k], h_shard_starts[k + 1]) holds file-wide row d_row_index[j].  uq_index_affine: d_out[j] = d_in[j] + add between
+ * uint32 / int64 index arrays.  uq_invert_permutation: d_inv[d_perm[j] - base] = j; *h_bad = UQ_NONE or the lowest j that points
+ * outside [0, n). */
+int uq_partition_rows(uq_ctx* ctx, const uint8_t* d_splitters, uint32_t nsplit, uint32_t cols, const uint8_t* d_table, uint64_t rows,
+                      uint64_t row_index_base, uint64_t total_rows, uint8_t* d_dest);
+int uq_owner_of_rows(uq_ctx* ctx, const int64_t* d_row_index, uint64_t n, const int64_t* h_shard_starts, uint32_t world, uint8_t* d_owner);
+int uq_index_affine(uq_ctx* ctx, const void* d_in, int in_itemsize, uint64_t n, int64_t add, void* d_out, int out_itemsize);
+int uq_invert_permutation(uq_ctx* ctx, const void* d_perm, int perm_itemsize, uint64_t n, int64_t base, uint32_t* d_inv, uint64_t* h_bad);
+
 /* ---- f1 INSIDE a3 / a4: the QNAME passes in the pack kernel's read of the stream (uq.py:394-444 layout inference, 555-565 field
  * split, 717-736 int() of the fields).  The pack kernel already holds every record's QNAME line in LDS; with a uq_qname_fused it
  * also splits each line at the separators, parses the fields and writes them as uint32 columns -- against a layout GUESSED on

@@ -37,6 +37,36 @@ class NumpyRows:
         keys = v(t)
         return torch.tensor([bisect.bisect_left(keys, k) for k in v(p)], dtype=torch.int64)
 
+    # the routing arithmetic of csrc/route.hip, restated (include/uqhip.h: uq_partition_rows, uq_owner_of_rows, uq_index_affine,
+    # uq_invert_permutation)
+    def partition_rows(self, splitters, nsplit, cols, table, rows, index_base, total):
+        import bisect
+        keys = [bytes(r) for r in splitters.numpy().reshape(nsplit, cols)]
+        out = np.zeros(rows, dtype=np.uint8)
+        for r, row in enumerate(table.numpy().reshape(rows, cols)):
+            lb, ub = bisect.bisect_left(keys, bytes(row)), bisect.bisect_right(keys, bytes(row))
+            e = ub - lb
+            out[r] = lb + ((index_base + r) * e) // total if e >= 2 else lb
+        return torch.from_numpy(out)
+
+    def owner_of_rows(self, gidx, starts):
+        s = np.asarray(list(starts), dtype=np.int64)
+        return torch.from_numpy((np.searchsorted(s[1:-1], gidx.numpy(), side='right')).astype(np.uint8))
+
+    def index_affine(self, index, add, out_itemsize):
+        a = index.numpy().astype(np.int64)
+        if index.dtype == torch.int32: a &= 0xFFFFFFFF
+        return torch.from_numpy((a + add).astype(np.int32 if out_itemsize == 4 else np.int64))
+
+    def invert_permutation(self, perm, base=0):
+        a = perm.numpy().astype(np.int64)
+        if perm.dtype == torch.int32: a &= 0xFFFFFFFF
+        a = a - base
+        assert sorted(a.tolist()) == list(range(len(a)))
+        inv = np.empty(len(a), dtype=np.int32)
+        inv[a] = np.arange(len(a), dtype=np.int32)
+        return torch.from_numpy(inv)
+
 
 class _Failed:
     def __init__(self, text): self.text = text
@@ -116,9 +146,33 @@ def test_global_sort_and_gather(world):
     assert np.array_equal(gidx, order)
     assert np.array_equal(np.concatenate([o['rows'] for o in outs]), T[order])
     assert np.array_equal(np.concatenate([o['other'] for o in outs]), U[order])
-    # equal rows never straddle ranks (unique needs no boundary fix)
+    # with 600 distinct rows and 2-3 ranks no value is heavier than a rank's share: equal rows do not straddle ranks
     for a, b in zip(outs[:-1], outs[1:]):
         if len(a['rows']) and len(b['rows']): assert bytes(a['rows'][-1]) != bytes(b['rows'][0])
+
+
+def _skew_job(rank, world):
+    n, cols = 6000, 9
+    T = _table(n, cols, 50, seed=11)
+    T[np.random.RandomState(3).rand(n) < 0.7] = T[0]                       # one value holds 70 % of the rows
+    lo, hi = uqdist.shard_range(n, rank, world)
+    res = uqdist.global_sort_rows(NumpyRows(), torch.from_numpy(T[lo:hi].reshape(-1).copy()), hi - lo, cols, lo, total_rows=n)
+    return dict(rows=res['table'].numpy().reshape(-1, cols), gidx=res['gidx'].numpy(), offset=res['offset'])
+
+
+@pytest.mark.parametrize('world', [3, 4])
+def test_global_sort_deals_a_heavy_tie_group_over_ranks(world):
+    """A value heavier than a rank's share takes up several splitters; its rows are dealt to those ranks by file position: the
+    global order stays THE stable order and no rank ends up with (nearly) everything."""
+    outs = _run(world, _skew_job)
+    n, cols = 6000, 9
+    T = _table(n, cols, 50, seed=11)
+    T[np.random.RandomState(3).rand(n) < 0.7] = T[0]
+    order = np.lexsort([T[:, c] for c in range(cols - 1, -1, -1)])
+    assert np.array_equal(np.concatenate([o['gidx'] for o in outs]), order)
+    assert np.array_equal(np.concatenate([o['rows'] for o in outs]), T[order])
+    assert [o['offset'] for o in outs] == list(np.cumsum([0] + [len(o['gidx']) for o in outs[:-1]]))
+    assert max(len(o['gidx']) for o in outs) < 0.6 * n, [len(o['gidx']) for o in outs]
 
 
 def _stats_job(rank, world):

@@ -62,6 +62,27 @@ def test_sharded_encode_equals_oracle(tmp_path, world, flags):
     _check(tmp_path, world, flags)
 
 
+@pytest.mark.parametrize('world,flags', [(3, ['--sort', 'DNA']), (4, ['--sort', 'QUAL']), (3, ['--sort', 'QUAL', '--raw', 'DNA', 'QUAL', 'QNAME'])],
+                         ids=lambda v: str(v).replace(' ', ''))
+def test_sharded_encode_with_a_heavy_tie_group(tmp_path, world, flags):
+    """Sixty per cent of the reads are copies of ONE read: the value takes up several splitters of the sample sort, its rows are dealt
+    over those ranks by file position, and the unique tables / keys are stitched at the rank boundaries -- the container is still
+    the oracle's, byte for byte."""
+    import numpy as np
+    base = synth.fastq(20261003 + 47, 2400, 40, n_rate=1)
+    recs = base.split(b'\n')
+    recs = [b'\n'.join(recs[4 * i:4 * i + 4]) + b'\n' for i in range(2400)]
+    rng = np.random.default_rng(5)
+    twin = recs[7].split(b'\n')
+    out = []
+    for i, r in enumerate(recs):
+        if rng.random() < 0.6:
+            q = r.split(b'\n')
+            r = q[0] + b'\n' + twin[1] + b'\n+\n' + twin[3] + b'\n'                  # this read's name, the twin's bases and qualities
+        out.append(r)
+    _check(tmp_path, world, flags, fq=b''.join(out))
+
+
 def test_sharded_encode_with_idle_ranks(tmp_path):
     """Two reads over three ranks: a rank without reads still takes part in every exchange."""
     fq = b'@a:1:7\nACGTN\n+\nIHIH#\n@a:2:9\nACGTA\n+\nHIHII\n'

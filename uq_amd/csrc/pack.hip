@@ -53,7 +53,6 @@ struct PackGeom {
     // 3-bit bases on the fast path: (character >> h_shift) & 7 is different for every base of the alphabet (found by the host);
     // i2c = code of each such index, c2c = character of each code, eight bytes each (what v_perm_b32 selects from)
     uint32_t h_shift, i2c_lo, i2c_hi, c2c_lo, c2c_hi;
-    uint32_t variable_dbg;   // EXPERIMENT
 };
 
 // four ACGT characters -> four 2-bit codes (A0 C1 G2 T3), one per byte
@@ -355,7 +354,7 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && (NTRICK || QN)) ? 4 : 5) void
         const bool ok = cur.ok;
         between();
         // the QNAME lines of the tile: the last wave, a lane per read (its lanes have no part in phase B: P is sized for three waves)
-        if (STATS && QN && qn_on && !(g.variable_dbg & 1) && ok && tid >= PK_THREADS - 64 && tid - (PK_THREADS - 64) < Rt)
+        if (STATS && QN && qn_on && ok && tid >= PK_THREADS - 64 && tid - (PK_THREADS - 64) < Rt)
             qname_tile(stage, meta, tid - (PK_THREADS - 64), qn, qvals, qpitch, r0 + (tid - (PK_THREADS - 64)));
         if (ok) {
             // ---- B: P lanes per read; a lane owns groups of 8 consecutive symbols, both streams:
@@ -421,7 +420,6 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && (NTRICK || QN)) ? 4 : 5) void
                             else {
                                 const uint32_t bin0 = (c0 << 6) | x0, bin1 = (c1 << 6) | x1;        // BQ <= 6: a bin per byte
                                 uint8_t* hb = (uint8_t*)cnt_tab + ((lane_id() & (PKS_COPIES - 1)) << 2);
-                                if (!(g.variable_dbg & 2))
 #pragma unroll
                                 for (int k = 0; k < 4; ++k) {
                                     atomicAdd((uint32_t*)(hb + (((bin0 >> (8 * k)) & 0xFFu) * (4 * PKS_COPIES))), 1u);
@@ -474,8 +472,7 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && (NTRICK || QN)) ? 4 : 5) void
                     // byte index counts from the row's LAST byte; only the top group can stick out of the row
                     uint8_t* od = orow_d - BD * gg;
                     uint8_t* oq = orow_q - BQ * gg;
-                    if (g.variable_dbg & 4) { if (gg == 0) { od[0] = (uint8_t)vd; oq[0] = (uint8_t)vq; } }
-                    else if (gg + 1 < g.G) {
+                    if (gg + 1 < g.G) {
                         // byte stores: unaligned ds_write_b32 / b16 pieces are accepted by gfx950 but slower (1.11 -> 1.27 ms)
 #pragma unroll
                         for (int i = 0; i < BD; ++i) od[-i] = (uint8_t)(vd >> (8 * i));
@@ -716,7 +713,7 @@ static int pack_impl(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_s
     uint32_t P = (d_q ? PK_THREADS - 64 : PK_THREADS) / R;        // (QN: the last wave parses QNAME lines instead)
     if (P > g.G) P = g.G;
     if (P < 1) P = 1;
-    g.P = P; g.magicP = magic_u32(P); g.variable_dbg = (getenv("UQ_QN_OFF") ? 1 : 0) | (getenv("UQ_NO_ATOM") ? 2 : 0) | (getenv("UQ_NO_ROWW") ? 4 : 0);
+    g.P = P; g.magicP = magic_u32(P);
     // fast path: bases == "ACGT" (2 bits) or up to eight bases that three bits of their characters tell apart (3 bits), qualities one
     // contiguous ASCII range below 128, at most one N-trick base
     bool fast = bd == 2 && hp->dna_code['A'] == 0 && hp->dna_code['C'] == 1 && hp->dna_code['G'] == 2 && hp->dna_code['T'] == 3;
@@ -787,8 +784,6 @@ static int pack_impl(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_s
         const uint32_t by_regs = 4 * waves_per_simd / waves_per_wg;
         if (by_regs >= 1 && by_regs < per_cu) per_cu = by_regs;
     }
-    if (getenv("UQ_DBG_GRID")) fprintf(stderr, "pack grid: per_cu %u lds %zu qn %d\n", per_cu, lds, d_q != nullptr);
-    if (getenv("UQ_PER_CU")) per_cu = (uint32_t)atoi(getenv("UQ_PER_CU"));
     if (per_cu > 6) per_cu = 6;
     if (per_cu < 1) per_cu = 1;
     const uint64_t blocks = tiles < (uint64_t)UQ_NUM_CU * per_cu ? tiles : (uint64_t)UQ_NUM_CU * per_cu;

@@ -150,7 +150,8 @@ class Shard:
 
 # --------------------------------------------------------------------------- global --sort
 class HipRows:
-    """Row operations of one rank, on the GPU through the C ABI (the product backend)."""
+    """Row and index operations of one rank, on the GPU through the C ABI (the product backend).  The CPU tests of the exchange
+    logic pass a numpy object with the same methods (tests/test_dist_gloo.py)."""
 
     def __init__(self, ctx):
         self.ctx = ctx
@@ -169,22 +170,63 @@ class HipRows:
         from . import ops
         return ops.lower_bound_rows(self.ctx, sorted_table, rows, cols, probes, nprobes)
 
+    def partition_rows(self, splitters, nsplit, cols, table, rows, index_base, total):
+        """uint8 destination rank per row (uq_partition_rows)."""
+        from ._lib import call
+        t = self.torch
+        dest = t.empty(rows, dtype=t.uint8, device=self.device)
+        call('uq_partition_rows', self.ctx.h, C.c_void_p(splitters.data_ptr()), int(nsplit), int(cols), C.c_void_p(table.data_ptr()), int(rows),
+             int(index_base), int(total), C.c_void_p(dest.data_ptr()))
+        return dest
 
-def exchange_split(send, splits, dist, torch, device, dtype, group=None):
+    def owner_of_rows(self, gidx, starts):
+        from ._lib import call
+        t = self.torch
+        n, world = int(gidx.numel()), len(starts) - 1
+        owner = t.empty(n, dtype=t.uint8, device=self.device)
+        call('uq_owner_of_rows', self.ctx.h, C.c_void_p(gidx.data_ptr()), n, (C.c_int64 * (world + 1))(*[int(x) for x in starts]), world,
+             C.c_void_p(owner.data_ptr()))
+        return owner
+
+    def index_affine(self, index, add, out_itemsize):
+        """index (int32 = unsigned 32-bit positions, or int64) + add -> int32 / int64 tensor (uq_index_affine)."""
+        from ._lib import call
+        t = self.torch
+        n = int(index.numel())
+        out = t.empty(n, dtype=t.int32 if out_itemsize == 4 else t.int64, device=self.device)
+        call('uq_index_affine', self.ctx.h, C.c_void_p(index.data_ptr()), index.element_size(), n, int(add), C.c_void_p(out.data_ptr()), out_itemsize)
+        return out
+
+    def invert_permutation(self, perm, base=0):
+        """inv[perm[j] - base] = j as an int32 tensor (uq_invert_permutation); raises when perm is no permutation of base .. base + n - 1."""
+        from ._lib import call
+        t = self.torch
+        n = int(perm.numel())
+        inv = t.empty(n, dtype=t.int32, device=self.device)
+        bad = C.c_uint64()
+        call('uq_invert_permutation', self.ctx.h, C.c_void_p(perm.data_ptr()), perm.element_size(), n, int(base), C.c_void_p(inv.data_ptr()), C.byref(bad))
+        if bad.value != UQ_NONE:
+            raise RuntimeError('row numbers received do not cover the shard (entry %d)' % bad.value)
+        return inv
+
+
+def exchange_split(send, splits, dist, torch, device, dtype, group=None, rcounts=None):
     """all-to-all(v) of ONE contiguous 1-D tensor: elements [sum(splits[:d]), sum(splits[:d + 1])) go to rank d.  Returns
-    (received tensor, list of received counts per source).  Two collectives -- the counts, then the payload, both
-    `all_to_all_single` (on the nccl backend RCCL's all-to-all: every xGMI link carries its own peer's slice at once) -- and
-    ONE host round trip (the receive sizes: the output buffer has to be allocated)."""
+    (received tensor, list of received counts per source).  `all_to_all_single` (on the nccl backend RCCL's all-to-all: every xGMI
+    link carries its own peer's slice at once); when the caller does not know the receive counts (`rcounts`) they are exchanged
+    first, which costs ONE host round trip (the output buffer has to be allocated)."""
     world = dist.get_world_size(group)
     out_device = device
     if dist.get_backend(group) == 'gloo' and torch.device(device).type != 'cpu':
         send = send.cpu()                            # gloo rehearsal on a GPU box (several ranks sharing one card): staged through the host
         device = 'cpu'
     splits = [int(x) for x in splits]
-    sc = torch.tensor(splits, dtype=torch.int64, device=device)
-    rc = torch.empty_like(sc)
-    dist.all_to_all_single(rc, sc, group=group)
-    rcounts = [int(x) for x in rc.tolist()]
+    if rcounts is None:
+        sc = torch.tensor(splits, dtype=torch.int64, device=device)
+        rc = torch.empty_like(sc)
+        dist.all_to_all_single(rc, sc, group=group)
+        rcounts = [int(x) for x in rc.tolist()]
+    rcounts = [int(x) for x in rcounts]
     recv = torch.empty(sum(rcounts), dtype=dtype, device=device)
     dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=rcounts, input_split_sizes=splits, group=group)
     if out_device != device:
@@ -199,75 +241,103 @@ def exchange_v(parts, dist, torch, device, dtype, group=None):
     return list(recv.split(rcounts))
 
 
-def choose_splitters(samples, cols, world):
-    """Host: W-1 splitter rows from the gathered sample rows (numpy; a few KB of control data)."""
-    s = np.asarray(samples, dtype=np.uint8).reshape(-1, cols)
-    if len(s) == 0:
-        return np.zeros((world - 1, cols), dtype=np.uint8)
-    order = np.lexsort([s[:, c] for c in range(cols - 1, -1, -1)])
-    s = s[order]
-    pick = [min(len(s) - 1, (k * len(s)) // world) for k in range(1, world)]
-    return s[pick]
+def gather_matrix(row, dist, torch, device, group=None):
+    """Every rank's list of `world` ints -> the world x world matrix on every rank (one all-gather, one host read)."""
+    world = dist.get_world_size(group)
+    dev = 'cpu' if dist.get_backend(group) == 'gloo' else device
+    mine = torch.tensor([int(x) for x in row], dtype=torch.int64, device=dev)
+    allr = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(allr, mine, group=group)
+    return [[int(x) for x in r.tolist()] for r in allr]
 
 
-def global_sort_rows(be, table, rows, cols, read_offset, group=None, samples_per_rank=None):
-    """Sample sort of row shards over the process group.  Every rank passes its shard (`rows` x `cols`
-    bytes, records [read_offset, read_offset + rows) of the file) and gets back a contiguous range of the
-    globally sorted order: dict(table=sorted rows, rows=m, gidx=int64 global read index of each row,
-    offset=global position of the first row).  Stable: equal rows keep file order (they all land on one
-    rank, arrive grouped by source rank, and the final local sort is stable)."""
+SAMPLES_PER_RANK = 1024
+
+
+def _sample_positions(rows, k, seed):
+    """k stratified pseudo-random row numbers of a shard (host control data: a few KB)."""
+    if rows == 0:
+        return np.zeros(0, dtype=np.int32)
+    rng = np.random.default_rng(seed)
+    k = min(k, rows)
+    edges = (np.arange(k + 1, dtype=np.int64) * rows) // k
+    return (edges[:-1] + (rng.random(k) * (edges[1:] - edges[:-1])).astype(np.int64)).astype(np.int32)
+
+
+def global_sort_rows(be, table, rows, cols, read_offset, group=None, samples_per_rank=None, total_rows=None):
+    """Sample sort of row shards over the process group -- ONE sort per row.  Every rank passes its UNSORTED shard (`rows` x `cols`
+    bytes, records [read_offset, read_offset + rows) of the file) and gets back a contiguous range of the globally sorted order:
+    dict(table=sorted rows, rows=m, gidx=int64 file-wide index of each row, offset=global position of the first row).
+      1. a stratified sample of every shard is all-gathered and sorted on the device; W - 1 splitters are its quantiles;
+      2. every row's destination = the number of splitters below it (uq_partition_rows) -- no local sort is needed for that;
+      3. stable partition of the shard by destination (a one-byte key: one radix pass), all-to-all(v) of rows and file indices;
+      4. ONE stable sort of what arrived.  The runs arrive in source-rank order and each is in file order, so equal rows end up in
+         file order: the global order is THE stable memcmp order, whatever the splitters.
+    Equal rows share a destination, except a value that takes up several splitters (a tie group heavier than a rank's share): it is
+    dealt over those ranks by file position, so consumers that count groups must look at their neighbours' boundary rows
+    (dist_encode._unique).  Host round trips: the send counts, and one all-gather of the count matrix."""
     dist, rank, world = _world()
     torch = be.torch
-    if rows:
-        perm = be.argsort_rows(table, rows, cols)
-        local_sorted = be.gather_rows(table, rows, cols, perm)
-        gidx = perm.to(torch.int64) & 0xFFFFFFFF
-        gidx += int(read_offset)
-    else:                                   # an empty shard still takes part in the exchange
-        local_sorted, gidx = table, torch.empty(0, dtype=torch.int64, device=be.device)
     if world == 1:
-        return dict(table=local_sorted, rows=rows, gidx=gidx, offset=0)
-    # 1. samples -> splitters (identical on every rank)
-    k = samples_per_rank or max(1, min(rows, 32 * world))
-    pick = torch.tensor([min(rows - 1, (i * rows) // k) for i in range(k)] if rows else [], dtype=torch.int32, device=be.device)
-    samp = be.gather_rows(local_sorted, rows, cols, pick) if rows else torch.empty(0, dtype=torch.uint8, device=be.device)
-    gathered = exchange_v([samp for _ in range(world)], dist, torch, be.device, torch.uint8, group)
-    allsamp = torch.cat(gathered).cpu().numpy()
-    split = choose_splitters(allsamp, cols, world)
-    d_split = torch.from_numpy(split.reshape(-1).copy()).to(be.device)
-    # 2. cut the sorted shard at the splitters: rows < splitter_k stay below cut k (lower bound: equal rows go up together)
-    cuts = be.lower_bound_rows(local_sorted, rows, cols, d_split, world - 1).cpu().tolist() if rows else [0] * (world - 1)
-    bounds = [0] + [int(c) for c in cuts] + [rows]
+        if rows:
+            perm = be.argsort_rows(table, rows, cols)
+            return dict(table=be.gather_rows(table, rows, cols, perm), rows=rows, gidx=be.index_affine(perm, int(read_offset), 8), offset=0)
+        return dict(table=table, rows=0, gidx=torch.empty(0, dtype=torch.int64, device=be.device), offset=0)
+    if total_rows is None:
+        total_rows = sum(r[0] for r in gather_matrix([rows], dist, torch, be.device, group))
+    # 1. samples -> splitters (identical on every rank: same gathered rows, same deterministic sort)
+    k = samples_per_rank or SAMPLES_PER_RANK
+    pick = torch.from_numpy(_sample_positions(rows, k, 20261003 + rank)).to(be.device)
+    samp = be.gather_rows(table, rows, cols, pick) if rows else torch.empty(0, dtype=torch.uint8, device=be.device)
+    allsamp = torch.cat(exchange_v([samp for _ in range(world)], dist, torch, be.device, torch.uint8, group))
+    ns = int(allsamp.numel()) // cols
+    if ns:
+        sorder = be.argsort_rows(allsamp, ns, cols)
+        qpos = torch.tensor([min(ns - 1, (j * ns) // world) for j in range(1, world)], dtype=torch.int32, device=be.device)
+        d_split = be.gather_rows(allsamp, ns, cols, be.gather_rows(sorder.view(torch.uint8), ns, 4, qpos).view(torch.int32))
+    else:
+        d_split = torch.zeros((world - 1) * cols, dtype=torch.uint8, device=be.device)
+    # 2 + 3. destinations, stable partition, exchange
+    if rows:
+        dest = be.partition_rows(d_split, world - 1, cols, table, rows, int(read_offset), int(total_rows))
+        order = be.argsort_rows(dest, rows, 1)
+        send_rows = be.gather_rows(table, rows, cols, order)
+        send_idx = be.index_affine(order, int(read_offset), 8)
+        sorted_dest = be.gather_rows(dest, rows, 1, order)
+        probes = torch.arange(1, world, dtype=torch.uint8, device=be.device)
+        cuts = [int(c) for c in be.lower_bound_rows(sorted_dest, rows, 1, probes, world - 1).cpu().tolist()]
+    else:
+        send_rows, send_idx, cuts = table, torch.empty(0, dtype=torch.int64, device=be.device), [0] * (world - 1)
+    bounds = [0] + cuts + [rows]
     nsend = [bounds[d + 1] - bounds[d] for d in range(world)]
-    # 3. all-to-all(v) of rows and their global indices: the sorted shard IS the send buffer, cut at the splitters
-    merged, _ = exchange_split(local_sorted, [k * cols for k in nsend], dist, torch, be.device, torch.uint8, group)
-    midx, _ = exchange_split(gidx, nsend, dist, torch, be.device, torch.int64, group)
-    m = int(midx.numel())
-    # 4. stable local sort of the received runs (source-rank order = file order inside ties)
+    matrix = gather_matrix(nsend, dist, torch, be.device, group)            # matrix[s][d] = rows rank s sends to rank d
+    nrecv = [matrix[s][rank] for s in range(world)]
+    merged, _ = exchange_split(send_rows, [c * cols for c in nsend], dist, torch, be.device, torch.uint8, group, rcounts=[c * cols for c in nrecv])
+    midx, _ = exchange_split(send_idx, nsend, dist, torch, be.device, torch.int64, group, rcounts=nrecv)
+    m = sum(nrecv)
+    # 4. the one sort
     if m:
         perm2 = be.argsort_rows(merged, m, cols)
         out = be.gather_rows(merged, m, cols, perm2)
         oidx = be.gather_rows(midx.view(torch.uint8), m, 8, perm2).view(torch.int64)
     else:
         out, oidx = merged, midx
-    counts = torch.zeros(world, dtype=torch.int64, device='cpu' if dist.get_backend(group) == 'gloo' else be.device)
-    counts[rank] = m
-    dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
-    offset = sum(counts.tolist()[:rank])
+    offset = sum(sum(matrix[s][d] for s in range(world)) for d in range(rank))
     return dict(table=out, rows=m, gidx=oidx, offset=offset)
 
 
 def _route_by_owner(be, shard_starts, gidx, world):
-    """Sort file-wide row numbers by owning rank: (order, sorted gidx, bounds per destination rank)."""
+    """Group file-wide row numbers by owning rank, stably: (order, grouped gidx, bounds per destination rank)."""
     torch = be.torch
     n = int(gidx.numel())
-    starts = torch.tensor(list(shard_starts), dtype=torch.int64, device=be.device)
-    owner = (torch.bucketize(gidx, starts[1:-1], right=True)).to(torch.uint8)          # plumbing on indices only
-    order = be.argsort_rows(owner, n, 1) if n else torch.empty(0, dtype=torch.int32, device=be.device)
-    sorted_idx = be.gather_rows(gidx.view(torch.uint8), n, 8, order).view(torch.int64) if n else gidx
-    sorted_owner = be.gather_rows(owner, n, 1, order) if n else owner
+    if n == 0:
+        return torch.empty(0, dtype=torch.int32, device=be.device), gidx, [0] * (world + 1)
+    owner = be.owner_of_rows(gidx, shard_starts)
+    order = be.argsort_rows(owner, n, 1)
+    sorted_idx = be.gather_rows(gidx.view(torch.uint8), n, 8, order).view(torch.int64)
+    sorted_owner = be.gather_rows(owner, n, 1, order)
     probes = torch.arange(1, world, dtype=torch.uint8, device=be.device)
-    cuts = be.lower_bound_rows(sorted_owner, n, 1, probes, world - 1).cpu().tolist() if n else [0] * (world - 1)
+    cuts = be.lower_bound_rows(sorted_owner, n, 1, probes, world - 1).cpu().tolist()
     return order, sorted_idx, [0] + [int(c) for c in cuts] + [n]
 
 
@@ -280,19 +350,15 @@ def dist_scatter_rows(be, values, cols, shard_starts, gidx, group=None):
     n = int(gidx.numel())
     mine = int(shard_starts[rank + 1]) - int(shard_starts[rank])
     if world == 1:
-        inv = torch.empty(n, dtype=torch.int32, device=be.device)
-        inv[gidx - int(shard_starts[0])] = torch.arange(n, dtype=torch.int32, device=be.device)
-        return be.gather_rows(values, n, cols, inv) if n else values
+        return be.gather_rows(values, n, cols, be.invert_permutation(gidx, int(shard_starts[0]))) if n else values
     order, sorted_idx, bounds = _route_by_owner(be, shard_starts, gidx, world)
     sorted_vals = be.gather_rows(values, n, cols, order) if n else values
     nsend = [bounds[d + 1] - bounds[d] for d in range(world)]
-    ridx, _ = exchange_split(sorted_idx, nsend, dist, torch, be.device, torch.int64, group)
-    rval, _ = exchange_split(sorted_vals, [k * cols for k in nsend], dist, torch, be.device, torch.uint8, group)
+    ridx, nrecv = exchange_split(sorted_idx, nsend, dist, torch, be.device, torch.int64, group)
+    rval, _ = exchange_split(sorted_vals, [k * cols for k in nsend], dist, torch, be.device, torch.uint8, group, rcounts=[k * cols for k in nrecv])
     if int(ridx.numel()) != mine:
         raise RuntimeError('dist_scatter_rows: received %d rows for a shard of %d' % (int(ridx.numel()), mine))
-    inv = torch.empty(mine, dtype=torch.int32, device=be.device)
-    inv[ridx - int(shard_starts[rank])] = torch.arange(mine, dtype=torch.int32, device=be.device)
-    return be.gather_rows(rval, mine, cols, inv) if mine else rval
+    return be.gather_rows(rval, mine, cols, be.invert_permutation(ridx, int(shard_starts[rank]))) if mine else rval
 
 
 def dist_gather_rows(be, table, rows, cols, shard_starts, gidx, group=None):
@@ -302,21 +368,13 @@ def dist_gather_rows(be, table, rows, cols, shard_starts, gidx, group=None):
     torch = be.torch
     n = int(gidx.numel())
     if world == 1:
-        return be.gather_rows(table, rows, cols, (gidx - int(shard_starts[0])).to(torch.int32))
-    starts = torch.tensor(list(shard_starts), dtype=torch.int64, device=be.device)
-    owner = (torch.bucketize(gidx, starts[1:-1], right=True)).to(torch.uint8)          # plumbing on indices only
-    order = be.argsort_rows(owner, n, 1) if n else torch.empty(0, dtype=torch.int32, device=be.device)
-    sorted_idx = be.gather_rows(gidx.view(torch.uint8), n, 8, order).view(torch.int64) if n else gidx
-    sorted_owner = be.gather_rows(owner, n, 1, order) if n else owner
-    probes = torch.arange(1, world, dtype=torch.uint8, device=be.device)
-    cuts = be.lower_bound_rows(sorted_owner, n, 1, probes, world - 1).cpu().tolist() if n else [0] * (world - 1)
-    bounds = [0] + [int(c) for c in cuts] + [n]
-    req, nreq = exchange_split(sorted_idx, [bounds[d + 1] - bounds[d] for d in range(world)], dist, torch, be.device, torch.int64, group)
+        return be.gather_rows(table, rows, cols, be.index_affine(gidx, -int(shard_starts[0]), 4))
+    order, sorted_idx, bounds = _route_by_owner(be, shard_starts, gidx, world)
+    nsend = [bounds[d + 1] - bounds[d] for d in range(world)]
+    req, nreq = exchange_split(sorted_idx, nsend, dist, torch, be.device, torch.int64, group)
     # one gather serves all the requesters: the reply buffer is the requests' order, i.e. already grouped by destination
-    want = (req - int(shard_starts[rank])).to(torch.int32)
+    want = be.index_affine(req, -int(shard_starts[rank]), 4)
     reply = be.gather_rows(table, rows, cols, want) if want.numel() else torch.empty(0, dtype=torch.uint8, device=be.device)
-    got, _ = exchange_split(reply, [k * cols for k in nreq], dist, torch, be.device, torch.uint8, group)
+    got, _ = exchange_split(reply, [k * cols for k in nreq], dist, torch, be.device, torch.uint8, group, rcounts=[k * cols for k in nsend])
     # rows came back in `order`; undo it: out[order[j]] = got[j]
-    inv = torch.empty(n, dtype=torch.int32, device=be.device)
-    inv[order.to(torch.int64) & 0xFFFFFFFF] = torch.arange(n, dtype=torch.int32, device=be.device)
-    return be.gather_rows(got, n, cols, inv) if n else got
+    return be.gather_rows(got, n, cols, be.invert_permutation(order, 0)) if n else got

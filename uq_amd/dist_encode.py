@@ -186,17 +186,28 @@ class ShardedSession(Session):
         return gs, {'gidx': gs['gidx'], 'offset': gs['offset'], 'rows': gs['rows']}
 
     def _unique(self, gs, cols):
-        """Head flags of a sorted shard -> (unique rows, count, first global group id, total groups, group id per sorted row)."""
+        """Head flags of a sorted shard -> (unique rows, count, first global group id, total groups, group id per sorted row).
+        A group may run on from the rank in front (dist.global_sort_rows deals a tie group heavier than a rank's share over several
+        ranks): the ranks exchange their first and last rows, and a rank whose first row equals the last row in front of it drops
+        that row from its unique table and starts its ids one lower."""
         ops, ctx, t = self.ops, self.ctx, self.ctx.torch
         m = gs['rows']
         if m:
             _, _, skey, uniq, nu = ops.unique_rows(ctx, gs['table'], m, cols, want_key=False)
+            edge = bytes(ctx.to_numpy(gs['table'][:cols]).tobytes()) + bytes(ctx.to_numpy(gs['table'][(m - 1) * cols:m * cols]).tobytes())
         else:
-            skey, uniq, nu = t.empty(0, dtype=t.int32, device=ctx.device), ctx.empty(0), 0
+            skey, uniq, nu, edge = t.empty(0, dtype=t.int32, device=ctx.device), ctx.empty(0), 0, b''
+        edges = self.shard.gather_bytes(edge)                       # first + last row of every rank (empty: no rows)
         per_rank = self.shard.gather_ints(nu)
-        g0, nu_total = sum(per_rank[:self.rank]), sum(per_rank)
-        g0_bits = g0 - (1 << 32) if g0 >= (1 << 31) else g0      # group ids are u32 bit patterns in an int32 tensor
-        return uniq, nu, g0, nu_total, skey + g0_bits              # index arithmetic only
+        cont, last = [], None                                       # cont[r]: rank r's first group is the one the rows in front ended with
+        for r in range(self.world):
+            cont.append(1 if (edges[r] and last is not None and edges[r][:cols] == last) else 0)
+            if edges[r]: last = edges[r][cols:]
+        eff = [per_rank[r] - cont[r] for r in range(self.world)]
+        g0, nu_total = sum(eff[:self.rank]), sum(eff)
+        mine = cont[self.rank]
+        shift = g0 - mine                                           # (group ids are u32 bit patterns in an int32 tensor)
+        return uniq[mine * cols:], nu - mine, g0, nu_total, self.be.index_affine(skey, shift, 4) if m else skey
 
     def _key_member(self, gs, order, gids, sort_order, isz, name):
         """The key member: group ids in sorted order (this table is sorted on), in file order, or in another table's order."""
