@@ -95,8 +95,12 @@ def main():
     ap.add_argument('--reads', type=int, default=10_000_000, help='reads per GPU (default: BASELINE configs[1])')
     ap.add_argument('--length', type=int, default=150)
     ap.add_argument('--cpu-sample', type=int, default=100_000, help='reads timed on the host for cpu_baseline (0 = skip)')
-    ap.add_argument('--sort-reads', type=int, default=25_000_000,
-                    help='N > 1 only: reads per GPU of the global --sort leg (BASELINE configs[3]: 200 M over 8 GPUs = 25 M each); 0 = skip')
+    ap.add_argument('--north-star-reads', type=int, default=200_000_000,
+                    help='N = 1: the same step timed once more at the north_star\'s single-GPU size (200 M x 150 bp), reported as '
+                         'north_star_200M; 0 = skip')
+    ap.add_argument('--sort-reads', type=int, default=200_000_000,
+                    help='reads of the global --sort legs over ALL GPUs (strong scaling: 200 M / N per GPU; BASELINE configs[3] is 200 M over '
+                         '8 GPUs); 0 = skip')
     ap.add_argument('--force-dist', action='store_true', help='initialise the process group and run the collectives even with one rank')
     ap.add_argument('--multi-pass', action='store_true',
                     help='round 1\'s step: census -> index -> statistics -> decisions -> pack, three reads of the stream (the default '
@@ -139,23 +143,15 @@ def main():
     from uq_amd.device import SideContext
     side = SideContext(ctx)
     red_dev = ctx.device if not (use_dist and dist.get_backend() == 'gloo') else 'cpu'     # where the closing all-reduces live
-
-    n = args.reads
     notricks = args.workload == 'cfg5-notricks'
-    if args.workload == 'cfg2':
-        spec = synth.Spec(SEED, args.length)
-    else:
-        spec = synth.Spec(20261003 + 5, (36, 301), n_rate=1)
-    d_buf = ops.synth_fastq(ctx, spec, rank * n, n)           # resident in HBM before timing
-    fastq_bytes = d_buf.numel()
-    ctx.sync()
-
-    pack_events = []
-    state = {}
     # N = 1: the step is the WHOLE encode of the shard, QNAME columns included.  N > 1: the QNAME layout is a property of the whole
     # file (line 1, common prefix): the sharded encoder (uq_amd.dist_encode) combines it over the ranks; this bench's shards are
     # timed without it and the JSON says so.
     qname_in_step = not use_dist and not args.no_qname
+
+    def fence():
+        if use_dist: dist.barrier()
+        torch.cuda.synchronize()
 
     def fetch(st):
         if use_dist:
@@ -163,207 +159,176 @@ def main():
             return uqdist.allreduce_stats(ctx, st)
         return ops.stats_fetch(ctx, st)
 
-    def decide_and_params(hs, nreads):
-        d = host_decide(hs, notricks=notricks)
-        p = ops.make_pack_params(d['bases'], d['qualities'], d['N_qual'], d['bits_per_base'], d['bits_per_quality'],
-                                 d['variable_read_lengths'], d['dna_bytes_per_row'], d['quality_bytes_per_row'],
-                                 d['dna_max'], hs.max_record_bytes, avg_record_bytes=fastq_bytes // max(nreads, 1))
-        return d, p
-
-    def step(timed):
-        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-        spec = None
-        guess = None
-        census = None
-        queued = None
-        st = None
-        ls_async = None
-        fq = None
-        if not args.multi_pass:
-            # the census kernel is queued first, its closing scan right behind it (the line count stays on the device); the guess
-            # (census / index / statistics of the shard's first 4 MB: small kernels, a read-back, the decisions on the host) runs
-            # meanwhile on a second stream; the record index and the pack + statistics kernel are then queued behind the census
-            # with the count taken on the device -- the host reads it after everything has been queued (no mid-step round trip)
-            st_q = ops.stats_new(ctx)                                    # (initialised before the census: off the critical path)
-            census = ops.ChunkedCensus(ctx, d_buf)
-            census.chunk(0, fastq_bytes)
-            census.end_async()
-            g = ops.head_guess(side, d_buf, notricks=notricks, head_bytes=ops.HEAD_BYTES_SMALL, head_reads=ops.HEAD_READS_INDEXED)
-            if g is not None:
-                guess, rpb = g
-                cap_reads = int(fastq_bytes * rpb * 1.02) + 1024
-                guess.avg_record_bytes = int(1.0 / rpb)                     # tile sizing hint: the head's own records
-                ls_cap = ls_async = ops.index_lines_async(ctx, d_buf, 4 * cap_reads)
-                if qname_in_step:
-                    # the QNAME passes ride in the pack kernel: layout guessed on the device from a sample of the reads (queued here,
-                    # behind the index), verified on every read while the fields are parsed; distinct counts queued behind it
-                    fq = ops.FusedQname(ctx, cap_reads)
-                    ops.qname_guess_async(ctx, d_buf, ls_cap, fq)
-                e0.record()
-                sp = ops.pack_stats_async(ctx, d_buf, ls_cap, cap_reads, guess, st=st_q, fq=fq)
-                e1.record()
-                if sp is not None and fq is not None: ops.qname_fused_finish(ctx, fq)
-                if sp is not None:
-                    # one rank: the statistics' read-back is queued (and waited for) first, the line count is there by then
-                    queued = (ls_cap, sp, None if use_dist else fetch(sp[3]))
-        hs = None
-        if census is not None:
-            nlines, ok = census.wait()
-            good = queued is not None and ok and nlines % 4 == 0 and nlines // 4 <= cap_reads
-            if not ok: nlines = ops.count_lines(ctx, d_buf)         # a tile's newline list overflowed: the bitmap form
-            nreads = nlines // 4
-            if good:
-                ls = queued[0][:nlines + 1]
-                dq = queued[1]
-                spec = (dq[0][:nreads * guess.dna_bytes_per_row], dq[1][:nreads * guess.quality_bytes_per_row], dq[2], dq[3])
-                st = dq[3]
-            elif queued is not None:                              # the queued form does not hold for this shard: the plain index, and
-                ls = ops.index_lines(ctx, d_buf, nlines)           # statistics flagged incomplete, so that EVERY rank redoes them below
-                st = queued[1][3]
-                st[ops.STATS_DTYPE.fields['reserved'][1]] = 1     # uq_stats.reserved: statistics incomplete
-                queued = None
-            if st is not None:
-                hs = queued[2] if (queued is not None and queued[2] is not None) else fetch(st)     # N > 1: the all-reduce of the statistics
-        if hs is None:
-            if census is None: nlines = ops.count_lines(ctx, d_buf)
-            if census is not None and ls_async is not None and ok and nlines <= 4 * cap_reads:
-                ls = ls_async[:nlines + 1]                        # the queued index holds (there is no fused pack kernel for this alphabet)
-            else:
-                ls = ops.index_lines(ctx, d_buf, nlines)          # record index
-            nreads = nlines // 4
-            st = ops.stats_new(ctx)
-            ops.stats_accumulate(ctx, st, d_buf, ls, 0, nreads)
-            hs = fetch(st)                                            # N > 1: the all-reduce of the statistics
-        if hs.incomplete:                                         # the speculative pass met something outside its guess
-            spec = None
-            st = ops.stats_new(ctx)
-            ops.stats_accumulate(ctx, st, d_buf, ls, 0, nreads)
-            hs = fetch(st)
-        if hs.bad_plus is not None or hs.bad_len is not None:
-            raise RuntimeError('malformed FASTQ record')
-        d, p = decide_and_params(hs, nreads)
-        if spec is not None and ops.same_pack_params(p, guess):
-            dna, qual, bad = spec[:3]
-            kernel = 'pack_tile_kernel<STATS> (pack + pass-1 statistics in one read of the stream)'
+    def run_encode(n, steps, warmup, compare_exact):
+        """`steps` timed steps of the hot path over n reads per GPU (W untimed first) -> everything the JSON needs."""
+        if args.workload == 'cfg2':
+            spec = synth.Spec(SEED, args.length)
         else:
+            spec = synth.Spec(20261003 + 5, (36, 301), n_rate=1)
+        d_buf = ops.synth_fastq(ctx, spec, rank * n, n)           # resident in HBM before timing
+        fastq_bytes = d_buf.numel()
+        ctx.sync()
+        pack_events = []
+        state = {}
+
+        def decide_and_params(hs, nreads):
+            d = host_decide(hs, notricks=notricks)
+            p = ops.make_pack_params(d['bases'], d['qualities'], d['N_qual'], d['bits_per_base'], d['bits_per_quality'],
+                                     d['variable_read_lengths'], d['dna_bytes_per_row'], d['quality_bytes_per_row'],
+                                     d['dna_max'], hs.max_record_bytes, avg_record_bytes=fastq_bytes // max(nreads, 1))
+            return d, p
+
+        def step(timed):
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-            e0.record()
-            dna, qual, bad = ops.pack(ctx, d_buf, ls, 0, nreads, p)
-            e1.record()
-            kernel = 'pack_tile_kernel'
-        # the QNAME analysis (uq.py:394-444, 555-678, 717-736): from the pack kernel's QNAME phase when every read conformed to the
-        # guessed layout, else by the exact kernels (layout reductions, tokeniser) -- inside the timed step either way
-        qpath, qres = None, None
-        if qname_in_step:
+            spec = None
+            guess = None
+            census = None
+            queued = None
+            st = None
+            ls_async = None
+            fq = None
+            if not args.multi_pass:
+                # the census kernel is queued first, its closing scan right behind it (the line count stays on the device); the guess
+                # (census / index / statistics of the shard's first 4 MB: small kernels, a read-back, the decisions on the host) runs
+                # meanwhile on a second stream; the record index and the pack + statistics kernel are then queued behind the census
+                # with the count taken on the device -- the host reads it after everything has been queued (no mid-step round trip)
+                st_q = ops.stats_new(ctx)                                    # (initialised before the census: off the critical path)
+                census = ops.ChunkedCensus(ctx, d_buf)
+                census.chunk(0, fastq_bytes)
+                census.end_async()
+                g = ops.head_guess(side, d_buf, notricks=notricks, head_bytes=ops.HEAD_BYTES_SMALL, head_reads=ops.HEAD_READS_INDEXED)
+                if g is not None:
+                    guess, rpb = g
+                    cap_reads = int(fastq_bytes * rpb * 1.02) + 1024
+                    guess.avg_record_bytes = int(1.0 / rpb)                     # tile sizing hint: the head's own records
+                    ls_cap = ls_async = ops.index_lines_async(ctx, d_buf, 4 * cap_reads)
+                    if qname_in_step:
+                        # the QNAME passes ride in the pack kernel: layout guessed on the device from a sample of the reads (queued here,
+                        # behind the index), verified on every read while the fields are parsed; distinct counts queued behind it
+                        fq = ops.FusedQname(ctx, cap_reads)
+                        ops.qname_guess_async(ctx, d_buf, ls_cap, fq)
+                    e0.record()
+                    sp = ops.pack_stats_async(ctx, d_buf, ls_cap, cap_reads, guess, st=st_q, fq=fq)
+                    e1.record()
+                    if sp is not None and fq is not None: ops.qname_fused_finish(ctx, fq)
+                    if sp is not None:
+                        # one rank: the statistics' read-back is queued (and waited for) first, the line count is there by then
+                        queued = (ls_cap, sp, None if use_dist else fetch(sp[3]))
+            hs = None
+            if census is not None:
+                nlines, ok = census.wait()
+                good = queued is not None and ok and nlines % 4 == 0 and nlines // 4 <= cap_reads
+                if not ok: nlines = ops.count_lines(ctx, d_buf)         # a tile's newline list overflowed: the bitmap form
+                nreads = nlines // 4
+                if good:
+                    ls = queued[0][:nlines + 1]
+                    dq = queued[1]
+                    spec = (dq[0][:nreads * guess.dna_bytes_per_row], dq[1][:nreads * guess.quality_bytes_per_row], dq[2], dq[3])
+                    st = dq[3]
+                elif queued is not None:                              # the queued form does not hold for this shard: the plain index, and
+                    ls = ops.index_lines(ctx, d_buf, nlines)           # statistics flagged incomplete, so that EVERY rank redoes them below
+                    st = queued[1][3]
+                    st[ops.STATS_DTYPE.fields['reserved'][1]] = 1     # uq_stats.reserved: statistics incomplete
+                    queued = None
+                if st is not None:
+                    hs = queued[2] if (queued is not None and queued[2] is not None) else fetch(st)     # N > 1: the all-reduce of the statistics
+            if hs is None:
+                if census is None: nlines = ops.count_lines(ctx, d_buf)
+                if census is not None and ls_async is not None and ok and nlines <= 4 * cap_reads:
+                    ls = ls_async[:nlines + 1]                        # the queued index holds (there is no fused pack kernel for this alphabet)
+                else:
+                    ls = ops.index_lines(ctx, d_buf, nlines)          # record index
+                nreads = nlines // 4
+                st = ops.stats_new(ctx)
+                ops.stats_accumulate(ctx, st, d_buf, ls, 0, nreads)
+                hs = fetch(st)                                            # N > 1: the all-reduce of the statistics
+            if hs.incomplete:                                         # the speculative pass met something outside its guess
+                spec = None
+                st = ops.stats_new(ctx)
+                ops.stats_accumulate(ctx, st, d_buf, ls, 0, nreads)
+                hs = fetch(st)
+            if hs.bad_plus is not None or hs.bad_len is not None:
+                raise RuntimeError('malformed FASTQ record')
+            d, p = decide_and_params(hs, nreads)
+            if spec is not None and ops.same_pack_params(p, guess):
+                dna, qual, bad = spec[:3]
+                kernel = 'pack_tile_kernel<STATS> (pack + pass-1 statistics in one read of the stream)'
+            else:
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                dna, qual, bad = ops.pack(ctx, d_buf, ls, 0, nreads, p)
+                e1.record()
+                kernel = 'pack_tile_kernel'
+            # the QNAME analysis (uq.py:394-444, 555-678, 717-736): from the pack kernel's QNAME phase when every read conformed to the
+            # guessed layout, else by the exact kernels (layout reductions, tokeniser) -- inside the timed step either way
+            qpath, qres = None, None
+            if qname_in_step:
+                from uq_amd import qname_device
+                qres = qname_device.analyse_fused(ctx, fq, nreads) if (fq is not None and spec is not None) else None
+                qpath = 'fused into the pack kernel'
+                if qres is None:
+                    qres = qname_device.analyse_device(ctx, d_buf, ls, nreads)
+                    qpath = 'exact kernels (layout, tokeniser)'
+                if qres is None: raise RuntimeError('the synthetic QNAMEs are outside the device subset')
+            if timed: pack_events.append((e0, e1, kernel))
+            state.update(dna=dna, qual=qual, bad=bad, d=d, nreads=nreads, ls=ls, params=p, qname=qres, qname_path=qpath)
+
+        for _ in range(warmup):
+            step(False)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(True)
+        fence()
+        dt = time.perf_counter() - t0
+        total_bytes, total_reads = fastq_bytes, state['nreads']
+        if use_dist:
+            t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+            tot = torch.tensor([fastq_bytes, state['nreads']], dtype=torch.int64, device=red_dev)   # shards differ by a few bytes
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            total_bytes, total_reads = int(tot[0].item()), int(tot[1].item())
+        # For comparison, outside the timed region: the exact QNAME kernels (two traversals of the QNAME lines) on the same shard.
+        qname_exact_ms = None
+        if compare_exact and not use_dist:
             from uq_amd import qname_device
-            qres = qname_device.analyse_fused(ctx, fq, nreads) if (fq is not None and spec is not None) else None
-            qpath = 'fused into the pack kernel'
-            if qres is None:
-                qres = qname_device.analyse_device(ctx, d_buf, ls, nreads)
-                qpath = 'exact kernels (layout, tokeniser)'
-            if qres is None: raise RuntimeError('the synthetic QNAMEs are outside the device subset')
-        if timed: pack_events.append((e0, e1, kernel))
-        state.update(dna=dna, qual=qual, bad=bad, d=d, nreads=nreads, ls=ls, params=p, qname=qres, qname_path=qpath)
+            best = None
+            for _ in range(3):
+                q0 = time.perf_counter()
+                qex = qname_device.analyse_device(ctx, d_buf, state['ls'], state['nreads'])
+                torch.cuda.synchronize()
+                q1 = time.perf_counter()
+                best = (q1 - q0) if best is None or (q1 - q0) < best else best
+                if qex is None: best = None; break
+            qname_exact_ms = None if best is None else best * 1e3
+            if qname_in_step and qex is not None:
+                # the step's columns against the exact path's: same layout, same column descriptions, same arrays
+                a, b = state['qname'], qex
+                if a[:4] != b[:4] or not all(torch.equal(x, y) for x, y in zip(a[4], b[4])):
+                    raise RuntimeError('parity failure: the fused QNAME pass differs from the exact kernels')
+        if state['bad'] is not None and ops.bad_index(state['bad']) is not None:
+            raise RuntimeError('pack reported an uncoded symbol at read %d' % ops.bad_index(state['bad']))
+        d, nreads = state['d'], state['nreads']
+        kernel = pack_events[-1][2]
+        pack_ms = float(np.mean([a.elapsed_time(b) for a, b, k in pack_events if k == kernel]))
+        # SURVEY.md 8d bytes per read: the record read once + both rows written (+ the QNAME columns when the kernel writes them:
+        # their final width, what an ideal pass would store)
+        qcol_bytes = sum(x.element_size() for x in state['qname'][4]) if (state.get('qname') and 'fused' in (state.get('qname_path') or '')) else 0
+        algo_bytes = fastq_bytes + nreads * (d['dna_bytes_per_row'] + d['quality_bytes_per_row'] + qcol_bytes)
+        step_bytes = fastq_bytes + nreads * (d['dna_bytes_per_row'] + d['quality_bytes_per_row'] + 32 + qcol_bytes)
+        return dict(d_buf=d_buf, fastq_bytes=fastq_bytes, state=state, dt_step=dt / steps, total_bytes=total_bytes, total_reads=total_reads,
+                    qname_exact_ms=qname_exact_ms, kernel=kernel, pack_ms=pack_ms, algo_bytes=algo_bytes, step_bytes=step_bytes, d=d, nreads=nreads)
 
-    for _ in range(args.warmup):
-        step(False)
+    def roofline_of(m, traffic=None):
+        achieved = m['algo_bytes'] / 1e9 / (m['pack_ms'] / 1e3)
+        return {'bound': 'hbm', 'kernel': m['kernel'], 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic, 'algorithmic_bytes_per_launch': int(m['algo_bytes']),
+                'avg_launch_ms': round(m['pack_ms'], 4)}
 
-    def fence():
-        if use_dist: dist.barrier()
-        torch.cuda.synchronize()
-
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    fence()
-    dt = time.perf_counter() - t0
-    total_bytes, total_reads = fastq_bytes, None
-    if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        tot = torch.tensor([fastq_bytes, state['nreads']], dtype=torch.int64, device=red_dev)   # shards differ by a few bytes
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        total_bytes, total_reads = int(tot[0].item()), int(tot[1].item())
-
-    # For comparison, outside the timed region: the exact QNAME kernels (two traversals of the QNAME lines) on the same shard.
-    qname_exact_ms = None
-    if not use_dist:
-        from uq_amd import qname_device
-        best = None
-        for _ in range(3):
-            q0 = time.perf_counter()
-            qex = qname_device.analyse_device(ctx, d_buf, state['ls'], state['nreads'])
-            torch.cuda.synchronize()
-            q1 = time.perf_counter()
-            best = (q1 - q0) if best is None or (q1 - q0) < best else best
-            if qex is None: best = None; break
-        qname_exact_ms = None if best is None else best * 1e3
-        if qname_in_step and qex is not None:
-            # the step's columns against the exact path's: same layout, same column descriptions, same arrays
-            a, b = state['qname'], qex
-            if a[:4] != b[:4] or not all(torch.equal(x, y) for x, y in zip(a[4], b[4])):
-                raise RuntimeError('parity failure: the fused QNAME pass differs from the exact kernels')
-    # ---- N > 1: the north_star's scaling claim is about the global --sort (BASELINE configs[3]: 200 M x 150 bp over 8 GPUs,
-    # `--sort QUAL --raw DNA QUAL QNAME`), whose data-path exchange the weak-scaling step above never touches.  Timed beside it:
-    # sample sort of the QUAL table over the ranks (local sort -> splitters -> all-to-all(v) of rows + file-wide indices by key
-    # range -> stable local sort of the received runs) and the DNA table moved into that order (requests to the owners, rows
-    # back): uq_amd.dist.global_sort_rows + dist_gather_rows, the table movements of that mix (QNAME columns: the same gather
-    # on 8-byte rows, not repeated).  Reported as `sort_leg`; `value` stays the weak-scaling step.
-    sort_leg = None
-    if use_dist and args.sort_reads > 0 and args.workload == 'cfg2':
-        from uq_amd import dist as uqdist
-        be = uqdist.HipRows(ctx)
-        ns = args.sort_reads
-        spec3 = synth.Spec(20261003 + 4, args.length, dup='qual', dup_templates=max(1, ns * world // 16))
-        buf3 = ops.synth_fastq(ctx, spec3, rank * ns, ns)
-        nl3 = ops.count_lines(ctx, buf3)
-        ls3 = ops.index_lines(ctx, buf3, nl3)
-        st3 = ops.stats_new(ctx)
-        ops.stats_accumulate(ctx, st3, buf3, ls3, 0, ns)
-        hs3 = fetch(st3)
-        d3 = host_decide(hs3)
-        p3 = ops.make_pack_params(d3['bases'], d3['qualities'], d3['N_qual'], d3['bits_per_base'], d3['bits_per_quality'], d3['variable_read_lengths'],
-                                  d3['dna_bytes_per_row'], d3['quality_bytes_per_row'], d3['dna_max'], hs3.max_record_bytes)
-        dna3, qual3, _ = ops.pack(ctx, buf3, ls3, 0, ns, p3)
-        del buf3, ls3
-        Cd3, Cq3 = d3['dna_bytes_per_row'], d3['quality_bytes_per_row']
-        starts = [r * ns for r in range(world + 1)]
-
-        def sort_step():
-            gs = uqdist.global_sort_rows(be, qual3, ns, Cq3, rank * ns)
-            dg = uqdist.dist_gather_rows(be, dna3, ns, Cd3, starts, gs['gidx'])
-            return gs, dg
-        sort_step()
-        fence()
-        ts = time.perf_counter()
-        K3 = 3
-        for _ in range(K3): gs, dg = sort_step()
-        fence()
-        dts = time.perf_counter() - ts
-        t3 = torch.tensor([dts], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t3, op=dist.ReduceOp.MAX)
-        dts = float(t3.item()) / K3
-        rows_here = torch.tensor([gs['rows']], dtype=torch.int64, device=red_dev)
-        dist.all_reduce(rows_here, op=dist.ReduceOp.MAX)
-        sort_leg = {'workload': 'BASELINE configs[3] shape: %d x %dbp per GPU, 10 %% of the reads copy one of N/16 QUAL templates; global --sort QUAL: '
-                                'sample sort of the %d-byte QUAL rows over %d rank(s) + the %d-byte DNA rows moved into that order'
-                                % (ns, args.length, Cq3, world, Cd3),
-                    'reads_per_gpu': ns, 'ms': round(dts * 1e3, 3), 'reads_per_s': round(ns * world / dts, 1),
-                    'largest_shard_after_exchange': int(rows_here.item()),
-                    'exchanged_bytes_per_rank': int(ns * (Cq3 + 8 + 8 + Cd3) * (world - 1) / world)}
-        del dna3, qual3, gs, dg
-    if state['bad'] is not None and ops.bad_index(state['bad']) is not None:
-        raise RuntimeError('pack reported an uncoded symbol at read %d' % ops.bad_index(state['bad']))
-    d = state['d']
-    nreads = state['nreads']
-    kernel = pack_events[-1][2]
-    two_reads = kernel.startswith('pack_tile_kernel<STATS>')
-    pack_ms = float(np.mean([a.elapsed_time(b) for a, b, k in pack_events if k == kernel]))
-    # SURVEY.md 8d bytes per read: the record read once + both rows written
-    algo_bytes = fastq_bytes + nreads * (d['dna_bytes_per_row'] + d['quality_bytes_per_row'])
-    achieved = algo_bytes / 1e9 / (pack_ms / 1e3)
+    m = run_encode(args.reads, args.steps, args.warmup, True)
+    state, d, nreads, fastq_bytes, kernel = m['state'], m['d'], m['nreads'], m['fastq_bytes'], m['kernel']
+    two_reads = kernel.startswith('pack_tile_kernel<STATS')
 
     traffic = None
     tpath = os.path.join(HERE, 'profiles', 'pack_stats_traffic.json' if two_reads else 'pack_traffic.json')
@@ -374,7 +339,8 @@ def main():
             # quoted while the kernel's source is byte for byte the one it was measured on
             import hashlib
             same_kernel = hashlib.sha256(open(os.path.join(HERE, tj['kernel_source']), 'rb').read()).hexdigest() == tj['kernel_source_sha256']
-            if args.workload == 'cfg2' and tj.get('reads') == nreads and tj.get('length') == args.length and same_kernel:
+            if args.workload == 'cfg2' and tj.get('reads') == nreads and tj.get('length') == args.length and same_kernel and \
+               tj.get('kernel_form', '') == ('qname' if qname_in_step else 'plain'):
                 traffic = tj.get('hbm_bytes_per_launch')
         except Exception:
             traffic = None
@@ -385,35 +351,31 @@ def main():
     qmode = ' + QNAME layout / typing / column encoding (%s)' % state.get('qname_path') if qname_in_step else ' (QNAME passes not in the step)'
     result = {
         'metric': 'FASTQ encode MB/s (150bp synthetic; bit-exact tables vs reference)',
-        'value': round(total_bytes / 1e6 / (dt / args.steps), 1), 'unit': 'MB/s',
+        'value': round(m['total_bytes'] / 1e6 / m['dt_step'], 1), 'unit': 'MB/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+        'ms_per_step': round(m['dt_step'] * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic',
-        'reads_per_s': round((total_reads if total_reads is not None else nreads) / (dt / args.steps), 1),
+        'reads_per_s': round(m['total_reads'] / m['dt_step'], 1),
         'qname': {'in_step': bool(qname_in_step), 'path': state.get('qname_path'),
-                  'exact_kernels_ms': None if qname_exact_ms is None else round(qname_exact_ms, 3)},
+                  'exact_kernels_ms': None if m['qname_exact_ms'] is None else round(m['qname_exact_ms'], 3)},
         'config': {'workload': ('BASELINE configs[1]: %d x %dbp synth-v1 FASTQ per GPU (%.3f GB), --sort None --raw DNA QUAL QNAME '
                                 '--pattern 0.1 0.1; step = census + index + stats + decisions + %d-bit DNA / %d-bit QUAL pack%s%s'
                                 % (nreads, args.length, fastq_bytes / 1e9, d['bits_per_base'], d['bits_per_quality'], mode, qmode)) if args.workload == 'cfg2' else
                                ('BASELINE configs[4] (%s): %d x 36-301bp synth-v1 FASTQ with 1%% N per GPU (%.3f GB); step = census + index + '
-                                'stats + decisions + %d-bit DNA / %d-bit QUAL variable-length pack%s'
-                                % (args.workload, nreads, fastq_bytes / 1e9, d['bits_per_base'], d['bits_per_quality'], mode)),
-                   'reads_per_gpu': nreads, 'read_length': args.length, 'fastq_bytes_per_gpu': fastq_bytes,
+                                'stats + decisions + %d-bit DNA / %d-bit QUAL variable-length pack%s%s'
+                                % (args.workload, nreads, fastq_bytes / 1e9, d['bits_per_base'], d['bits_per_quality'], mode, qmode)),
+                   'reads_per_gpu': nreads, 'read_length': args.length if args.workload == 'cfg2' else '36-301', 'fastq_bytes_per_gpu': fastq_bytes,
                    'sharding': 'record-parallel, %d shard(s)' % world},
-        'step_roofline': {'algorithmic_bytes_per_step': int(fastq_bytes + nreads * (d['dna_bytes_per_row'] + d['quality_bytes_per_row'] + 32)),
-                          'note': 'one ideal pass: the records read once, both rows and the 32 B of line offsets written',
-                          'frac_of_8TBps': round((fastq_bytes + nreads * (d['dna_bytes_per_row'] + d['quality_bytes_per_row'] + 32)) / 1e9
-                                                 / (dt / args.steps) / HBM_PEAK_GBS, 4)},
-        'roofline': {'bound': 'hbm', 'kernel': kernel, 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
-                     'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
-                     'algorithmic_bytes_per_launch': int(algo_bytes), 'avg_launch_ms': round(pack_ms, 4)},
+        'step_roofline': {'algorithmic_bytes_per_step': int(m['step_bytes']),
+                          'note': 'one ideal pass: the records read once; both rows, the 32 B of line offsets and the QNAME columns written',
+                          'frac_of_8TBps': round(m['step_bytes'] / 1e9 / m['dt_step'] / HBM_PEAK_GBS, 4)},
+        'roofline': roofline_of(m, traffic),
     }
 
-    if sort_leg is not None: result['sort_leg'] = sort_leg
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         ns = min(args.cpu_sample, nreads)
         end = int(state['ls'][4 * ns].item())
-        sample = bytes(d_buf[:end].cpu().numpy().tobytes())
+        sample = bytes(m['d_buf'][:end].cpu().numpy().tobytes())
         cb, (rd, rq) = cpu_baseline(sample, ns, d)
         gd = state['dna'][:ns * d['dna_bytes_per_row']].cpu().numpy().reshape(ns, -1)
         gq = state['qual'][:ns * d['quality_bytes_per_row']].cpu().numpy().reshape(ns, -1)
@@ -421,10 +383,108 @@ def main():
         if not cb['gpu_rows_match_oracle_on_sample']:
             raise RuntimeError('parity failure: GPU rows differ from the oracle on the CPU sample')
         result['cpu_baseline'] = cb
+    del m, state
+    torch.cuda.empty_cache()
+
+    # ---- the north_star's single-GPU size in the driver's own record: the same step over 200 M x 150 bp (67.9 GB of FASTQ in HBM)
+    if world == 1 and not use_dist and args.workload == 'cfg2' and args.north_star_reads > 0 and args.north_star_reads != args.reads:
+        big = run_encode(args.north_star_reads, 3, 2, False)       # (two warm-up steps: both generations of the 30 GB of tables are in the allocator's cache)
+        result['north_star_200M'] = {
+            'workload': 'the same step over %d x %dbp (%.1f GB of FASTQ resident in HBM), 3 timed steps after 2 warm-up steps' % (big['nreads'], args.length, big['fastq_bytes'] / 1e9),
+            'ms_per_step': round(big['dt_step'] * 1e3, 3), 'value': round(big['total_bytes'] / 1e6 / big['dt_step'], 1), 'unit': 'MB/s',
+            'reads_per_s': round(big['total_reads'] / big['dt_step'], 1), 'qname_path': big['state'].get('qname_path'),
+            'step_frac_of_8TBps': round(big['step_bytes'] / 1e9 / big['dt_step'] / HBM_PEAK_GBS, 4), 'roofline': roofline_of(big)}
+        if 'cpu_baseline' in result:
+            result['north_star_200M']['times_cpu_baseline'] = round(result['north_star_200M']['value'] / result['cpu_baseline']['value'], 1)
+        del big
+        torch.cuda.empty_cache()
+
+    # ---- the global --sort legs (the north_star's scaling claim: ">= 6x further at 8 GPUs for --sort DNA"; BASELINE configs[3] is
+    # `--sort QUAL --raw DNA QUAL QNAME` over 8 GPUs).  STRONG scaling: args.sort_reads reads over all N GPUs (200 M / N each), so
+    # that the N = 1 and N = 8 lines divide directly.  Table movements of the two mixes, through uq_amd.dist (N = 1: the same calls
+    # without an exchange):
+    #   sort_qual_raw   sample sort of the QUAL rows + the DNA rows moved into that order                 (uq.py:773-777 twice)
+    #   sort_dna_keyed  sample sort of the DNA rows + unique / group ids; the same for the QUAL rows + their ids sent back to file
+    #                   order and fetched in the DNA order                                                (uq.py:784-798 twice)
+    if args.sort_reads > 0 and args.workload == 'cfg2':
+        result['sort_leg'] = sort_legs(ctx, args, rank, world, use_dist, fence, fetch, red_dev)
     if rank == 0:
         print(json.dumps(result), file=json_out, flush=True)
     if use_dist:
         dist.destroy_process_group()
+
+
+def sort_legs(ctx, args, rank, world, use_dist, fence, fetch, red_dev):
+    import torch
+    import torch.distributed as dist
+    from uq_amd import dist as uqdist, ops, synth
+    be = uqdist.HipRows(ctx)
+    total = args.sort_reads
+    lo, hi = uqdist.shard_range(total, rank, world)
+    ns = hi - lo
+    spec3 = synth.Spec(20261003 + 4, args.length, dup='both', dup_templates=max(1, total // 16))
+    buf3 = ops.synth_fastq(ctx, spec3, lo, ns)
+    nl3 = ops.count_lines(ctx, buf3)
+    ls3 = ops.index_lines(ctx, buf3, nl3)
+    st3 = ops.stats_new(ctx)
+    ops.stats_accumulate(ctx, st3, buf3, ls3, 0, ns)
+    hs3 = fetch(st3)
+    d3 = host_decide(hs3)
+    p3 = ops.make_pack_params(d3['bases'], d3['qualities'], d3['N_qual'], d3['bits_per_base'], d3['bits_per_quality'], d3['variable_read_lengths'],
+                              d3['dna_bytes_per_row'], d3['quality_bytes_per_row'], d3['dna_max'], hs3.max_record_bytes)
+    dna3, qual3, _ = ops.pack(ctx, buf3, ls3, 0, ns, p3)
+    del buf3, ls3
+    torch.cuda.empty_cache()
+    Cd3, Cq3 = d3['dna_bytes_per_row'], d3['quality_bytes_per_row']
+    starts = [uqdist.shard_range(total, r, world)[0] for r in range(world)] + [total]
+    t = torch
+
+    def sort_qual_raw():
+        gs = uqdist.global_sort_rows(be, qual3, ns, Cq3, lo, total_rows=total)
+        dg = uqdist.dist_gather_rows(be, dna3, ns, Cd3, starts, gs['gidx'])
+        return gs['rows'], (gs, dg)
+
+    def group_ids(gs, cols):
+        m = gs['rows']
+        if not m: return t.empty(0, dtype=t.int32, device=ctx.device)
+        _, _, skey, uniq, nu = ops.unique_rows(ctx, gs['table'], m, cols, want_key=False)
+        return skey                                          # (the per-rank id offsets are a handful of integers: dist_encode._unique)
+
+    def sort_dna_keyed():
+        gd = uqdist.global_sort_rows(be, dna3, ns, Cd3, lo, total_rows=total)
+        kd = group_ids(gd, Cd3)
+        gq = uqdist.global_sort_rows(be, qual3, ns, Cq3, lo, total_rows=total)
+        kq = group_ids(gq, Cq3)
+        in_file_order = uqdist.dist_scatter_rows(be, kq.view(t.uint8), 4, starts, gq['gidx'])
+        kq_sorted = uqdist.dist_gather_rows(be, in_file_order, ns, 4, starts, gd['gidx'])
+        return gd['rows'], (gd, kd, gq, kq_sorted)
+
+    out = {'workload': 'BASELINE configs[2] / [3] shape: %d x %dbp over %d GPU(s) (%d per GPU, strong scaling), 10 %% of the reads copy one of N/16 '
+                       'templates (bases and qualities); rows: DNA %d B, QUAL %d B' % (total, args.length, world, ns, Cd3, Cq3),
+           'reads_total': total, 'reads_per_gpu': ns}
+    for name, fn, moved in (('sort_qual_raw', sort_qual_raw, Cq3 + 8 + 8 + Cd3), ('sort_dna_keyed', sort_dna_keyed, Cd3 + 8 + Cq3 + 8 + 3 * (4 + 8))):
+        rows, keep = fn()
+        del keep
+        fence()
+        ts = time.perf_counter()
+        K3 = 2
+        for _ in range(K3):
+            rows, keep = fn()
+            del keep
+        fence()
+        dts = (time.perf_counter() - ts) / K3
+        biggest = rows
+        if use_dist:
+            t3 = torch.tensor([dts], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(t3, op=dist.ReduceOp.MAX)
+            dts = float(t3.item())
+            r3 = torch.tensor([rows], dtype=torch.int64, device=red_dev)
+            dist.all_reduce(r3, op=dist.ReduceOp.MAX)
+            biggest = int(r3.item())
+        out[name] = {'ms': round(dts * 1e3, 3), 'reads_per_s': round(total / dts, 1), 'largest_shard_after_exchange': int(biggest),
+                     'exchanged_bytes_per_rank': int(ns * moved * (world - 1) / world)}
+        torch.cuda.empty_cache()
+    return out
 
 
 if __name__ == '__main__':
