@@ -213,3 +213,44 @@ def test_200M_x150_single_gpu_encode(ctx):
     s.members = {}
     del text, s, dna, qual, buf
     _free(ctx)
+
+
+def test_configs3_shard_25M_sort_qual_through_the_exchange_code(ctx):
+    """BASELINE configs[3] is 200 M x 150 bp over 8 GPUs, `--sort QUAL --raw DNA QUAL QNAME`: one rank's share is 25 M reads.  That
+    shard, at its real size, through the code the sharded encoder runs (uq_amd.dist.global_sort_rows + dist_gather_rows on HipRows;
+    one rank: no exchange partner on a one-GPU box), 10 % of the reads copying one of N/16 QUAL templates: the order that comes
+    back is THE stable memcmp argsort of the 113-byte QUAL rows and the DNA rows follow it."""
+    from uq_amd import analysis, dist as uqdist
+    t = ctx.torch
+    N = 25_000_000 // SCALE
+    spec = synth.Spec(20261003 + 4, 150, dup='qual', dup_templates=max(1, N // 16))
+    buf = ops.synth_fastq(ctx, spec, 0, N)
+    nl = ops.count_lines(ctx, buf)
+    ls, st = ops.index_and_stats(ctx, buf, nl)
+    hs = ops.stats_fetch(ctx, st)
+    d = analysis.decide_from_stats(hs)
+    p = ops.make_pack_params(d['bases'], d['qualities'], d['N_qual'], d['bits_per_base'], d['bits_per_quality'], d['variable_read_lengths'],
+                             d['dna_bytes_per_row'], d['quality_bytes_per_row'], d['dna_max'], hs.max_record_bytes)
+    dna, qual, bad = ops.pack(ctx, buf, ls, 0, N, p)
+    assert ops.bad_index(bad) is None
+    del buf, ls
+    Cd, Cq = d['dna_bytes_per_row'], d['quality_bytes_per_row']
+    assert (Cd, Cq) == (38, 113)
+    be = uqdist.HipRows(ctx)
+    gs = uqdist.global_sort_rows(be, qual, N, Cq, 0, total_rows=N)
+    assert gs['rows'] == N and gs['offset'] == 0
+    p64, g, same = _check_stable_argsort(t, qual, N, Cq, gs['gidx'].to(t.int32))
+    assert t.equal(gs['table'].view(N, Cq), g)
+    nu = int((~same).sum()) + 1
+    T = max(1, N // 16)
+    expect = 0.9 * N + T * (1 - np.exp(-0.1 * N / T))
+    assert abs(nu - expect) < 0.002 * N + 50, (nu, expect)
+    del g
+    moved = uqdist.dist_gather_rows(be, dna, N, Cd, [0, N], gs['gidx'])
+    for a in range(0, N, 10_000_000):
+        b = min(N, a + 10_000_000)
+        assert t.equal(moved.view(N, Cd)[a:b], dna.view(N, Cd)[p64[a:b]])
+    # ... and back: rows scattered to file order by the same indices give the table again
+    back = uqdist.dist_scatter_rows(be, moved, Cd, [0, N], gs['gidx'])
+    assert t.equal(back, dna)
+    _free(ctx)

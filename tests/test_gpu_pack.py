@@ -575,3 +575,35 @@ def test_pack_three_bit_alphabets(ctx, bases):
     bad_host[at] = ord('Z') if ord('Z') not in bases else ord('X')
     dna, qual, bad = ops.pack(ctx, ctx.to_device(bad_host), ls, 0, n, p)
     assert ops.bad_index(bad) == 1234
+
+
+def test_side_context_allocations_follow_the_discipline(ctx):
+    """SideContext (uq_amd/device.py): what head_guess allocates under scope() belongs to the side stream and what it adopts from the
+    main stream is recorded on it -- two guesses and two whole queued steps back to back, WITHOUT a host wait between them, while
+    the main stream allocates and frees blocks of the same sizes: the guesses and the tables stay those of the plain calls."""
+    from uq_amd.device import SideContext
+    t = ctx.torch
+    side = SideContext(ctx)
+    n = 60_000
+    d_buf = ops.synth_fastq(ctx, synth.Spec(20261009, 100), 0, n)
+    nl = ops.count_lines(ctx, d_buf); ls = ops.index_lines(ctx, d_buf, nl)
+    ref_guess = ops.head_guess_indexed(ctx, d_buf, ls, n)
+    ref = ops.pack_stats(ctx, d_buf, ls, 0, n, ref_guess)
+    ctx.sync()
+    outs = []
+    for it in range(2):
+        st = ops.stats_new(ctx)
+        cen = ops.ChunkedCensus(ctx, d_buf); cen.chunk(0, d_buf.numel()); cen.end_async()
+        junk = [t.empty(512 * 1024, dtype=t.uint8, device=ctx.device).fill_(it) for _ in range(4)]     # main-stream blocks of the sizes the guess uses
+        g, rpb = ops.head_guess(side, d_buf, head_bytes=ops.HEAD_BYTES_SMALL, head_reads=ops.HEAD_READS_INDEXED)
+        del junk
+        assert ops.same_pack_params(g, ref_guess)
+        cap = n + 512
+        ls2 = ops.index_lines_async(ctx, d_buf, 4 * cap)
+        outs.append((cen, ops.pack_stats_async(ctx, d_buf, ls2, cap, g, st=st)))                         # no wait: the next iteration queues behind it
+    for cen, got in outs:
+        nl2, ok = cen.wait() if cen is outs[-1][0] else (nl, True)                                      # (only the last census is still open)
+        assert ok and nl2 == nl
+        assert t.equal(got[0][:n * g.dna_bytes_per_row], ref[0]) and t.equal(got[1][:n * g.quality_bytes_per_row], ref[1])
+        assert np.array_equal(ops.stats_fetch(ctx, got[3]).counts, ops.stats_fetch(ctx, ref[3]).counts)
+    assert side.stream.cuda_stream != ctx.stream.cuda_stream
