@@ -447,7 +447,7 @@ def sort_legs(ctx, args, rank, world, use_dist, fence, fetch, red_dev):
     def group_ids(gs, cols):
         m = gs['rows']
         if not m: return t.empty(0, dtype=t.int32, device=ctx.device)
-        _, _, skey, uniq, nu = ops.unique_rows(ctx, gs['table'], m, cols, want_key=False)
+        skey, uniq, nu = ops.unique_sorted_rows(ctx, gs['table'], m, cols)
         return skey                                          # (the per-rank id offsets are a handful of integers: dist_encode._unique)
 
     def sort_dna_keyed():

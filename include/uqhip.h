@@ -301,6 +301,10 @@ int uq_encode_int(uq_ctx* ctx, const int64_t* d_val, uint64_t n, int64_t sub, in
  * [h_shard_starts[k], h_shard_starts[k + 1]) holds file-wide row d_row_index[j].  uq_index_affine: d_out[j] = d_in[j] + add between
  * uint32 / int64 index arrays.  uq_invert_permutation: d_inv[d_perm[j] - base] = j; *h_bad = UQ_NONE or the lowest j that points
  * outside [0, n). */
+/* unique + group ids (uq.py:786) of a shard that is ALREADY in memcmp order -- what the global sort hands a rank: no sort, one comparison
+ * of neighbouring rows.  d_group[j] = dense rank of row j's value (from 0), d_unique (may be NULL) = the distinct rows in order. */
+int uq_unique_sorted_rows(uq_ctx* ctx, const uint8_t* d_sorted_table, uint64_t rows, uint32_t cols, uint32_t* d_group, uint8_t* d_unique,
+                          uint64_t* h_nunique);
 int uq_partition_rows(uq_ctx* ctx, const uint8_t* d_splitters, uint32_t nsplit, uint32_t cols, const uint8_t* d_table, uint64_t rows,
                       uint64_t row_index_base, uint64_t total_rows, uint8_t* d_dest);
 int uq_owner_of_rows(uq_ctx* ctx, const int64_t* d_row_index, uint64_t n, const int64_t* h_shard_starts, uint32_t world, uint8_t* d_owner);

@@ -130,6 +130,22 @@ def test_unique_rows(ctx, n, C, nd, prefix):
     assert np.array_equal(ctx.to_numpy(nk, O.narrow_key(rkey).dtype), O.narrow_key(rkey))
 
 
+@pytest.mark.parametrize('n,C,nd,prefix', SORT_CASES, ids=lambda v: str(v))
+def test_unique_sorted_rows(ctx, n, C, nd, prefix):
+    """uq_unique_sorted_rows (what a rank runs on the shard the global sort handed it): on a table already in memcmp order the group
+    ids and the distinct rows are numpy.unique's."""
+    rng = np.random.RandomState(n * 5 + C)
+    T = _rows_with_dups(rng, n, C, nd, prefix)
+    T = T[O.argsort_rows(T)]
+    group, uniq, nu = ops.unique_sorted_rows(ctx, _dev(ctx, T.ravel()), n, C)
+    ru, rkey = O.unique_rows(T)
+    assert nu == len(ru)
+    assert np.array_equal(ctx.to_numpy(uniq).reshape(nu, C), ru)
+    assert np.array_equal(ctx.to_numpy(group, np.uint32).astype(np.int64), rkey)
+    g2, none, nu2 = ops.unique_sorted_rows(ctx, _dev(ctx, T.ravel()), n, C, want_unique=False)
+    assert none is None and nu2 == nu and ctx.torch.equal(g2, group)
+
+
 def _rows_in_prefix_groups(rng, n, C, sizes):
     """Rows that tie on their first 6 bytes in groups of the given sizes (the 32-bit round 0 of the sort cannot separate them),
     members differing anywhere behind -- the last byte, the middle, right behind the prefix -- or not at all; shuffled."""

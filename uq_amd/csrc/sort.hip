@@ -479,11 +479,30 @@ __global__ __launch_bounds__(ST) void keys_from_groups2_kernel(const uint8_t* __
         const uint64_t j = j0 + i;
         if (j >= n) break;
         g += hd[i];                              // inclusive count of heads
-        const uint32_t row = perm[j];
+        const uint32_t row = perm ? perm[j] : (uint32_t)j;          // (no perm: the table itself is in sorted order)
         if (key) key[row] = g - 1;
         if (sorted_key) sorted_key[j] = g - 1;
         if (uidx && hd[i]) uidx[g - 1] = row;
     }
+}
+
+// heads of a table that IS sorted: 1 = the row differs from the one in front of it (or is the first), 2 = a duplicate of it.  A lane
+// per row; neighbouring rows differ within their first bytes unless they are equal, so the common case is one 8-byte compare.
+__global__ __launch_bounds__(ST) void adjacent_heads_kernel(const uint8_t* __restrict__ table, uint64_t n, uint32_t C, uint8_t* __restrict__ heads) {
+    const uint64_t j = (uint64_t)blockIdx.x * ST + threadIdx.x;
+    if (j >= n) return;
+    if (j == 0) { heads[0] = 1; return; }
+    const uint8_t* a = table + j * C;
+    const uint8_t* b = a - C;
+    bool same = true;
+    uint32_t i = 0;
+    for (; i + 8 <= C; i += 8) {
+        unsigned long long x, y;
+        __builtin_memcpy(&x, a + i, 8); __builtin_memcpy(&y, b + i, 8);
+        if (x != y) { same = false; break; }
+    }
+    if (same) for (; i < C; ++i) if (a[i] != b[i]) { same = false; break; }
+    heads[j] = same ? 2 : 1;
 }
 
 __global__ void lower_bound_rows_kernel(const uint8_t* __restrict__ table, uint64_t rows, uint32_t C, const uint8_t* __restrict__ probes,
@@ -565,6 +584,39 @@ extern "C" int uq_unique_rows(uq_ctx* ctx, const uint8_t* d_table, uint64_t rows
     UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     *h_nunique = ctx->h_pinned[0];
     if (d_unique) UQ_TRY(uq_gather_rows_internal(ctx, d_table, rows, cols, uidx, 4, *h_nunique, d_unique));
+    return 0;
+}
+
+// unique + group ids of a table that is already in memcmp order (a shard that came out of the global sort): no sort, one
+// streaming comparison of neighbours.  d_group[j] = rank of row j's value (dense, from 0); d_unique (may be null) = the distinct rows.
+extern "C" int uq_unique_sorted_rows(uq_ctx* ctx, const uint8_t* d_sorted_table, uint64_t rows, uint32_t cols, uint32_t* d_group,
+                                     uint8_t* d_unique, uint64_t* h_nunique) {
+    UQ_REQUIRE(ctx && h_nunique && cols >= 1 && (rows == 0 || (d_sorted_table && d_group)), "uq_unique_sorted_rows: null argument");
+    UQ_REQUIRE(rows < (uint64_t(1) << 32), "uq_unique_sorted_rows: more than 2^32-1 rows");
+    *h_nunique = 0;
+    if (rows == 0) return 0;
+    const uint64_t ncb = (rows + CB - 1) / CB;
+    ScratchPlan sp;
+    const size_t o_heads = sp.add(rows), o_f = sp.add(ncb * 4), o_scan = sp.add(ncb * 4), o_uidx = sp.add(d_unique ? rows * 4 : 4), o_tot = sp.add(16);
+    void* scr;
+    UQ_TRY(uq_scratch(ctx, sp.off, &scr));
+    uint8_t* base = (uint8_t*)scr;
+    uint8_t* heads = base + o_heads;
+    uint32_t* f = (uint32_t*)(base + o_f);
+    uint32_t* gscan = (uint32_t*)(base + o_scan);
+    uint32_t* uidx = (uint32_t*)(base + o_uidx);
+    uint64_t* tot = (uint64_t*)(base + o_tot);
+    adjacent_heads_kernel<<<blocks_for(rows), ST, 0, ctx->stream>>>(d_sorted_table, rows, cols, heads);
+    UQ_LAUNCH_CHECK();
+    heads_count_kernel<<<(uint32_t)ncb, ST, 0, ctx->stream>>>(heads, rows, f);
+    UQ_LAUNCH_CHECK();
+    UQ_TRY(uq_scan_exclusive_u32(ctx, f, gscan, ncb, tot));
+    keys_from_groups2_kernel<<<(uint32_t)ncb, ST, 0, ctx->stream>>>(heads, gscan, nullptr, rows, nullptr, d_group, d_unique ? uidx : nullptr);
+    UQ_LAUNCH_CHECK();
+    UQ_TRY(uq_read_back(ctx, ctx->h_pinned, tot, 8));
+    UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    *h_nunique = ctx->h_pinned[0];
+    if (d_unique) UQ_TRY(uq_gather_rows_internal(ctx, d_sorted_table, rows, cols, uidx, 4, *h_nunique, d_unique));
     return 0;
 }
 

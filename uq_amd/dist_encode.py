@@ -193,7 +193,7 @@ class ShardedSession(Session):
         ops, ctx, t = self.ops, self.ctx, self.ctx.torch
         m = gs['rows']
         if m:
-            _, _, skey, uniq, nu = ops.unique_rows(ctx, gs['table'], m, cols, want_key=False)
+            skey, uniq, nu = ops.unique_sorted_rows(ctx, gs['table'], m, cols)       # the shard came out of the sort in order: neighbours only
             edge = bytes(ctx.to_numpy(gs['table'][:cols]).tobytes()) + bytes(ctx.to_numpy(gs['table'][(m - 1) * cols:m * cols]).tobytes())
         else:
             skey, uniq, nu, edge = t.empty(0, dtype=t.int32, device=ctx.device), ctx.empty(0), 0, b''

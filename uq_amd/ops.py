@@ -397,6 +397,17 @@ def unique_rows(ctx, table, rows, cols, want_key=True, want_sorted_key=True, wan
     return perm, key, skey, uniq, nu.value
 
 
+def unique_sorted_rows(ctx, sorted_table, rows, cols, want_unique=True):
+    """unique of a table that is already in memcmp order (uq_unique_sorted_rows): (group id per row i32[rows], unique rows or None, nunique)."""
+    t = ctx.torch
+    group = t.empty(rows, dtype=t.int32, device=ctx.device)
+    uniq = t.empty(rows * cols, dtype=t.uint8, device=ctx.device) if want_unique else None
+    nu = C.c_uint64()
+    call('uq_unique_sorted_rows', ctx.h, _p(sorted_table), rows, cols, _p(group), _p(uniq), C.byref(nu))
+    if uniq is not None: uniq = uniq[:nu.value * cols]
+    return group, uniq, nu.value
+
+
 def key_itemsize(max_key):
     return load().uq_key_itemsize(int(max_key))
 
