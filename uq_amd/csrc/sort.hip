@@ -187,13 +187,14 @@ __global__ __launch_bounds__(ST) void active_count_kernel(const uint8_t* __restr
 }
 // after the 32-bit round 0, in one pass over the sorted keys: the group-head flags (two copies: segment_sort_kernel reads one and
 // writes the other) and the per-block counters of active_count_kernel
-__global__ __launch_bounds__(ST) void heads32_count_kernel(const uint32_t* __restrict__ keys, uint64_t n, uint8_t* __restrict__ heads,
+template <typename K>
+__global__ __launch_bounds__(ST) void heads32_count_kernel(const K* __restrict__ keys, uint64_t n, uint8_t* __restrict__ heads,
                                                            uint8_t* __restrict__ flags, uint32_t* __restrict__ counts) {
     __shared__ uint32_t sa[ST / 64], sh[ST / 64];
     const uint64_t j0 = (uint64_t)blockIdx.x * CB + (uint64_t)threadIdx.x * 4;
-    uint32_t k[6];                                   // keys j0 - 1 .. j0 + 4
+    K k[6];                                          // keys j0 - 1 .. j0 + 4
 #pragma unroll
-    for (int i = 0; i < 6; ++i) { const uint64_t j = j0 + i; k[i] = (j >= 1 && j - 1 < n) ? keys[j - 1] : 0u; }
+    for (int i = 0; i < 6; ++i) { const uint64_t j = j0 + i; k[i] = (j >= 1 && j - 1 < n) ? keys[j - 1] : (K)0; }
     uint32_t a = 0, h = 0, packed = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -372,7 +373,7 @@ int sort_rows_core(uq_ctx* ctx, const uint8_t* table, uint64_t n, uint32_t C, ui
             uint8_t* flags = b + o_heads2;
             const uint64_t ncb0 = (n + CB - 1) / CB;
             uint32_t* bcnt0 = apos;
-            heads32_count_kernel<<<(uint32_t)ncb0, ST, 0, s>>>(alt ? k32b : k32a, n, heads, flags, bcnt0);
+            heads32_count_kernel<uint32_t><<<(uint32_t)ncb0, ST, 0, s>>>(alt ? k32b : k32a, n, heads, flags, bcnt0);
             UQ_LAUNCH_CHECK();
             UQ_TRY(uq_scan_exclusive_u64(ctx, (const uint64_t*)bcnt0, (uint64_t*)bcnt0, ncb0, tot));
             segment_starts_kernel<<<(uint32_t)ncb0, ST, 0, s>>>(heads, (const unsigned long long*)bcnt0, n, pos);
@@ -392,8 +393,30 @@ int sort_rows_core(uq_ctx* ctx, const uint8_t* table, uint64_t n, uint32_t C, ui
         const uint64_t* K = alt ? keysB : keysA;
         const uint32_t* V = alt ? valsB : valsA;
         UQ_CHECK_HIP(hipMemcpyAsync(d_perm, V, n * 4, hipMemcpyDeviceToDevice, s));
-        heads_first_kernel<<<blocks_for(n), ST, 0, s>>>(K, n, heads);
-        UQ_LAUNCH_CHECK();
+        if (C <= 8) {
+            heads_first_kernel<<<blocks_for(n), ST, 0, s>>>(K, n, heads);      // the chunk IS the row: ties are duplicates, nothing to refine
+            UQ_LAUNCH_CHECK();
+        } else {
+            // rows that tie on all 64 bits of chunk 0 are nearly all whole-row duplicates in SHORT groups (a duplicated read, the odd
+            // pair that collides by chance): as after the 32-bit round 0, a lane sorts each group by whole rows on the spot and sets
+            // its final flags -- one pair that differs somewhere behind byte 8 used to send every tied row (a tenth of a 200 M row
+            // QUAL table) through a radix refinement round of fifteen more passes
+            uint8_t* flags = b + o_heads2;
+            const uint64_t ncb0 = (n + CB - 1) / CB;
+            uint32_t* bcnt0 = apos;
+            heads32_count_kernel<uint64_t><<<(uint32_t)ncb0, ST, 0, s>>>(K, n, heads, flags, bcnt0);
+            UQ_LAUNCH_CHECK();
+            UQ_TRY(uq_scan_exclusive_u64(ctx, (const uint64_t*)bcnt0, (uint64_t*)bcnt0, ncb0, tot));
+            segment_starts_kernel<<<(uint32_t)ncb0, ST, 0, s>>>(heads, (const unsigned long long*)bcnt0, n, pos);
+            UQ_LAUNCH_CHECK();
+            UQ_CHECK_HIP(hipMemsetAsync(tot + 3, 0, 8, s));
+            segment_sort_kernel<<<UQ_NUM_CU * 8, ST, 0, s>>>(table, C, d_perm, heads, flags, n, pos, (const unsigned long long*)tot, (uint32_t*)(tot + 3));
+            UQ_LAUNCH_CHECK();
+            heads = flags; out->heads = flags;
+            UQ_TRY(uq_read_back(ctx, ctx->h_pinned, tot + 3, 8));
+            UQ_CHECK_HIP(hipStreamSynchronize(s));
+            if ((uint32_t)ctx->h_pinned[0] == 0) return 0;        // every group settled: the order is final
+        }
     }
 
     // ---- refinement rounds (after a 32-bit round 0 the first one looks at the whole of chunk 0 again)
