@@ -249,6 +249,18 @@ def main():
                 hs = fetch(st)
             if hs.bad_plus is not None or hs.bad_len is not None:
                 raise RuntimeError('malformed FASTQ record')
+            # the QNAME analysis (uq.py:394-444, 555-678, 717-736): from the pack kernel's QNAME phase when every read conformed to the
+            # guessed layout, else by the exact kernels (layout reductions, tokeniser) -- inside the timed step either way.  First: its
+            # column encoders run on the device while the host takes the DNA / QUAL decisions below.
+            qpath, qres = None, None
+            if qname_in_step:
+                from uq_amd import qname_device
+                qres = qname_device.analyse_fused(ctx, fq, nreads) if (fq is not None and spec is not None) else None
+                qpath = 'fused into the pack kernel'
+                if qres is None:
+                    qres = qname_device.analyse_device(ctx, d_buf, ls, nreads)
+                    qpath = 'exact kernels (layout, tokeniser)'
+                if qres is None: raise RuntimeError('the synthetic QNAMEs are outside the device subset')
             d, p = decide_and_params(hs, nreads)
             if spec is not None and ops.same_pack_params(p, guess):
                 dna, qual, bad = spec[:3]
@@ -259,17 +271,6 @@ def main():
                 dna, qual, bad = ops.pack(ctx, d_buf, ls, 0, nreads, p)
                 e1.record()
                 kernel = 'pack_tile_kernel'
-            # the QNAME analysis (uq.py:394-444, 555-678, 717-736): from the pack kernel's QNAME phase when every read conformed to the
-            # guessed layout, else by the exact kernels (layout reductions, tokeniser) -- inside the timed step either way
-            qpath, qres = None, None
-            if qname_in_step:
-                from uq_amd import qname_device
-                qres = qname_device.analyse_fused(ctx, fq, nreads) if (fq is not None and spec is not None) else None
-                qpath = 'fused into the pack kernel'
-                if qres is None:
-                    qres = qname_device.analyse_device(ctx, d_buf, ls, nreads)
-                    qpath = 'exact kernels (layout, tokeniser)'
-                if qres is None: raise RuntimeError('the synthetic QNAMEs are outside the device subset')
             if timed: pack_events.append((e0, e1, kernel))
             state.update(dna=dna, qual=qual, bad=bad, d=d, nreads=nreads, ls=ls, params=p, qname=qres, qname_path=qpath)
 
