@@ -172,9 +172,13 @@ def test_bench_two_ranks_rehearsal():
     r = json.loads(lines[0])
     assert r['n_gpus'] == 2 and r['scaling'] == 'weak' and r['value'] > 0 and r['config']['reads_per_gpu'] == 200000
     assert r['roofline']['bound'] == 'hbm' and 'cpu_baseline' not in r          # the CPU baseline is timed at N = 1 only
-    # the global --sort leg (BASELINE configs[3] shape): sample sort + all-to-all(v) of the QUAL rows, DNA rows moved along
+    assert r['qname']['in_step'] is False                                        # (the QNAME layout belongs to the whole file: N = 1 only)
+    # the global --sort legs, strong-scaled (150 000 reads over the two ranks): sample sort + all-to-all(v) of the QUAL rows with the
+    # DNA rows moved along; and the keyed --sort DNA mix (two sorts, group ids scattered back and fetched in the DNA order)
     sl = r['sort_leg']
-    assert sl['reads_per_gpu'] == 150000 and sl['ms'] > 0 and 150000 <= sl['largest_shard_after_exchange'] <= 200000
+    assert sl['reads_total'] == 150000 and sl['reads_per_gpu'] == 75000
+    for leg in ('sort_qual_raw', 'sort_dna_keyed'):
+        assert sl[leg]['ms'] > 0 and 75000 <= sl[leg]['largest_shard_after_exchange'] <= 100000, sl[leg]
 
 
 def _run_sharded_expect_error(world, inp, out, flags, timeout=120):

@@ -336,13 +336,15 @@ def test_pack_tiles_sized_from_the_average_record(ctx, fused):
     assert np.array_equal(ctx.to_numpy(dna).reshape(n, -1), rd) and np.array_equal(ctx.to_numpy(qual).reshape(n, -1), rq)
 
 
-FUSED_CASES = [('fixed150', 4096 + 37, 150, {}), ('fixed100', 3000, 100, {}), ('var_ntrick', 5000, (36, 301), dict(n_rate=1)),
-               ('short_var', 2000, (1, 12), {})]
+FUSED_CASES = [('fixed150', 4096 + 37, 150, {}, {}), ('fixed100', 3000, 100, {}, {}), ('var_ntrick', 5000, (36, 301), dict(n_rate=1), {}),
+               ('short_var', 2000, (1, 12), {}, {}),
+               # three bits of base (uq.py:479 --notricks keeps N as a fifth base): bins of nine bits, counted pair by pair
+               ('var_notricks_ACGNT', 5000, (36, 301), dict(n_rate=1), dict(notricks=True)), ('fixed_notricks_ACGNT', 3000, 100, dict(n_rate=2), dict(notricks=True))]
 
 
-@pytest.mark.parametrize('name,n,length,kw', FUSED_CASES, ids=[c[0] for c in FUSED_CASES])
-def test_pack_stats_fused(ctx, name, n, length, kw):
-    """uq_pack_stats: with the right guess the tables AND the statistics equal those of the two separate passes."""
+@pytest.mark.parametrize('name,n,length,kw,dk', FUSED_CASES, ids=[c[0] for c in FUSED_CASES])
+def test_pack_stats_fused(ctx, name, n, length, kw, dk):
+    """uq_pack_stats: with the right guess the tables AND the statistics equal those of the two separate passes -- and the oracle's."""
     spec = synth.Spec(S + 6, length, **kw)
     host = synth.fastq_array(spec, n)
     d_buf = ctx.to_device(host)
@@ -350,12 +352,15 @@ def test_pack_stats_fused(ctx, name, n, length, kw):
     st = ops.stats_new(ctx)
     ops.stats_accumulate(ctx, st, d_buf, ls, 0, n)
     hs = ops.stats_fetch(ctx, st)
-    d = _decide_from_stats(hs)
+    ref = oracle_c.stats(host, oracle_c.index_lines(host), 0, n)
+    assert np.array_equal(hs.counts, ref['counts'])
+    d = _decide_from_stats(hs, **dk)
+    if dk.get('notricks'): assert d['bits_per_base'] == 3 and d['bases'] == 'ACGNT'
     p = ops.make_pack_params(d['bases'], d['qualities'], d['N_qual'], d['bits_per_base'], d['bits_per_quality'], d['variable_read_lengths'],
                              d['dna_bytes_per_row'], d['quality_bytes_per_row'], d['dna_max'], hs.max_record_bytes)
     ref_d, ref_q, bad = ops.pack(ctx, d_buf, ls, 0, n, p)
     res = ops.pack_stats(ctx, d_buf, ls, 0, n, p)
-    assert res is not None, 'this geometry (2-bit A/C/G/T, contiguous qualities) has a fused kernel'
+    assert res is not None, 'this geometry (2- or 3-bit bases, contiguous qualities) has a fused kernel'
     dna, qual, bad2, st2 = res
     hs2 = ops.stats_fetch(ctx, st2)
     assert not hs2.incomplete
@@ -397,9 +402,18 @@ def test_pack_stats_wrong_guesses(ctx):
     hs2 = ops.stats_fetch(ctx, res[3])
     assert hs2.incomplete or np.array_equal(hs2.counts, hs.counts)
     assert not ops.same_pack_params(g, truth)
-    # (d) no fused kernel for 3-bit DNA: nothing launched
+    # (d) 3-bit DNA (--notricks keeps N as a base) has a fused kernel too: exact counts, the separate pass's tables
     d3 = _decide_from_stats(hs, notricks=True)
-    assert ops.pack_stats(ctx, d_buf, ls, 0, n, mk(d3, hs.max_record_bytes)) is None
+    p3 = mk(d3, hs.max_record_bytes)
+    res = ops.pack_stats(ctx, d_buf, ls, 0, n, p3)
+    assert res is not None
+    hs3 = ops.stats_fetch(ctx, res[3])
+    assert not hs3.incomplete and np.array_equal(hs3.counts, hs.counts)
+    ref3 = ops.pack(ctx, d_buf, ls, 0, n, p3)
+    assert ctx.torch.equal(res[0], ref3[0]) and ctx.torch.equal(res[1], ref3[1])
+    # (e) a geometry without one -- eight bits per base (--pad on a five-letter alphabet): nothing launched
+    d8 = _decide_from_stats(hs, notricks=True, pad=True)
+    assert d8['bits_per_base'] == 4 and ops.pack_stats(ctx, d_buf, ls, 0, n, mk(d8, hs.max_record_bytes)) is None
 
 
 @pytest.mark.parametrize('variable', [False, True])

@@ -227,7 +227,8 @@ constexpr int PK_NV_STATS = 4;   // the fused pack + statistics kernel keeps a f
 // again at the flush, the N-trick base's own pairs go to a 128-entry table by quality character.  A symbol outside the guessed
 // alphabets is not counted at all: the statistics are flagged incomplete (the guess is wrong then anyway).
 constexpr int PKS_COPIES = 4;
-constexpr uint32_t PKS_WORDS = 256 * PKS_COPIES + 128;
+constexpr uint32_t pks_bins(int bd) { return bd == 3 ? 512u : 256u; }     // bin = base code << 6 | quality code (3-bit bases: nine bits)
+constexpr uint32_t pks_words(int bd) { return pks_bins(bd) * PKS_COPIES + 128; }
 
 // LDS carve (dynamic): [16 B guard][stage][out_d | out_q][meta u32 x (4R+4)][luts 3 x 512 B]
 // Workgroups are persistent: each walks tiles b, b + S, b + 2S, ... with a software pipeline -- the
@@ -267,8 +268,9 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && (NTRICK || QN)) ? 4 : 5) void
     bool incomplete = false;
     uint32_t* cnt_tab = (uint32_t*)(l_nq + 256);                 // [256 bins][PKS_COPIES], then [128] N-trick base by quality character
     uint32_t fill_pairs = 0, n_pairs = 0;                        // pairs counted in bin 0 / bin n_code that were fills / N-trick positions
+    constexpr uint32_t PKS_BINS = pks_bins(BD), PKS_WORDS = pks_words(BD);
     if (STATS) for (uint32_t i = tid; i < PKS_WORDS; i += PK_THREADS) cnt_tab[i] = 0;       // the first tile's barrier orders it
-    QnLds* qn = (QnLds*)(cnt_tab + PKS_WORDS);                   // the QNAME phase's state (uq_pack_stats_qname only)
+    QnLds* qn = (QnLds*)(cnt_tab + pks_words(BD));                   // the QNAME phase's state (uq_pack_stats_qname only)
     bool qn_on = false;
     if (STATS && QN) qn_on = qf->ok != 0;                        // the guess kernels in front may have declined: the lines are left alone
     if (STATS && QN) {
@@ -418,12 +420,21 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && (NTRICK || QN)) ? 4 : 5) void
                         if (STATS) {
                             if (generic) incomplete = true;          // a symbol outside the guess: not counted here
                             else {
-                                const uint32_t bin0 = (c0 << 6) | x0, bin1 = (c1 << 6) | x1;        // BQ <= 6: a bin per byte
                                 uint8_t* hb = (uint8_t*)cnt_tab + ((lane_id() & (PKS_COPIES - 1)) << 2);
+                                if constexpr (BD == 2) {
+                                    const uint32_t bin0 = (c0 << 6) | x0, bin1 = (c1 << 6) | x1;    // BQ <= 6 and two bits of base: a bin per byte
 #pragma unroll
-                                for (int k = 0; k < 4; ++k) {
-                                    atomicAdd((uint32_t*)(hb + (((bin0 >> (8 * k)) & 0xFFu) * (4 * PKS_COPIES))), 1u);
-                                    atomicAdd((uint32_t*)(hb + (((bin1 >> (8 * k)) & 0xFFu) * (4 * PKS_COPIES))), 1u);
+                                    for (int k = 0; k < 4; ++k) {
+                                        atomicAdd((uint32_t*)(hb + (((bin0 >> (8 * k)) & 0xFFu) * (4 * PKS_COPIES))), 1u);
+                                        atomicAdd((uint32_t*)(hb + (((bin1 >> (8 * k)) & 0xFFu) * (4 * PKS_COPIES))), 1u);
+                                    }
+                                } else {                                                            // three bits of base: nine bits of bin, pair by pair
+#pragma unroll
+                                    for (int k = 0; k < 4; ++k) {
+                                        const uint32_t b0 = (((c0 >> (8 * k)) & 7u) << 6) | ((x0 >> (8 * k)) & 63u), b1 = (((c1 >> (8 * k)) & 7u) << 6) | ((x1 >> (8 * k)) & 63u);
+                                        atomicAdd((uint32_t*)(hb + b0 * (4 * PKS_COPIES)), 1u);
+                                        atomicAdd((uint32_t*)(hb + b1 * (4 * PKS_COPIES)), 1u);
+                                    }
                                 }
                                 if (j0 < 0) fill_pairs += (uint32_t)(-j0);
                                 if (NTRICK && (e0 | e1)) {
@@ -530,20 +541,21 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && (NTRICK || QN)) ? 4 : 5) void
         if (fill_pairs) atomicSub(&cnt_tab[lane_id() & (PKS_COPIES - 1)], fill_pairs);
         if (NTRICK && n_pairs) {
             atomicSub(&cnt_tab[((g.n_code & 0xFFu) * PKS_COPIES) + (lane_id() & (PKS_COPIES - 1))], n_pairs);
-            atomicAdd(&cnt_tab[256 * PKS_COPIES], n_pairs);       // ... and onto the N-trick base's own counter
+            atomicAdd(&cnt_tab[PKS_BINS * PKS_COPIES], n_pairs);       // ... and onto the N-trick base's own counter
         }
         __syncthreads();
         const uint32_t qmin = 0x80u - (g.q_addlo & 0xFFu);
-        {
-            const uint32_t bin = tid;                            // 256 bins, 256 lanes
+        for (uint32_t bin = tid; bin < PKS_BINS; bin += PK_THREADS) {
             uint32_t v = 0;
 #pragma unroll
             for (int c = 0; c < PKS_COPIES; ++c) v += cnt_tab[bin * PKS_COPIES + c];
-            const uint32_t base = (0x54474341u >> (8 * (bin >> 6))) & 0xFFu;                  // "ACGT"[code]
+            const uint32_t code = bin >> 6;
+            const uint32_t base = BD == 2 ? (0x54474341u >> (8 * code)) & 0xFFu                           // "ACGT"[code]
+                                          : ((code < 4 ? g.c2c_lo >> (8 * code) : g.c2c_hi >> (8 * (code - 4))) & 0xFFu);
             if (v) atomicAdd((unsigned long long*)&st->counts[base * 256 + qmin + (bin & 63u)], (unsigned long long)v);
         }
         if (NTRICK && tid == 0) {
-            const uint32_t v = cnt_tab[256 * PKS_COPIES];
+            const uint32_t v = cnt_tab[PKS_BINS * PKS_COPIES];
             if (v) atomicAdd((unsigned long long*)&st->counts[(g.n_char & 0xFFu) * 256 + (g.n_qchar & 0xFFu)], (unsigned long long)v);
         }
         acc.flush(st, first);
@@ -602,13 +614,16 @@ PackKernel pick_nt(bool ntrick, bool fast) {
 }
 
 // the fused pack + statistics kernels exist for the lookup-free path only (2-bit A/C/G/T, contiguous qualities)
-template <bool QN>
+template <int BD, bool QN>
 PackKernel pick_stats_kernel_q(int bq, bool ntrick) {
-#define UQ_PS(B) case B: return ntrick ? pack_tile_kernel<2, B, true, true, true, QN> : pack_tile_kernel<2, B, false, true, true, QN>;
-    switch (bq) { UQ_PS(1) UQ_PS(2) UQ_PS(3) UQ_PS(4) UQ_PS(5) default: return ntrick ? pack_tile_kernel<2, 6, true, true, true, QN> : pack_tile_kernel<2, 6, false, true, true, QN>; }
+#define UQ_PS(B) case B: return ntrick ? pack_tile_kernel<BD, B, true, true, true, QN> : pack_tile_kernel<BD, B, false, true, true, QN>;
+    switch (bq) { UQ_PS(1) UQ_PS(2) UQ_PS(3) UQ_PS(4) UQ_PS(5) default: return ntrick ? pack_tile_kernel<BD, 6, true, true, true, QN> : pack_tile_kernel<BD, 6, false, true, true, QN>; }
 #undef UQ_PS
 }
-PackKernel pick_stats_kernel(int bq, bool ntrick, bool qn) { return qn ? pick_stats_kernel_q<true>(bq, ntrick) : pick_stats_kernel_q<false>(bq, ntrick); }
+PackKernel pick_stats_kernel(int bd, int bq, bool ntrick, bool qn) {
+    if (bd == 3) return qn ? pick_stats_kernel_q<3, true>(bq, ntrick) : pick_stats_kernel_q<3, false>(bq, ntrick);
+    return qn ? pick_stats_kernel_q<2, true>(bq, ntrick) : pick_stats_kernel_q<2, false>(bq, ntrick);
+}
 
 template <int BD>
 PackKernel pick_bq(int bq, bool ntrick, bool fast) {
@@ -760,11 +775,11 @@ static int pack_impl(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_s
         }
     }
     if (d_stats && ntrick_bases == 1 && hp->n_qual[nchar] >= nq) return 0;    // the N-trick code is no quality of the alphabet (Q9): exact kernels only
-    if (d_stats && (!fast || bd != 2 || bq > 6)) return 0;  // the fused kernels exist for the 2-bit lookup-free path with a bin per byte (<= 64 qualities) only
-    const size_t lds = 16 + (size_t)g.stage_bytes + g.out_bytes + (4 * R + 4) * 4 + 3 * 512 + (d_stats ? PKS_WORDS * 4 + sizeof(QnLds) : 0);
+    if (d_stats && (!fast || (bd != 2 && bd != 3) || bq > 6)) return 0;  // the fused kernels exist for the lookup-free paths (2- / 3-bit bases, <= 64 contiguous qualities) only
+    const size_t lds = 16 + (size_t)g.stage_bytes + g.out_bytes + (4 * R + 4) * 4 + 3 * 512 + (d_stats ? pks_words((int)bd) * 4 + sizeof(QnLds) : 0);
     UQ_REQUIRE(lds <= 160 * 1024, "uq_pack: tile needs %zu bytes of LDS", lds);
     const uint64_t tiles = (nreads + R - 1) / R;
-    PackKernel k = d_stats ? pick_stats_kernel((int)bq, ntrick, d_q != nullptr) : pick_kernel((int)bd, (int)bq, ntrick, fast);
+    PackKernel k = d_stats ? pick_stats_kernel((int)bd, (int)bq, ntrick, d_q != nullptr) : pick_kernel((int)bd, (int)bq, ntrick, fast);
     if (lds > 48 * 1024) UQ_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // persistent workgroups: exactly as many as are resident at once (LDS and registers both limit that: a grid sized from the LDS
     // alone would leave the kernels built for four waves per SIMD with a second, quarter-full round of workgroups)
