@@ -259,6 +259,10 @@ def test_fused_pass_demotion_and_offsets(ctx):
     assert _check(ctx, _fastq(names), must_answer=True) == 'ok'
     names = [b'@r_%d_%d' % (i, 250 + i % 10) for i in range(70000)]                                # u4 / offset columns
     assert _check(ctx, _fastq(names), must_answer=True, fused_must_answer=True) == 'ok'
+    # a first QNAME beyond 64 bytes (the guess kernel builds line 1's character table a lane per position up to 64, serially beyond)
+    long_prefix = b'@' + b'instrument-0123456789-instrument-0123456789-instrument-0123456789-instrument.run'
+    names = [long_prefix + b':%d:%d:%d' % (1 + i % 4, 1101 + i % 64, 1000 + (i * 7919) % 29000) for i in range(12000)]
+    assert len(names[0]) > 64 and _check(ctx, _fastq(names), must_answer=True, fused_must_answer=True) == 'ok'
     # reads that break the layout late in the file: the fused pass must notice each of them
     base = [b'@r_%d_%d' % (i % 50, i) for i in range(20000)]
     for bad in (b'@r_7_x9', b'@r_7_007', b'@r_7', b'@r_7_8_9', b'@q_7_8', b'@r_7_+8', b'@r_7_', b'@r_7_12345678901'):

@@ -48,11 +48,13 @@ __device__ __forceinline__ void stage_line(uint8_t* row, const uint8_t* q, uint3
 }
 
 // n: reads in the buffer (d_async: taken from the queued census).  `lay` was initialised by the host side of the call.
-__global__ __launch_bounds__(QF_THREADS) void qname_sample_kernel(const uint8_t* __restrict__ buf, const uint64_t* __restrict__ ls, uint64_t n,
+// One wave per workgroup, QF_SPW samples per wave: the work per sample is a chain of dependent wave-wide operations, so the kernel's
+// time is one wave's -- 4096 samples over 256 CUs as 16 per wave, not over 16 CUs as 256 per workgroup.
+constexpr uint32_t QF_SPW = 8;
+__global__ __launch_bounds__(64) void qname_sample_kernel(const uint8_t* __restrict__ buf, const uint64_t* __restrict__ ls, uint64_t n,
                                                                    const unsigned long long* __restrict__ d_async, uq_qname_layout_result* __restrict__ lay,
                                                                    DevLine1* __restrict__ l1_out, uint32_t* __restrict__ step_out) {
-    __shared__ uint8_t cnt[QF_MAXCH * QF_THREADS];
-    __shared__ __align__(16) uint8_t stage[QF_THREADS * QF_STRIDE];
+    __shared__ __align__(16) uint8_t stage[64 * QF_STRIDE];
     __shared__ DevLine1 l1;
     __shared__ unsigned long long s_entry[QF_MAXCH], s_viol[QF_MAXCH];
     __shared__ uint32_t s_lcp, s_lcs, s_flags;
@@ -61,13 +63,31 @@ __global__ __launch_bounds__(QF_THREADS) void qname_sample_kernel(const uint8_t*
     // ---- line 1 and its character table (every workgroup builds its own copy: 255 bytes, one lane)
     uint32_t len = 0;
     if (n) { const uint64_t e = ls[1]; len = e >= 1 && e <= 256 ? (uint32_t)(e - 1) : 0xFFFFFFFFu; }
-    l1.text[tid] = (len != 0xFFFFFFFFu && tid < len) ? buf[tid] : 0;
-    l1.slot[tid] = 0xFF;
+    for (uint32_t x = tid; x < 256; x += 64) { l1.text[x] = (len != 0xFFFFFFFFu && x < len) ? buf[x] : 0; l1.slot[x] = 0xFF; }
     if (tid < QF_MAXCH) { l1.ch[tid] = 0; l1.cnt[tid] = 0; l1.lastpos[tid] = 0; s_entry[tid] = UQ_NONE; s_viol[tid] = 0; }
     if (tid == 0) { s_lcp = 0xFFFFFFFFu; s_lcs = 0xFFFFFFFFu; s_flags = 0; }
     __syncthreads();
-    if (tid == 0) {
-        uint32_t nch = 0, bad = (len == 0 || len == 0xFFFFFFFFu || l1.text[0] != '@') ? 1u : 0u;
+    const bool bad0 = len == 0 || len == 0xFFFFFFFFu || l1.text[0] != '@';
+    if (!bad0 && len <= 64) {
+        // the character table of a line of at most 64 bytes, a lane per position: lane p learns the set of positions that hold its
+        // character (one ballot per position), from which its count, its last position and -- for a first occurrence -- its slot follow
+        const uint32_t lane0 = lane_id();
+        const uint32_t mych = lane0 < len ? (uint32_t)l1.text[lane0] : 0x100u;
+        unsigned long long same = 0;
+        for (uint32_t j = 0; j < len; ++j) {
+            const unsigned long long bm = __ballot(mych == (uint32_t)__builtin_amdgcn_readlane((int)mych, (int)j));
+            if (lane0 == j) same = bm;
+        }
+        const bool first = lane0 < len && (uint32_t)__builtin_ctzll(same | (1ull << 63)) == lane0;
+        const unsigned long long fm = __ballot(first);
+        if (first) {
+            const uint32_t sl = (uint32_t)__popcll(fm & ((1ull << lane0) - 1));
+            l1.slot[mych] = (uint8_t)sl; l1.ch[sl] = (uint8_t)mych;
+            l1.cnt[sl] = (uint16_t)__popcll(same); l1.lastpos[sl] = (uint16_t)(63 - __builtin_clzll(same));
+        }
+        if (lane0 == 0) { l1.len = len; l1.nch = (uint32_t)__popcll(fm); l1.bad = 0; l1.pad = 0; }
+    } else if (tid == 0) {
+        uint32_t nch = 0, bad = bad0 ? 1u : 0u;
         if (!bad)
             for (uint32_t p = 0; p < len; ++p) {
                 const uint8_t c = l1.text[p];
@@ -82,47 +102,69 @@ __global__ __launch_bounds__(QF_THREADS) void qname_sample_kernel(const uint8_t*
     __syncthreads();
     const uint32_t step = (uint32_t)(n / QF_SAMPLES > 1 ? n / QF_SAMPLES : 1);
     if (blockIdx.x == 0) {
-        for (uint32_t i = tid; i < sizeof(DevLine1) / 4; i += QF_THREADS) ((uint32_t*)l1_out)[i] = ((const uint32_t*)&l1)[i];
+        for (uint32_t i = tid; i < sizeof(DevLine1) / 4; i += 64) ((uint32_t*)l1_out)[i] = ((const uint32_t*)&l1)[i];
         if (tid == 0) *step_out = step;
     }
     if (l1.bad) return;
-    for (uint32_t k = 0; k < l1.nch; ++k) cnt[k * QF_THREADS + tid] = 0;
     const uint8_t* buf_end = buf + ls[4 * n];
-    uint32_t my_lcp = 0xFFFFFFFFu, my_lcs = 0xFFFFFFFFu;
+    uint32_t my_lcp = 0xFFFFFFFFu, my_lcs = 0xFFFFFFFFu;         // (wave-uniform below: every lane holds the same value)
+    const uint32_t lane = lane_id();
+    const uint32_t my_ch = lane < l1.nch ? l1.ch[lane] : 0x100u;   // lane c speaks for candidate character c of line 1
+    const uint32_t my_cnt = lane < l1.nch ? l1.cnt[lane] : 0u, my_last = lane < l1.nch ? l1.lastpos[lane] : 0u;
     // sample = one record out of every `step` consecutive ones, at a pseudo-random place in its stratum (a fixed stride would
-    // alias with periodic names: interleaved mates, lanes that cycle); record 0 is line 1 itself
-    for (uint64_t k = (uint64_t)blockIdx.x * QF_THREADS + tid; k * step < n; k += (uint64_t)gridDim.x * QF_THREADS) {
+    // alias with periodic names: interleaved mates, lanes that cycle); record 0 is line 1 itself.  Two steps per round of 64 samples
+    // a wave: (1) every lane fetches ITS sample's line into its LDS row (64 index and line loads in flight at once); (2) the wave goes
+    // through the 64 lines one by one with a lane per BYTE: common prefix / suffix with line 1 and the per-character counts are a
+    // few ballots each, no loop over the bytes (a lane per sample walking its line byte by byte took 72 us for 4096 samples).
+    for (uint64_t k0 = (uint64_t)blockIdx.x * QF_SPW; k0 * step < n; k0 += (uint64_t)gridDim.x * QF_SPW) {
+        const uint64_t k = k0 + lane;
         uint64_t h = (k + 0x9E3779B97F4A7C15ull) * 0xBF58476D1CE4E5B9ull;
         h ^= h >> 29; h *= 0x94D049BB133111EBull; h ^= h >> 32;
-        const uint64_t i = k * step + h % step;
-        if (i == 0 || i >= n) continue;
-        const uint8_t* q = buf + ls[4 * i];
-        const uint32_t ql = (uint32_t)(ls[4 * i + 1] - ls[4 * i] - 1);
-        if (ql > 255) { atomicOr(&s_flags, 2u); continue; }
-        const uint8_t* row = stage + tid * QF_STRIDE;
-        const bool staged = ql <= QF_ROW;
-        if (staged) stage_line(stage + tid * QF_STRIDE, q, ql, buf_end);
-        auto at = [&](uint32_t j) -> uint32_t { return staged ? row[j] : q[j]; };
-        const uint32_t m = ql < l1.len ? ql : l1.len;
-        uint32_t lcp = 0;
-        while (lcp < m && at(lcp) == l1.text[lcp]) ++lcp;
-        uint32_t lcs = 0;
-        while (lcs < m && at(ql - 1 - lcs) == l1.text[l1.len - 1 - lcs]) ++lcs;
-        if ((lcp == ql && ql < l1.len) || (lcs == ql && ql < l1.len)) atomicOr(&s_flags, 1u);
-        if (lcp < my_lcp) my_lcp = lcp;
-        if (lcs < my_lcs) my_lcs = lcs;
-        for (uint32_t j = 0; j < ql; ++j) {
-            const uint32_t sl = l1.slot[at(j)];
-            if (sl != 0xFFu) cnt[sl * QF_THREADS + tid] += 1;
+        uint64_t i = k * step + h % step;
+        if (lane >= QF_SPW || i >= n) i = 0;                            // (0 = no sample in this lane)
+        const uint8_t* q = buf;
+        uint32_t ql = 0;
+        uint8_t* row = stage + tid * QF_STRIDE;
+        if (i) {
+            q = buf + ls[4 * i];
+            ql = (uint32_t)(ls[4 * i + 1] - ls[4 * i] - 1);
+            if (ql <= QF_ROW) stage_line(row, q, ql, buf_end);
         }
-        for (uint32_t c = 0; c < l1.nch; ++c) {
-            const uint32_t have = cnt[c * QF_THREADS + tid];
-            cnt[c * QF_THREADS + tid] = 0;
-            if (lcp <= l1.lastpos[c] && (unsigned long long)i < s_entry[c]) atomicMin(&s_entry[c], (unsigned long long)i);
-            if (have != l1.cnt[c] && (unsigned long long)i > s_viol[c]) atomicMax(&s_viol[c], (unsigned long long)i);
+        for (uint32_t sidx = 0; sidx < QF_SPW; ++sidx) {
+            const uint64_t si = __shfl(i, sidx, 64);
+            if (si == 0) continue;                                      // (uniform)
+            const uint32_t sql = (uint32_t)__shfl(ql, sidx, 64);
+            if (sql > 255) { if (lane == 0) atomicOr(&s_flags, 2u); continue; }
+            const uint8_t* sq = (const uint8_t*)__shfl((unsigned long long)(uintptr_t)q, sidx, 64);
+            const uint8_t* srow = stage + sidx * QF_STRIDE;
+            const uint32_t m = sql < l1.len ? sql : l1.len;
+            uint32_t lcp = m, last_bad = 0xFFFFFFFFu, have = 0;         // last_bad: highest position that differs from line 1 counted from the ends
+            bool lcp_open = true;
+            for (uint32_t base = 0; base < sql; base += 64) {
+                const uint32_t pos = base + lane;
+                const bool valid = pos < sql;
+                const uint32_t b = valid ? (sql <= QF_ROW ? srow[pos] : sq[pos]) : 0x100u;
+                const unsigned long long pm = __ballot(valid && pos < m && b != l1.text[pos]);
+                if (lcp_open && pm) { lcp = base + (uint32_t)__builtin_ctzll(pm); lcp_open = false; }
+                const uint32_t t = sql - 1 - pos;                       // distance from the line's end
+                const unsigned long long sm = __ballot(valid && t < m && b != l1.text[l1.len - 1 - t]);
+                if (sm) last_bad = base + 63u - (uint32_t)__builtin_clzll(sm);
+                for (uint32_t c = 0; c < l1.nch; ++c) {
+                    const unsigned long long cm = __ballot(b == (uint32_t)l1.ch[c]);
+                    if (lane == c) have += (uint32_t)__popcll(cm);
+                }
+            }
+            const uint32_t lcs = last_bad == 0xFFFFFFFFu ? m : sql - 1 - last_bad;
+            if (lane == 0 && ((lcp == sql && sql < l1.len) || (lcs == sql && sql < l1.len))) atomicOr(&s_flags, 1u);
+            if (lcp < my_lcp) my_lcp = lcp;
+            if (lcs < my_lcs) my_lcs = lcs;
+            if (lane < l1.nch) {
+                if (lcp <= my_last && (unsigned long long)si < s_entry[lane]) atomicMin(&s_entry[lane], (unsigned long long)si);
+                if (have != my_cnt && (unsigned long long)si > s_viol[lane]) atomicMax(&s_viol[lane], (unsigned long long)si);
+            }
         }
     }
-    my_lcp = wave_min(my_lcp); my_lcs = wave_min(my_lcs);
+    (void)my_ch;
     if (lane_id() == 0) { atomicMin(&s_lcp, my_lcp); atomicMin(&s_lcs, my_lcs); }
     __syncthreads();
     if (tid < l1.nch) {
@@ -135,13 +177,19 @@ __global__ __launch_bounds__(QF_THREADS) void qname_sample_kernel(const uint8_t*
     }
 }
 
+__global__ void layout_init_kernel(uq_qname_layout_result* lay) {
+    const uint32_t t = threadIdx.x;
+    if (t < QF_MAXCH) { lay->entry[t] = UQ_NONE; lay->lastviol[t] = 0; lay->ch[t] = 0; }
+    if (t == 0) { lay->min_lcp = 0xFFFFFFFFu; lay->min_lcs = 0xFFFFFFFFu; lay->flags = 0; lay->nch = 0; }
+}
+
 __device__ bool regex_special(uint8_t c) {
     const char* s = ".^$*+?{}[]\\|()-";
     for (int i = 0; s[i]; ++i) if ((uint8_t)s[i] == c) return true;
     return false;
 }
 
-// uq.py:428-444 on the sample's reductions -> the guess.  One lane.
+// uq.py:428-444 on the sample's reductions -> the guess.  One wave.
 __global__ void qname_guess_kernel(const DevLine1* __restrict__ g_l1, const uq_qname_layout_result* __restrict__ g_lay, const uint32_t* __restrict__ step,
                                    uq_qname_fused* __restrict__ q) {
     // the inputs are copied to LDS first: lane 0's loops below are serial, and a dependent global load costs ten LDS reads
@@ -158,39 +206,41 @@ __global__ void qname_guess_kernel(const DevLine1* __restrict__ g_l1, const uq_q
     if (t < UQ_QF_MAXC) { q->vmin[t] = 0xFFFFFFFFu; q->vmax[t] = 0; q->undetermined[t] = 0; }
     for (uint32_t i = t; i < UQ_QF_MAXC * UQ_QF_MAXT; i += 64) (&q->counts[0][0])[i] = 0;
     if (t < UQ_QF_MAXT) q->thresholds[t] = 0;
-    if (t != 0) return;
-    q->ok = 0; q->plen = q->slen = q->nsep = q->l1len = 0; q->flags = 0; q->sample_step = *step; q->nth = 0; q->nreads = 0;
-    if (l1->bad || lay->flags) return;
+    if (t == 0) { q->ok = 0; q->plen = q->slen = q->nsep = q->l1len = 0; q->flags = 0; q->sample_step = *step; q->nth = 0; q->nreads = 0; }
+    if (l1->bad || lay->flags) return;                        // (uniform)
     const uint32_t len = l1->len;
     // min_lcp / min_lcs start at line 1's length: with no sampled read (a file of one record) plen + slen > len declines below
     const uint32_t plen = lay->min_lcp < len ? lay->min_lcp : len, slen = lay->min_lcs < len ? lay->min_lcs : len;
     if (plen == 0 || plen + slen > len) return;               // every QNAME starts with '@': an empty prefix is no FASTQ the fused pass takes
-    bool is_sep[QF_MAXCH];
-    uint32_t nsepch = 0;
-    for (uint32_t k = 0; k < l1->nch; ++k) {
-        is_sep[k] = false;
-        if (lay->entry[k] == UQ_NONE || lay->lastviol[k] >= lay->entry[k]) continue;
-        const uint8_t c = l1->ch[k];
+    // lane k judges character k of line 1 (uq.py:428-431): it survived the loop and occurs in the middle of line 1
+    __shared__ uint8_t s_sep[QF_MAXCH];
+    bool mine = false, special = false;
+    if (t < l1->nch && lay->entry[t] != UQ_NONE && lay->lastviol[t] < lay->entry[t]) {
+        const uint8_t c = l1->ch[t];
         int mid = 0;                                          // l1[plen:].count(c) - suffix.count(c)
         for (uint32_t p = plen; p < len - slen; ++p) mid += l1->text[p] == c;
-        if (mid == 0) continue;
-        if (regex_special(c)) return;                         // '[seps]+' and '(.*)'.join(seps) are regexes in the reference: the host's `re` path
-        is_sep[k] = true; ++nsepch;
+        mine = mid != 0;
+        special = mine && regex_special(c);                   // '[seps]+' and '(.*)'.join(seps) are regexes in the reference: the host's `re` path
     }
-    if (nsepch == 0) return;                                  // (the reference refuses such files: the exact path words the error)
+    s_sep[t] = mine ? 1 : 0;
+    const uint32_t nsepch = (uint32_t)__popcll(__ballot(mine));
+    if (__ballot(special) || nsepch == 0 || nsepch > 4) return;      // (no separator: the reference refuses such files, the exact path words the error;
+                                                                     //  more than four: the pack kernel tests a window against four characters)
+    __syncthreads();
+    if (t != 0) return;
     // separators = the separator characters of l1[plen : len - 1 - slen] in order (Q14: the slice drops one more character)
     uint32_t nsep = 0;
     const uint32_t end = len - slen >= 1 ? len - slen - 1 : 0;
     for (uint32_t p = plen; p < end; ++p) {
         const uint8_t c = l1->text[p];
-        if (l1->slot[c] != 0xFF && is_sep[l1->slot[c]]) {
+        if (l1->slot[c] != 0xFF && s_sep[l1->slot[c]]) {
             if (nsep == UQ_QF_MAXC - 1) return;
             q->seps[nsep++] = c;
         }
     }
-    if (nsep == 0 || nsepch > 4) return;                      // (the pack kernel tests a window against four separator characters)
+    if (nsep == 0) return;
     __builtin_amdgcn_s_waitcnt(0);                            // (the other lanes' zeroes of inset[] are stores of this same wave: in order)
-    for (uint32_t k = 0; k < l1->nch; ++k) if (is_sep[k]) q->inset[l1->ch[k]] = 1;
+    for (uint32_t k = 0; k < l1->nch; ++k) if (s_sep[k]) q->inset[l1->ch[k]] = 1;
     q->plen = plen; q->slen = slen; q->nsep = nsep; q->l1len = len;
     q->ok = 1;
 }
@@ -333,11 +383,10 @@ int guess_impl(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start, 
     uint8_t* base = (uint8_t*)scr;
     uq_qname_layout_result* d_lay = (uq_qname_layout_result*)(base + o_lay);
     // initial values of the reductions: min_lcp = min_lcs = 0xFFFFFFFF (clamped to line 1's length by the guess kernel), entry = none
-    UQ_CHECK_HIP(hipMemsetAsync(d_lay, 0, sizeof(*d_lay), ctx->stream));
-    UQ_CHECK_HIP(hipMemsetAsync(&d_lay->min_lcp, 0xFF, 8, ctx->stream));
-    UQ_CHECK_HIP(hipMemsetAsync(d_lay->entry, 0xFF, sizeof(d_lay->entry), ctx->stream));
-    const uint32_t grid = QF_SAMPLES / QF_THREADS;
-    qname_sample_kernel<<<grid, QF_THREADS, 0, ctx->stream>>>(d_buf, d_line_start, nreads, d_async, d_lay, (DevLine1*)(base + o_l1), (uint32_t*)(base + o_step));
+    layout_init_kernel<<<1, 256, 0, ctx->stream>>>(d_lay);             // (one launch instead of three fills)
+    UQ_LAUNCH_CHECK();
+    const uint32_t grid = QF_SAMPLES / QF_SPW;
+    qname_sample_kernel<<<grid, 64, 0, ctx->stream>>>(d_buf, d_line_start, nreads, d_async, d_lay, (DevLine1*)(base + o_l1), (uint32_t*)(base + o_step));
     UQ_LAUNCH_CHECK();
     qname_guess_kernel<<<1, 64, 0, ctx->stream>>>((const DevLine1*)(base + o_l1), d_lay, (const uint32_t*)(base + o_step), d_q);
     UQ_LAUNCH_CHECK();
