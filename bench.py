@@ -159,7 +159,7 @@ def main():
             return uqdist.allreduce_stats(ctx, st)
         return ops.stats_fetch(ctx, st)
 
-    def run_encode(n, steps, warmup, compare_exact):
+    def run_encode(n, steps, warmup, compare_exact, qname_in_step=qname_in_step):
         """`steps` timed steps of the hot path over n reads per GPU (W untimed first) -> everything the JSON needs."""
         if args.workload == 'cfg2':
             spec = synth.Spec(SEED, args.length)
@@ -384,6 +384,12 @@ def main():
         if not cb['gpu_rows_match_oracle_on_sample']:
             raise RuntimeError('parity failure: GPU rows differ from the oracle on the CPU sample')
         result['cpu_baseline'] = cb
+    # what the N > 1 lines measure (their step leaves the QNAME passes out), at N = 1: the like-for-like baseline of a scaling curve
+    if qname_in_step and world == 1:
+        plain = run_encode(args.reads, max(5, args.steps // 2), 2, False, qname_in_step=False)
+        result['qname']['step_without_qname_ms'] = round(plain['dt_step'] * 1e3, 3)
+        result['qname']['value_without_qname'] = round(plain['total_bytes'] / 1e6 / plain['dt_step'], 1)
+        del plain
     del m, state
     torch.cuda.empty_cache()
 

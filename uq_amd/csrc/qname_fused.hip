@@ -325,12 +325,21 @@ __global__ __launch_bounds__(QF_THREADS) void qf_wide_kernel(uq_qname_fused* __r
     uint32_t k = 0;
     for (; k < cp.nth && k < QF_WIDE_CP && cp.t[k] < QF_PREFIX; ++k) {
         uint32_t fresh = 0;
-        for (uint64_t i = done + threadIdx.x; i <= cp.t[k]; i += QF_THREADS) {
-            const uint32_t slot = v[i] - vmin;
-            if (slot >= range) continue;
+        auto add = [&](uint32_t val) {
+            const uint32_t slot = val - vmin;
+            if (slot >= range) return;
             const uint32_t bit = 1u << (slot & 31);
             if (!(atomicOr(&bits[slot >> 5], bit) & bit)) ++fresh;
+        };
+        uint64_t i = done + threadIdx.x;
+        for (; i + 7 * QF_THREADS <= cp.t[k]; i += 8 * QF_THREADS) {       // eight loads in flight, then their eight updates
+            uint32_t x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = v[i + (uint64_t)u * QF_THREADS];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) add(x[u]);
         }
+        for (; i <= cp.t[k]; i += QF_THREADS) add(v[i]);
         done = cp.t[k] + 1;
         fresh = wave_sum(fresh);
         if (lane_id() == 0 && fresh) atomicAdd(&s_count, fresh);

@@ -235,7 +235,7 @@ def analyse_fused(ctx, fq, nreads):
     suffix = l1[r.l1len - r.slen:] if r.slen else ''
     separators = bytes(r.seps[:r.nsep]).decode('latin-1')
     thresholds = _thresholds(n)
-    if [int(x) for x in r.thresholds[:r.nth]] != thresholds:
+    if list(r.thresholds[:r.nth]) != thresholds:
         return None
     columns, arrays = [], []
     for c in range(r.nsep + 1):
@@ -246,11 +246,11 @@ def analyse_fused(ctx, fq, nreads):
         # where the `len(map) > entries_read / 10` rule fires at once or the values are sorted (type_and_encode_device's rule)
         counts = None
         if not r.undetermined[c] and vmax - vmin + 1 <= INT_RANGE_SMALL:
-            ths, counts = thresholds, [int(x) for x in r.counts[c][:len(thresholds)]]
+            ths, counts = thresholds, r.counts[c][:len(thresholds)]
             nu = counts[-1]
         elif not r.undetermined[c]:
             ths = [T for T in thresholds if T < INT_PREFIX]
-            counts = [int(x) for x in r.counts[c][:len(ths)]]
+            counts = r.counts[c][:len(ths)]
             if any(cnt > T // 10 for T, cnt in zip(ths, counts)): nu = None
             elif len(ths) == len(thresholds): nu = counts[-1]
             else: counts = None
