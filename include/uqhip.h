@@ -310,6 +310,10 @@ int uq_partition_rows(uq_ctx* ctx, const uint8_t* d_splitters, uint32_t nsplit, 
 int uq_owner_of_rows(uq_ctx* ctx, const int64_t* d_row_index, uint64_t n, const int64_t* h_shard_starts, uint32_t world, uint8_t* d_owner);
 int uq_index_affine(uq_ctx* ctx, const void* d_in, int in_itemsize, uint64_t n, int64_t add, void* d_out, int out_itemsize);
 int uq_invert_permutation(uq_ctx* ctx, const void* d_perm, int perm_itemsize, uint64_t n, int64_t base, uint32_t* d_inv, uint64_t* h_bad);
+/* d_out[(d_index[j] - base) * cols ...] = d_values[j * cols ...]: rows to their places (keys back to file order, uq.py:786's inverse) in one
+ * random pass; *h_bad = UQ_NONE or the lowest j whose target lies outside [0, out_rows). */
+int uq_scatter_rows(uq_ctx* ctx, const uint8_t* d_values, uint64_t n, uint32_t cols, const void* d_index, int index_itemsize, int64_t base,
+                    uint64_t out_rows, uint8_t* d_out, uint64_t* h_bad);
 
 /* ---- f1 INSIDE a3 / a4: the QNAME passes in the pack kernel's read of the stream (uq.py:394-444 layout inference, 555-565 field
  * split, 717-736 int() of the fields).  The pack kernel already holds every record's QNAME line in LDS; with a uq_qname_fused it

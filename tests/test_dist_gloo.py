@@ -58,6 +58,15 @@ class NumpyRows:
         if index.dtype == torch.int32: a &= 0xFFFFFFFF
         return torch.from_numpy((a + add).astype(np.int32 if out_itemsize == 4 else np.int64))
 
+    def scatter_rows(self, values, n, cols, index, base, out_rows):
+        a = index.numpy().astype(np.int64)
+        if index.dtype == torch.int32: a &= 0xFFFFFFFF
+        a = a - base
+        assert sorted(a.tolist()) == list(range(out_rows))
+        out = np.empty((out_rows, cols), dtype=np.uint8)
+        out[a] = values.numpy().reshape(n, cols)
+        return torch.from_numpy(out.reshape(-1))
+
     def invert_permutation(self, perm, base=0):
         a = perm.numpy().astype(np.int64)
         if perm.dtype == torch.int32: a &= 0xFFFFFFFF

@@ -245,6 +245,30 @@ def test_lower_bound_rows_and_single_rank_global_sort(ctx):
     assert np.array_equal(ctx.to_numpy(res['table']).reshape(n, C), S)
     g = uqdist.dist_gather_rows(uqdist.HipRows(ctx), _dev(ctx, T.ravel()), n, C, [1000, 1000 + n], res['gidx'])
     assert np.array_equal(ctx.to_numpy(g).reshape(n, C), S)
+    back = uqdist.dist_scatter_rows(uqdist.HipRows(ctx), res['table'], C, [1000, 1000 + n], res['gidx'])
+    assert np.array_equal(ctx.to_numpy(back).reshape(n, C), T)
+
+
+@pytest.mark.parametrize('C', [1, 3, 4, 7, 8, 13, 16, 38, 64, 113, 200])
+@pytest.mark.parametrize('itemsize', [4, 8])
+def test_scatter_rows(ctx, C, itemsize):
+    """uq_scatter_rows: out[index[j] - base] = values[j] for every row width class (1 / 2 / 4 / 16 / 64 lanes per row) and both index
+    widths; an index outside the output is reported, not written."""
+    be = __import__('uq_amd.dist', fromlist=['HipRows']).HipRows(ctx)
+    rng = np.random.RandomState(C * 2 + itemsize)
+    n, base = 5003, 77
+    V = rng.randint(0, 256, size=(n, C)).astype(np.uint8)
+    perm = rng.permutation(n)
+    idx = (perm + base).astype(np.uint32 if itemsize == 4 else np.int64)
+    out = be.scatter_rows(_dev(ctx, V.ravel()), n, C, _dev(ctx, idx.view(np.uint8)).view(ctx.torch.int32 if itemsize == 4 else ctx.torch.int64), base, n)
+    want = np.empty_like(V)
+    want[perm] = V
+    assert np.array_equal(ctx.to_numpy(out).reshape(n, C), want)
+    idx[1234] = base + n
+    idx[4000] = base - 1 if itemsize == 8 else base + n + 5
+    with pytest.raises(RuntimeError, match='entry 1234'):
+        be.scatter_rows(_dev(ctx, V.ravel()), n, C, _dev(ctx, idx.view(np.uint8)).view(ctx.torch.int32 if itemsize == 4 else ctx.torch.int64), base, n)
+    assert len(be.scatter_rows(_dev(ctx, V[:0].ravel()), 0, C, _dev(ctx, idx[:1].view(np.uint8)).view(ctx.torch.int32 if itemsize == 4 else ctx.torch.int64)[:0], base, 0)) == 0
 
 
 UNPACK_CASES = [('fixed', 2000, 100, {}, {}), ('var_ntrick', 3000, (36, 301), dict(n_rate=1), {}),

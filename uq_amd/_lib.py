@@ -126,6 +126,7 @@ SIGNATURES = {
     'uq_owner_of_rows': [_vp, _vp, _u64, _P(C.c_int64), _u32, _vp],
     'uq_index_affine': [_vp, _vp, _int, _u64, C.c_int64, _vp, _int],
     'uq_invert_permutation': [_vp, _vp, _int, _u64, C.c_int64, _vp, _P(_u64)],
+    'uq_scatter_rows': [_vp, _vp, _u64, _u32, _vp, _int, C.c_int64, _u64, _vp, _P(_u64)],
     'uq_qname_guess': [_vp, _vp, _vp, _u64, _vp],
     'uq_qname_guess_async': [_vp, _vp, _vp, _vp],
     'uq_pack_stats_qname': [_vp, _vp, _vp, _u64, _u64, _P(PackParams), _vp, _vp, _vp, _vp, _vp, _vp, _u64, _P(_int)],

@@ -222,10 +222,14 @@ __global__ __launch_bounds__(QN_THREADS) void qname_tokenise_kernel(const uint8_
 }
 
 // number of groups (runs of equal sorted keys) whose FIRST member in file order has index <= T_k
+// the checkpoints travel by value in the kernel-argument segment: nothing of the caller's has to stay alive, no copy, no wait
+struct Thresholds { unsigned long long t[64]; };
+
 template <typename IDX>
 __global__ __launch_bounds__(QN_THREADS) void prefix_distinct_kernel(const IDX* __restrict__ perm, const uint32_t* __restrict__ skey, uint64_t n,
-                                                                     const unsigned long long* __restrict__ th, int nth,
+                                                                     Thresholds thv, int nth,
                                                                      unsigned long long* __restrict__ counts) {
+    const unsigned long long* th = thv.t;
     __shared__ uint32_t s_cnt[64];
     if (threadIdx.x < 64) s_cnt[threadIdx.x] = 0;
     __syncthreads();
@@ -272,8 +276,9 @@ __global__ __launch_bounds__(QN_THREADS) void first_seen_kernel(const long long*
 
 // counts[k] = number of values whose first occurrence is <= T_k
 __global__ __launch_bounds__(QN_THREADS) void first_seen_count_kernel(const unsigned long long* __restrict__ first, uint32_t range,
-                                                                      const unsigned long long* __restrict__ th, int nth,
+                                                                      Thresholds thv, int nth,
                                                                       unsigned long long* __restrict__ counts) {
+    const unsigned long long* th = thv.t;
     __shared__ uint32_t s_cnt[64];
     if (threadIdx.x < 64) s_cnt[threadIdx.x] = 0;
     __syncthreads();
@@ -384,11 +389,11 @@ extern "C" int uq_prefix_distinct(uq_ctx* ctx, const void* d_perm, int perm_item
     UQ_REQUIRE(d_perm && d_sorted_key, "uq_prefix_distinct: null buffer");
     void* scr;
     UQ_TRY(uq_scratch(ctx, 2048, &scr));
-    unsigned long long* d_th = (unsigned long long*)scr;
-    unsigned long long* d_cnt = d_th + 64;
-    UQ_CHECK_HIP(hipMemcpyAsync(d_th, h_thresholds, nthresholds * 8, hipMemcpyHostToDevice, ctx->stream));
+    unsigned long long* d_cnt = (unsigned long long*)scr + 64;
+    Thresholds d_th;
+    memset(&d_th, 0, sizeof(d_th));
+    for (int k = 0; k < nthresholds; ++k) d_th.t[k] = h_thresholds[k];
     UQ_CHECK_HIP(hipMemsetAsync(d_cnt, 0, 64 * 8, ctx->stream));
-    UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));       // h_thresholds may be a temporary of the caller
     if (perm_itemsize == 4)
         prefix_distinct_kernel<uint32_t><<<grid_for(n), QN_THREADS, 0, ctx->stream>>>((const uint32_t*)d_perm, d_sorted_key, n, d_th, nthresholds, d_cnt);
     else
@@ -410,13 +415,13 @@ extern "C" int uq_int_prefix_distinct(uq_ctx* ctx, const int64_t* d_val, uint64_
     UQ_REQUIRE(d_val, "uq_int_prefix_distinct: null buffer");
     void* scr;
     UQ_TRY(uq_scratch(ctx, 2048 + range * 8, &scr));
-    unsigned long long* d_th = (unsigned long long*)scr;
-    unsigned long long* d_cnt = d_th + 64;
-    unsigned long long* d_first = d_th + 256;
-    UQ_CHECK_HIP(hipMemcpyAsync(d_th, h_thresholds, nthresholds * 8, hipMemcpyHostToDevice, ctx->stream));
+    unsigned long long* d_cnt = (unsigned long long*)scr + 64;
+    unsigned long long* d_first = (unsigned long long*)scr + 256;
+    Thresholds d_th;
+    memset(&d_th, 0, sizeof(d_th));
+    for (int k = 0; k < nthresholds; ++k) d_th.t[k] = h_thresholds[k];
     UQ_CHECK_HIP(hipMemsetAsync(d_cnt, 0, 64 * 8, ctx->stream));
     UQ_CHECK_HIP(hipMemsetAsync(d_first, 0xFF, range * 8, ctx->stream));
-    UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));       // h_thresholds may be a temporary of the caller
     const uint32_t grid = grid_for(n);
     if (range <= 4096) first_seen_kernel<true><<<grid, QN_THREADS, range * 8, ctx->stream>>>((const long long*)d_val, n, vmin, (uint32_t)range, read_index_base, d_first);
     else first_seen_kernel<false><<<grid, QN_THREADS, 0, ctx->stream>>>((const long long*)d_val, n, vmin, (uint32_t)range, read_index_base, d_first);

@@ -7,6 +7,7 @@
 //   uq_owner_of_rows       owner rank of a file-wide row number (shards are contiguous record ranges)
 //   uq_index_affine        out[j] = in[j] + add, between 32- and 64-bit index arrays (local order <-> file-wide row numbers)
 //   uq_invert_permutation  inv[perm[j] - base] = j
+//   uq_scatter_rows        out[index[j] - base] = values[j]: rows to their places in ONE random pass (instead of inverse + gather)
 #include "common.h"
 
 namespace {
@@ -86,8 +87,49 @@ __global__ __launch_bounds__(RT) void invert_kernel(const TI* __restrict__ perm,
     if (at < n) inv[at] = (uint32_t)j; else atomicMin(bad, (unsigned long long)j);
 }
 
+// out[(perm[j] - base) * C ..] = values[j * C ..]: rows to their places (the inverse of a gather, without the inverse permutation).
+// A wave moves 64 / lanes-per-row rows at a time, a lane a dword (or the row's tail bytes) of its row.
+template <typename TI>
+__global__ __launch_bounds__(RT) void scatter_rows_kernel(const uint8_t* __restrict__ values, uint64_t n, uint32_t C, const TI* __restrict__ perm, long long base,
+                                                          uint64_t out_rows, uint8_t* __restrict__ out, unsigned long long* __restrict__ bad) {
+    const uint32_t lpr = C <= 4 ? 1u : (C <= 8 ? 2u : (C <= 16 ? 4u : (C <= 64 ? 16u : 64u)));     // lanes per row
+    const uint64_t slot = ((uint64_t)blockIdx.x * RT + threadIdx.x) / lpr;
+    const uint32_t part = threadIdx.x % lpr;
+    if (slot >= n) return;
+    const unsigned long long at = (unsigned long long)((long long)perm[slot] - base);
+    if (at >= out_rows) { if (part == 0) atomicMin(bad, (unsigned long long)slot); return; }
+    const uint8_t* src = values + slot * C;
+    uint8_t* dst = out + at * C;
+    for (uint32_t b = part * 4; b < C; b += lpr * 4) {
+        if (b + 4 <= C) { uint32_t w; __builtin_memcpy(&w, src + b, 4); __builtin_memcpy(dst + b, &w, 4); }
+        else for (uint32_t k = b; k < C; ++k) dst[k] = src[k];
+    }
+}
+
 uint32_t blocks_of(uint64_t n) { return (uint32_t)((n + RT - 1) / RT); }
 }  // namespace
+
+// d_out[(d_index[j] - base) * cols ...] = d_values[j * cols ...] for j < n; every target row must lie in [0, out_rows).  *h_bad = UQ_NONE or
+// the lowest j that points outside.  Synchronises.
+extern "C" int uq_scatter_rows(uq_ctx* ctx, const uint8_t* d_values, uint64_t n, uint32_t cols, const void* d_index, int index_itemsize, int64_t base,
+                               uint64_t out_rows, uint8_t* d_out, uint64_t* h_bad) {
+    UQ_REQUIRE(ctx && h_bad && cols >= 1 && (index_itemsize == 4 || index_itemsize == 8), "uq_scatter_rows: bad argument");
+    *h_bad = UQ_NONE;
+    if (n == 0) return 0;
+    UQ_REQUIRE(d_values && d_index && d_out, "uq_scatter_rows: null buffer");
+    void* scr;
+    UQ_TRY(uq_scratch(ctx, 256, &scr));
+    UQ_CHECK_HIP(hipMemsetAsync(scr, 0xFF, 8, ctx->stream));
+    const uint32_t lpr = cols <= 4 ? 1u : (cols <= 8 ? 2u : (cols <= 16 ? 4u : (cols <= 64 ? 16u : 64u)));
+    const uint32_t blocks = blocks_of(n * lpr);
+    if (index_itemsize == 4) scatter_rows_kernel<uint32_t><<<blocks, RT, 0, ctx->stream>>>(d_values, n, cols, (const uint32_t*)d_index, base, out_rows, d_out, (unsigned long long*)scr);
+    else scatter_rows_kernel<long long><<<blocks, RT, 0, ctx->stream>>>(d_values, n, cols, (const long long*)d_index, base, out_rows, d_out, (unsigned long long*)scr);
+    UQ_LAUNCH_CHECK();
+    UQ_TRY(uq_read_back(ctx, ctx->h_pinned, scr, 8));
+    UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    *h_bad = ctx->h_pinned[0];
+    return 0;
+}
 
 extern "C" int uq_partition_rows(uq_ctx* ctx, const uint8_t* d_splitters, uint32_t nsplit, uint32_t cols, const uint8_t* d_table, uint64_t rows,
                                  uint64_t row_index_base, uint64_t total_rows, uint8_t* d_dest) {

@@ -197,6 +197,18 @@ class HipRows:
         call('uq_index_affine', self.ctx.h, C.c_void_p(index.data_ptr()), index.element_size(), n, int(add), C.c_void_p(out.data_ptr()), out_itemsize)
         return out
 
+    def scatter_rows(self, values, n, cols, index, base, out_rows):
+        """out[index[j] - base] = row j of `values` (uq_scatter_rows); every row of `out` must be hit exactly once by the caller's contract."""
+        from ._lib import call
+        t = self.torch
+        out = t.empty(out_rows * cols, dtype=t.uint8, device=self.device)
+        bad = C.c_uint64()
+        call('uq_scatter_rows', self.ctx.h, C.c_void_p(values.data_ptr()), int(n), int(cols), C.c_void_p(index.data_ptr()), index.element_size(), int(base),
+             int(out_rows), C.c_void_p(out.data_ptr()), C.byref(bad))
+        if bad.value != UQ_NONE:
+            raise RuntimeError('row numbers received do not cover the shard (entry %d)' % bad.value)
+        return out
+
     def invert_permutation(self, perm, base=0):
         """inv[perm[j] - base] = j as an int32 tensor (uq_invert_permutation); raises when perm is no permutation of base .. base + n - 1."""
         from ._lib import call
@@ -350,7 +362,7 @@ def dist_scatter_rows(be, values, cols, shard_starts, gidx, group=None):
     n = int(gidx.numel())
     mine = int(shard_starts[rank + 1]) - int(shard_starts[rank])
     if world == 1:
-        return be.gather_rows(values, n, cols, be.invert_permutation(gidx, int(shard_starts[0]))) if n else values
+        return be.scatter_rows(values, n, cols, gidx, int(shard_starts[0]), n) if n else values
     order, sorted_idx, bounds = _route_by_owner(be, shard_starts, gidx, world)
     sorted_vals = be.gather_rows(values, n, cols, order) if n else values
     nsend = [bounds[d + 1] - bounds[d] for d in range(world)]
@@ -358,7 +370,7 @@ def dist_scatter_rows(be, values, cols, shard_starts, gidx, group=None):
     rval, _ = exchange_split(sorted_vals, [k * cols for k in nsend], dist, torch, be.device, torch.uint8, group, rcounts=[k * cols for k in nrecv])
     if int(ridx.numel()) != mine:
         raise RuntimeError('dist_scatter_rows: received %d rows for a shard of %d' % (int(ridx.numel()), mine))
-    return be.gather_rows(rval, mine, cols, be.invert_permutation(ridx, int(shard_starts[rank]))) if mine else rval
+    return be.scatter_rows(rval, mine, cols, ridx, int(shard_starts[rank]), mine) if mine else rval
 
 
 def dist_gather_rows(be, table, rows, cols, shard_starts, gidx, group=None):
