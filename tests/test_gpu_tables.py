@@ -347,6 +347,55 @@ def test_decode_fastq_is_the_input_and_the_two_pass_text(ctx, name, n, length, k
         assert text is None and bad == 7
 
 
+@pytest.mark.parametrize('L', [8, 40, 65, 66, 73, 100, 150, 152, 250, 303, 700], ids=lambda v: 'L%d' % v)
+@pytest.mark.parametrize('with_n', [False, True], ids=['acgt', 'n-trick'])
+def test_decode_fixed_lengths_chunks_per_lane(ctx, L, with_n):
+    """Fixed-length tables on both sides of the length where the tile kernel's lanes take five 8-character chunks of a line instead of one
+    (66 characters): the text is the input; then the same tables with random bytes for quality rows -- codes beyond the alphabet, which no encoder
+    writes -- decode to the same text through both decoders (such a code becomes byte 0, as through the tables)."""
+    from uq_amd import qname
+    rng = np.random.default_rng(L * 2 + with_n)
+    n = 1500
+    recs = []
+    for i in range(n):
+        seq = rng.choice(np.frombuffer(b'ACGT', np.uint8), L)
+        q = rng.integers(38, 38 + 41, L).astype(np.uint8)
+        if with_n:
+            at = rng.random(L) < 0.03
+            seq[at] = ord('N'); q[at] = 35
+        recs.append(b'@m%d:%d:%d\n' % (i % 7, i, int(rng.integers(0, 10 ** int(rng.integers(1, 9))))) + bytes(seq) + b'\n+\n' + bytes(q) + b'\n')
+    host = np.frombuffer(b''.join(recs), dtype=np.uint8)
+    hls = oracle_c.index_lines(host)
+    st = oracle_c.stats(host, hls, 0, n)
+    d = O.decide(O.histogram_to_static_qualities(st['counts'], st['first_seen']), st['len_min'], st['len_max'])
+    assert not d['variable_read_lengths'] and d['bits_per_quality'] == 6 and bool(d['N_qual']) == with_n
+    rd, rq, _ = oracle_c.pack(host, hls, 0, n, d['bases'], d['qualities'], d['N_qual'], d['bits_per_base'], d['bits_per_quality'],
+                              d['variable_read_lengths'], d['dna_bytes_per_row'], d['quality_bytes_per_row'])
+    prefix, suffix, separators, columns, arrays = qname.analyse(qname.qname_lines(host, hls, n))
+    cfg = dict(bases=d['bases'], qualities=d['qualities'], N_qual=d['N_qual'], bits_per_base=d['bits_per_base'],
+               bits_per_quality=d['bits_per_quality'], variable_read_lengths=d['variable_read_lengths'], dna_max=d['dna_max'],
+               QNAME_prefix=prefix, QNAME_suffix=suffix, QNAME_separators=separators, QNAME_columns=columns)
+    cols = [_dev(ctx, np.ascontiguousarray(a)) for a in arrays]
+    ops.scribble_lds(ctx, 0xA5A5A5A5)
+    text, bad = ops.decode_fastq(ctx, cfg, cols, _dev(ctx, rd.ravel()), _dev(ctx, rq.ravel()), n)
+    assert bad is None
+    assert ctx.to_numpy(text).tobytes() == host.tobytes()
+    rq2 = rq.copy()
+    rows = rng.random(n) < 0.3
+    rq2[rows] = rng.integers(0, 256, size=(int(rows.sum()), rq.shape[1])).astype(np.uint8)
+    dq2 = _dev(ctx, rq2.ravel())
+    text2, bad = ops.decode_fastq(ctx, cfg, cols, _dev(ctx, rd.ravel()), dq2, n)
+    seq, qt, ln, ubad = ops.unpack(ctx, _dev(ctx, rd.ravel()), dq2, n, ops.make_unpack_params(cfg))
+    two = ops.emit_fastq(ctx, cfg, cols, seq, qt, ln, n)
+    a, b = ctx.to_numpy(text2), ctx.to_numpy(two)
+    assert a.tobytes() == b.tobytes()
+    assert (a == 0).any()                      # 23 of the 64 codes are beyond the alphabet
+    keep = ~np.repeat(rows, 1)                 # the rows left alone still decode to the input
+    offs = hls[::4]
+    for r in np.flatnonzero(keep)[:200]:
+        assert a[offs[r]:offs[r + 1]].tobytes() == host[offs[r]:offs[r + 1]].tobytes()
+
+
 @pytest.mark.parametrize('variable', [False, True], ids=['fixed', 'variable'])
 @pytest.mark.parametrize('with_n', [False, True, 'six'], ids=['acgt', 'n-trick', 'six-bases'])
 @pytest.mark.parametrize('nq', [3, 4, 6, 12, 20, 41, 70], ids=lambda v: 'q%d' % v)

@@ -130,8 +130,13 @@ __device__ void emit_record_direct(const EmitGeom& g, const uint8_t* __restrict_
 //                  unpack_pipe_kernel).  The 2 x dna_max bytes per read of intermediate text never exist.
 //   3  the LDS image is stored to HBM: it mirrors the destination's 16-byte phase, so all interior stores are
 //      aligned uint4
+#ifndef UQ_EXP
+#define UQ_EXP 0
+#endif
 constexpr int EM_THREADS = 256;
 constexpr uint32_t EM_RMAX = 64;
+constexpr int DE_K = 5;                  // chunks per lane of the fixed-length instances
+constexpr int DS_K = 4;                  // groups per lane of decode_stream_kernel's instances
 constexpr int DE_NVD = 2, DE_NVQ = 3;    // 16-byte vectors per lane of packed rows in flight: DNA rows <= 8 KiB, QUAL rows <= 12 KiB per tile
 constexpr uint32_t EM_BUDGET_TEXT = 19 * 1024, EM_BUDGET_PACKED = 36 * 1024;   // dynamic LDS per workgroup (the registers allow four workgroups per CU)
 
@@ -140,7 +145,8 @@ struct TileGeom {
     uint32_t o_off, o_len, o_flen, o_ind, o_inq;                 // LDS byte offsets behind the image
     uint32_t magicP;                                             // magic_u32(prefix_len)
     uint32_t bd, bq, Cd, Cq, G, magicG;                          // packed form: row geometry, G = 8-symbol groups per read
-    uint32_t variable, NC, magicNC, o_cum, RS;                   // fixed length: NC = chunks a line can touch, RS = reads a workgroup-step covers (EM_THREADS / NC)
+    uint32_t variable, NC, magicNC, o_cum, RS;                   // fixed length: NC = lanes per line (the chunks a line can touch, or pieces of K chunks), RS = reads a workgroup-step covers (EM_THREADS / NC)
+    uint32_t K;                                                  // chunks per lane (emit_tile_kernel<.., K>)
     FastAlphabet fa;
 };
 struct NoLut {};
@@ -197,6 +203,67 @@ __device__ __forceinline__ void qual_codes8(uint32_t bq, const uint8_t* tile, ui
         default: qual_codes8<7>(tile, end, t0, qlo, qhi); break;
     }
 }
+// ---- K chunks (8 K symbols) per lane: one window, one selector and one shift for all of them.  A lane that owns eight characters pays
+// ~ 25 instructions of addressing / alignment per line on top of ~ 35 of field extraction; with K = 5 the first part is paid once per
+// forty characters (emit_tile_kernel<.., K>: 10 M x 150 bp 1.50 -> see DESIGN 10).
+// B-bit codes of the symbols t0 + 8 K - 1 .. t0 of the row whose last byte is tile[end], as K chunks in TEXT order: byte k of (lo[c], hi[c]) =
+// the code of text byte k of chunk c.  Reads up to 4 * ND + 3 bytes in front of the window's last byte: inside the rows' carve (plan_tile's slack).
+// ALIGNED: t0 is a multiple of 8 (the window ends on a byte: no shift).
+template <int B, int K, bool ALIGNED = false>
+__device__ __forceinline__ void codes_piece(const uint8_t* tile, uint32_t end, int32_t t0, uint32_t (&lo)[K], uint32_t (&hi)[K]) {
+    constexpr int TB = 8 * K * B, NB = TB / 8 + 1, ND = (NB + 3) / 4, NV = (TB + 31) / 32;
+    static_assert(NV <= ND && 4 * B <= 28, "codes_piece: window");
+    const int32_t b0 = __mul24(B, t0);
+    const uint32_t a0 = (uint32_t)((int32_t)end - (4 * ND - 1) - (b0 >> 3));
+    const uint32_t* q = (const uint32_t*)(tile + (a0 & ~3u));
+    const uint32_t sel = be_selector(a0), sh = (uint32_t)b0 & 7u;
+    uint32_t d[ND + 1], W[ND], V[NV];
+#pragma unroll
+    for (int k = 0; k <= ND; ++k) d[k] = q[k];
+#pragma unroll
+    for (int k = 0; k < ND; ++k) W[k] = __builtin_amdgcn_perm(d[k + 1], d[k], sel);          // big-endian dwords, most significant first
+#pragma unroll
+    for (int i = 0; i < NV; ++i) V[i] = ALIGNED ? W[ND - 1 - i] : ND - 2 - i >= 0 ? __builtin_amdgcn_alignbit(W[ND - 2 - i >= 0 ? ND - 2 - i : 0], W[ND - 1 - i], sh) : W[ND - 1 - i] >> sh;
+    constexpr uint32_t M = (1u << B) - 1u;
+#pragma unroll
+    for (int f = 0; f < 2 * K; ++f) {                      // four symbols t0 + 4 f .. + 3: bits 4 B f .. of V
+        const int idx = (4 * B * f) / 32, s = (4 * B * f) % 32;
+        const uint32_t x = s == 0 ? V[idx] : (idx + 1 < NV ? __builtin_amdgcn_alignbit(V[idx + 1 < NV ? idx + 1 : idx], V[idx], s) : V[idx] >> s);
+        // the four B-bit fields into bytes in two steps (pairs into 16-bit halves, then each pair apart), then the bytes reversed: text order is
+        // most significant first
+        constexpr uint32_t M2 = (1u << (2 * B)) - 1u;
+        const uint32_t t = (x & M2) | ((x << (16 - 2 * B)) & (M2 << 16));
+        const uint32_t y = (t & (M * 0x00010001u)) | ((t << (8 - B)) & (M * 0x01000100u));
+#if UQ_EXP & 32
+        const uint32_t o = ((x >> (3 * B)) & M) | (((x >> (2 * B)) & M) << 8) | (((x >> B) & M) << 16) | ((x & M) << 24);
+#else
+        const uint32_t o = __builtin_amdgcn_perm(0u, y, 0x00010203u);
+#endif
+        if (f & 1) lo[K - 1 - f / 2] = o; else hi[K - 1 - f / 2] = o;
+    }
+}
+// the same for 2-bit base codes (spread2 is cheaper than four field extractions)
+template <int K, bool ALIGNED = false>
+__device__ __forceinline__ void dna_piece(const uint8_t* tile, uint32_t end, int32_t t0, uint32_t (&lo)[K], uint32_t (&hi)[K]) {
+    constexpr int TB = 16 * K, NB = TB / 8 + 1, ND = (NB + 3) / 4, NV = (TB + 31) / 32;
+    const int32_t b0 = 2 * t0;
+    const uint32_t a0 = (uint32_t)((int32_t)end - (4 * ND - 1) - (b0 >> 3));
+    const uint32_t* q = (const uint32_t*)(tile + (a0 & ~3u));
+    const uint32_t sel = be_selector(a0), sh = (uint32_t)b0 & 7u;
+    uint32_t d[ND + 1], W[ND], V[NV];
+#pragma unroll
+    for (int k = 0; k <= ND; ++k) d[k] = q[k];
+#pragma unroll
+    for (int k = 0; k < ND; ++k) W[k] = __builtin_amdgcn_perm(d[k + 1], d[k], sel);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) V[i] = ALIGNED ? W[ND - 1 - i] : ND - 2 - i >= 0 ? __builtin_amdgcn_alignbit(W[ND - 2 - i >= 0 ? ND - 2 - i : 0], W[ND - 1 - i], sh) : W[ND - 1 - i] >> sh;
+#pragma unroll
+    for (int c = 0; c < K; ++c) {
+        const int bit = 16 * (K - 1 - c);
+        const uint32_t w = V[bit / 32] >> (bit % 32);
+        lo[c] = spread2((w >> 8) & 0xFFu); hi[c] = spread2(w & 0xFFu);
+    }
+}
 // one symbol through the tables: t = its index from the END of the read (rows are right-aligned)
 __device__ __forceinline__ void decode_symbol(const uint8_t* drow, const uint8_t* qrow, const TileGeom& tg, uint32_t t, const uint8_t* l_base,
                                               const uint8_t* l_qual, const uint8_t* l_qn, uint8_t& cb, uint8_t& cc) {
@@ -230,7 +297,7 @@ __device__ void decode_record_direct(const EmitGeom& g, const TileGeom& tg, cons
 // BQ / HASN: the packed form's lookup-free path with the quality width and the N-trick known at compile time (fixed-length tables
 // whose chunk loop has the per-lane mapping: uq_decode_fastq picks the instance) -- no scalar dispatch per chunk, constant shifts:
 // 1.59 -> 1.54 ms for 10 M x 150 bp at 6 bits.  BQ = 0: everything at run time.
-template <bool PACKED, int BQ = 0, bool HASN = false>
+template <bool PACKED, int BQ = 0, bool HASN = false, int K = 1>
 __global__ __launch_bounds__(EM_THREADS, 4) void emit_tile_kernel(EmitGeom g, TileGeom tg, std::conditional_t<PACKED, UnpackLut, NoLut> lut,
                                                                const uint8_t* __restrict__ seq, const uint8_t* __restrict__ qual,
                                                                const uint32_t* __restrict__ len, uint64_t n, const uint64_t* __restrict__ offsets,
@@ -351,6 +418,7 @@ __global__ __launch_bounds__(EM_THREADS, 4) void emit_tile_kernel(EmitGeom g, Ti
         // ro(i + 1) - 2 L - 4 whatever the QNAME was: the three parts below need no barrier between them
         auto ro = [&](uint32_t i) { if constexpr (PACKED && BQ != 0) return cum[i]; else return (uint32_t)(s_off[i] - o0) + skew; };
         // ---- 1b: render the fields, the separators and (lane of the last field) the suffix + '\n'
+        if (!(UQ_EXP & 2))
         for (uint32_t idx = tid; idx < Rt * ncols; idx += EM_THREADS) {
             const uint32_t i = idx / ncols, c = idx - i * ncols;
             uint32_t pos = g.prefix_len;
@@ -374,7 +442,7 @@ __global__ __launch_bounds__(EM_THREADS, 4) void emit_tile_kernel(EmitGeom g, Ti
             }
         }
         if (one_item && ncols) {                          // the prefix: shared out among the record's field lanes
-            if (tid < Rt * ncols) {
+            if (!(UQ_EXP & 4) && tid < Rt * ncols) {
                 const uint32_t i = tid / ncols, c = tid - i * ncols;
                 uint8_t* o = tile + ro(i);
                 for (uint32_t k = c; k < g.prefix_len; k += ncols) o[k] = sg.prefix[k];
@@ -434,6 +502,59 @@ __global__ __launch_bounds__(EM_THREADS, 4) void emit_tile_kernel(EmitGeom g, Ti
                     if (ps >= 0 && ps + 8 <= (int32_t)L) *(uint64_t*)(tile + (ds & ~7u) + 8 * j) = seq8(r, L, ps);
                     if (pq >= 0 && pq + 8 <= (int32_t)L) *(uint64_t*)(tile + (dq & ~7u) + 8 * j) = qual8(r, L, pq);
                 };
+                // K chunks of both lines of read r (K > 1: my_j counts pieces of K chunks)
+                auto pieces = [&](uint32_t r, uint32_t m, uint32_t L) {
+                    if constexpr (K > 1 && BQ != 0) {
+                        const uint32_t e = ro(r + 1), ds = e - 2 * L - 4, dq = e - L - 1;
+                        const int32_t ps = (int32_t)(8 * K * m) - (int32_t)(ds & 7u), pq = (int32_t)(8 * K * m) - (int32_t)(dq & 7u);
+                        const uint32_t endd = od + __umul24(r, tg.Cd), endq = oq + __umul24(r, tg.Cq);
+                        uint32_t lo[K], hi[K];
+                        if (ps + 8 * K > 0 && ps < (int32_t)L) {
+                            const int32_t t0 = (int32_t)L - 8 * K - ps;
+                            if (fa.bd == 2) dna_piece<K>(tile, endd, t0, lo, hi); else codes_piece<3, K>(tile, endd, t0, lo, hi);
+                            uint32_t nlo[K], nhi[K];
+                            if constexpr (HASN) codes_piece<BQ, K>(tile, endq, t0, nlo, nhi);
+                            uint8_t* base = tile + (ds & ~7u) + 8 * K * m;
+#pragma unroll
+                            for (int c = 0; c < K; ++c) {
+                                uint32_t blo = __builtin_amdgcn_perm(fa.base_tab_hi, fa.base_tab, lo[c]), bhi = __builtin_amdgcn_perm(fa.base_tab_hi, fa.base_tab, hi[c]);
+                                if constexpr (HASN) {
+                                    const uint32_t mlo = ~nonzero_bytes(nlo[c] ^ fa.n_code4), mhi = ~nonzero_bytes(nhi[c] ^ fa.n_code4);
+                                    blo = bfi(mlo, fa.n_char4, blo); bhi = bfi(mhi, fa.n_char4, bhi);
+                                }
+                                const int32_t p = ps + 8 * c;
+                                if (p >= 0 && p + 8 <= (int32_t)L) *(uint64_t*)(base + 8 * c) = ((uint64_t)bhi << 32) | blo;
+                            }
+                        }
+                        if (pq + 8 * K > 0 && pq < (int32_t)L) {
+                            codes_piece<BQ, K>(tile, endq, (int32_t)L - 8 * K - pq, lo, hi);
+                            uint8_t* base = tile + (dq & ~7u) + 8 * K * m;
+                            uint32_t over = 0;                                     // bit 7 of a byte: a code beyond the alphabet in one of the chunks stored
+#pragma unroll
+                            for (int c = 0; c < K; ++c) {
+                                const int32_t p = pq + 8 * c;
+                                if (p >= 0 && p + 8 <= (int32_t)L) {
+                                    over |= (lo[c] + fa.q_over) | (hi[c] + fa.q_over);
+                                    *(uint64_t*)(base + 8 * c) = ((uint64_t)(hi[c] + fa.qmin4) << 32) | (lo[c] + fa.qmin4);
+                                }
+                            }
+                            if ((UQ_EXP & 64) || (over & 0x80808080u)) {                              // (no encoder writes such a table) those codes decode to 0, as through the tables
+#pragma unroll
+                                for (int c = 0; c < K; ++c) {
+                                    uint32_t qlo = lo[c], qhi = hi[c];
+                                    uint32_t olo = (qlo + fa.q_over) & 0x80808080u, ohi = (qhi + fa.q_over) & 0x80808080u;
+                                    olo |= olo - (olo >> 7); ohi |= ohi - (ohi >> 7);
+                                    qlo = (qlo + fa.qmin4) & ~olo; qhi = (qhi + fa.qmin4) & ~ohi;
+                                    const int32_t p = pq + 8 * c;
+                                    if (p >= 0 && p + 8 <= (int32_t)L) *(uint64_t*)(base + 8 * c) = ((uint64_t)qhi << 32) | qlo;
+                                }
+                            }
+                        }
+                    }
+                };
+                if (K > 1) {
+                    if (!(UQ_EXP & 1) && my_slot < tg.RS) for (uint32_t r = my_slot; r < Rt; r += tg.RS) pieces(r, my_j, g.dna_max);
+                } else
                 if (BQ == 0 && (tg.variable || tg.RS == 0)) {  // (RS = 0: fixed-length reads of more chunks than the workgroup has lanes)
                     // flat over the tile: item = (read, chunk) in the order of cum[] (the running count of chunks, left by wave 0
                     // before the first barrier)
@@ -444,7 +565,7 @@ __global__ __launch_bounds__(EM_THREADS, 4) void emit_tile_kernel(EmitGeom g, Ti
                         for (int it = 0; it < 6; ++it) { const uint32_t mid = (r + hi) >> 1; if (cum[mid] <= item) r = mid; else hi = mid; }
                         chunks(r, item - cum[r], s_len[r]);
                     }
-                } else if (my_slot < tg.RS) {
+                } else if (!(UQ_EXP & 1) && my_slot < tg.RS) {
                     // fixed length: a lane keeps its chunk number for the whole kernel (my_slot, my_j = tid / NC, tid % NC) and
                     // walks over the reads my_slot, my_slot + RS, ...
                     for (uint32_t r = my_slot; r < Rt; r += tg.RS) chunks(r, my_j, g.dna_max);
@@ -455,7 +576,7 @@ __global__ __launch_bounds__(EM_THREADS, 4) void emit_tile_kernel(EmitGeom g, Ti
                 static_assert(EM_THREADS == 4 * 64 && EM_RMAX <= 64, "the edge pass is one step of four waves");
                 do {
                     const uint32_t i = lane, w = tid >> 6;
-                    if (i >= Rt) continue;
+                    if ((UQ_EXP & 8) || i >= Rt) continue;
                     const uint32_t L = s_len[i], e = ro(i + 1);
                     const uint32_t d = w < 2 ? e - 2 * L - 4 : e - L - 1;
                     if (w == 0) { tile[d + L] = '\n'; tile[d + L + 1] = '+'; tile[d + L + 2] = '\n'; tile[d + 2 * L + 3] = '\n'; }
@@ -548,7 +669,7 @@ __global__ __launch_bounds__(EM_THREADS, 4) void emit_tile_kernel(EmitGeom g, Ti
             uint8_t* dst = out + o0 - skew;                            // 16-byte aligned
             const uint32_t endb = skew + (uint32_t)span;
             const uint32_t v0 = skew ? 1u : 0u, v1 = endb >> 4;         // full vectors [v0, v1)
-            for (uint32_t v = v0 + tid; v < v1; v += EM_THREADS) ((uint4*)dst)[v] = ((const uint4*)tile)[v];
+            if (!(UQ_EXP & 16)) for (uint32_t v = v0 + tid; v < v1; v += EM_THREADS) ((uint4*)dst)[v] = ((const uint4*)tile)[v];
             if (skew) for (uint32_t b = skew + tid; b < 16 && b < endb; b += EM_THREADS) dst[b] = tile[b];
             if (v1 >= v0) for (uint32_t b = (v1 << 4) + tid; b < endb; b += EM_THREADS) dst[b] = tile[b];
         }
@@ -604,7 +725,7 @@ __device__ __forceinline__ void store_low_bytes(uint8_t* p, uint64_t v, uint32_t
     if (nb & 1u) *p = (uint8_t)v;
 }
 
-template <int BQ = 0, bool HASN = false>
+template <int BQ = 0, bool HASN = false, int K = 1>
 __global__ __launch_bounds__(EM_THREADS, 4) void decode_stream_kernel(EmitGeom g, StreamGeom tg, const uint8_t* __restrict__ dna, const uint8_t* __restrict__ qual,
                                                                    const uint32_t* __restrict__ len, uint64_t n, const uint64_t* __restrict__ offsets,
                                                                    uint8_t* __restrict__ out) {
@@ -669,7 +790,7 @@ __global__ __launch_bounds__(EM_THREADS, 4) void decode_stream_kernel(EmitGeom g
         if (tid < 64) {                                   // wave 0 holds every offset and length of the tile (R <= 63): two running sums
             const uint32_t lo1 = __shfl_down((uint32_t)cur.off, 1, 64);               // record sizes fit 32 bits
             const uint32_t size = lo1 - (uint32_t)cur.off;
-            uint32_t v = tid < Rt ? cur.L >> 3 : 0u;
+            uint32_t v = tid < Rt ? ((cur.L >> 3) + (K - 1)) / K : 0u;                // items: pieces of K whole groups (the one at the line's front may hold fewer)
             uint32_t q = tid < Rt ? (size - 2u * cur.L - 4u + 7u) & ~7u : 0u;        // the QNAME line with its '\n', rounded up
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
@@ -701,7 +822,7 @@ __global__ __launch_bounds__(EM_THREADS, 4) void decode_stream_kernel(EmitGeom g
         __syncthreads();
         nx = fetch(t + gridDim.x);
         nr = fetch_rows(t + gridDim.x);
-        const bool staged = qst[Rt] <= tg.qcap;           // else (QNAME lines far beyond what the staging was sized for): a wave per line, straight out
+        const bool staged = !(UQ_EXP & 256) && qst[Rt] <= tg.qcap;           // else (QNAME lines far beyond what the staging was sized for): a wave per line, straight out
         // ---- QNAME lines -> staging: render the fields, the separators and (lane of the last field) the suffix + '\n'
         if (staged) {
             for (uint32_t idx = tid; idx < Rt * ncols; idx += EM_THREADS) {
@@ -747,12 +868,61 @@ __global__ __launch_bounds__(EM_THREADS, 4) void decode_stream_kernel(EmitGeom g
         const uint32_t od = tg.o_ind + skd + tg.Cd - 1, oq = tg.o_inq + skq + tg.Cq - 1;      // last byte of row 0
         if (tg.variable || tg.RS == 0) {                  // (RS = 0: fixed-length reads of more groups than the workgroup has lanes)
             // flat over the tile: item = (read, group) in the order of cum[]
-            const uint32_t total = cum[Rt];
+            const uint32_t total = (UQ_EXP & 128) ? 0u : cum[Rt];
             for (uint32_t item = tid; item < total; item += EM_THREADS) {
                 uint32_t r = 0, hi = Rt;                                 // largest r with cum[r] <= item
 #pragma unroll
                 for (int it = 0; it < 6; ++it) { const uint32_t mid = (r + hi) >> 1; if (cum[mid] <= item) r = mid; else hi = mid; }
                 const uint32_t wg = cum[r + 1] - 1 - item, L = s_len[r];     // addresses rise with the lane
+                if constexpr (K > 1 && BQ != 0) {
+                    // K groups a lane: one window per row, 8 K contiguous characters of each line (the stores of a full piece are 16 bytes wide)
+                    const uint32_t have = (L >> 3) - K * wg, nv = have < (uint32_t)K ? have : (uint32_t)K;       // groups of the piece inside the read
+                    const uint32_t endd = od + __umul24(r, tg.Cd), endq = oq + __umul24(r, tg.Cq);
+                    const FastAlphabet& fa = tg.fa;
+                    uint32_t blo[K], bhi[K], qlo[K], qhi[K];
+                    if (fa.bd == 2) dna_piece<K, true>(tile, endd, (int32_t)(8 * K * wg), blo, bhi); else codes_piece<3, K, true>(tile, endd, (int32_t)(8 * K * wg), blo, bhi);
+                    codes_piece<BQ, K, true>(tile, endq, (int32_t)(8 * K * wg), qlo, qhi);
+                    uint32_t over = 0;
+#pragma unroll
+                    for (int c = 0; c < K; ++c) {
+                        blo[c] = __builtin_amdgcn_perm(fa.base_tab_hi, fa.base_tab, blo[c]); bhi[c] = __builtin_amdgcn_perm(fa.base_tab_hi, fa.base_tab, bhi[c]);
+                        if constexpr (HASN) {
+                            const uint32_t mlo = ~nonzero_bytes(qlo[c] ^ fa.n_code4), mhi = ~nonzero_bytes(qhi[c] ^ fa.n_code4);
+                            blo[c] = bfi(mlo, fa.n_char4, blo[c]); bhi[c] = bfi(mhi, fa.n_char4, bhi[c]);
+                        }
+                        over |= (qlo[c] + fa.q_over) | (qhi[c] + fa.q_over);
+                    }
+                    if (over & 0x80808080u) {                                // a code beyond the alphabet (no encoder writes one; the bits in front of a short piece may look like one) decodes to 0
+#pragma unroll
+                        for (int c = 0; c < K; ++c) {
+                            uint32_t olo = (qlo[c] + fa.q_over) & 0x80808080u, ohi = (qhi[c] + fa.q_over) & 0x80808080u;
+                            olo |= olo - (olo >> 7); ohi |= ohi - (ohi >> 7);
+                            qlo[c] = (qlo[c] + fa.qmin4) & ~olo; qhi[c] = (qhi[c] + fa.qmin4) & ~ohi;
+                        }
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < K; ++c) { qlo[c] += fa.qmin4; qhi[c] += fa.qmin4; }
+                    }
+                    if ((UQ_EXP & 1024) && over != 0x12345u) continue;
+                    uint8_t* ts = out + s_off[r + 1] - (L + 8 * K * (wg + 1) + 4);      // chunk c of the piece: SEQ at ts + 8 c, QUAL at ts + L + 3 + 8 c
+                    if (nv == (uint32_t)K) {
+                        uint32_t vb[2 * K], vq[2 * K];
+#pragma unroll
+                        for (int c = 0; c < K; ++c) { vb[2 * c] = blo[c]; vb[2 * c + 1] = bhi[c]; vq[2 * c] = qlo[c]; vq[2 * c + 1] = qhi[c]; }
+                        __builtin_memcpy(ts, vb, 8 * K);
+                        __builtin_memcpy(ts + L + 3, vq, 8 * K);
+                    } else {
+#pragma unroll
+                        for (int c = 1; c < K; ++c) {
+                            if ((uint32_t)c >= (uint32_t)K - nv) {
+                                const uint64_t b = ((uint64_t)bhi[c] << 32) | blo[c], q = ((uint64_t)qhi[c] << 32) | qlo[c];
+                                __builtin_memcpy(ts + 8 * c, &b, 8);
+                                __builtin_memcpy(ts + L + 3 + 8 * c, &q, 8);
+                            }
+                        }
+                    }
+                    continue;
+                }
                 uint64_t vb, vq;
                 group_text<BQ, HASN>(tile, tg, od + __umul24(r, tg.Cd), oq + __umul24(r, tg.Cq), (int32_t)(8 * wg), vb, vq);
                 uint8_t* ts = out + s_off[r + 1] - (L + 8 * wg + 12);    // line start = record end - 2 L - 4, the group at + L - 8 wg - 8
@@ -774,6 +944,7 @@ __global__ __launch_bounds__(EM_THREADS, 4) void decode_stream_kernel(EmitGeom g
         }
         // ---- a lane per read: the L % 8 characters at the front of the two lines (their row bytes are read like a group's: what
         // lies before them decodes to characters that are not stored), and the separators
+        if (!(UQ_EXP & 512))
         for (uint32_t i = tid; i < Rt; i += EM_THREADS) {
             const uint32_t L = s_len[i], nsym = L & 7u;
             uint8_t* ts = out + s_off[i + 1] - (2 * L + 4);
@@ -803,7 +974,7 @@ __global__ __launch_bounds__(EM_THREADS, 4) void decode_stream_kernel(EmitGeom g
                     else store_low_bytes(out + o + c, v, q - c);
                 }
             }
-        } else {
+        } else if (!(UQ_EXP & 256)) {
             for (uint32_t i = tid >> 6; i < Rt; i += EM_THREADS / 64) emit_qname_direct(g, out + s_off[i], r0 + i, lane);
         }
     }
@@ -924,7 +1095,7 @@ size_t plan_tile(TileGeom& tg, uint64_t avg, const EmitGeom& g, bool packed) {
     tg.o_off = carve((tg.R + 1) * 8); tg.o_len = carve(tg.R * 4); tg.o_cum = carve((tg.R + 2) * 4);
     tg.o_flen = carve(tg.R * (ncols ? ncols : 1) * 2);
     tg.o_ind = tg.o_inq = 0;
-    if (packed && fits) { tg.o_ind = carve(tg.R * tg.Cd + 32); tg.o_inq = carve(tg.R * tg.Cq + 32); }
+    if (packed && fits) { tg.o_ind = carve(tg.R * tg.Cd + 64); tg.o_inq = carve(tg.R * tg.Cq + 64); }      // (the windows of a line's edge pieces reach up to 40 bytes beyond the last row)
     return off;
 }
 
@@ -1014,9 +1185,12 @@ extern "C" int uq_decode_fastq(uq_ctx* ctx, const uq_emit_params* hp, const uq_u
     UQ_REQUIRE(tg.Cd == (tg.bd * Lv + 7) / 8 && tg.Cq == (tg.bq * Lv + 7) / 8, "uq_decode_fastq: row bytes do not match the geometry");
     tg.G = (up->dna_max + 7) / 8;
     tg.magicG = magic_u32(tg.G);
-    tg.variable = variable; tg.NC = (up->dna_max + 14) / 8; tg.magicNC = magic_u32(tg.NC);
-    tg.RS = EM_THREADS / tg.NC;
     tg.fa = fast_alphabet(up);
+    tg.variable = variable; tg.NC = (up->dna_max + 14) / 8; tg.K = 1;
+    // pieces of DE_K chunks per lane where a line has enough of them to keep the lanes busy (fixed lengths of 66 characters and more)
+    if (tg.fa.fast && !variable && tg.bq >= 2 && tg.bq <= 6 && tg.NC >= 2 * DE_K) { tg.K = DE_K; tg.NC = (tg.NC + DE_K - 1) / DE_K; }
+    tg.magicNC = magic_u32(tg.NC);
+    tg.RS = EM_THREADS / tg.NC;
     if (nreads == 0) return 0;
     UQ_REQUIRE(d_dna && d_qual && (d_len || !variable), "uq_decode_fastq: null buffer");
     const uint32_t* lens = variable ? d_len : nullptr;       // fixed-length tables: every read is dna_max long
@@ -1046,8 +1220,8 @@ extern "C" int uq_decode_fastq(uq_ctx* ctx, const uq_emit_params* hp, const uq_u
             const uint64_t tiles = (nreads + sg.R - 1) / sg.R;
             const uint32_t tb = tile_blocks(tiles, lds, 4);
 #define UQ_STREAM_CASE(Q) \
-            case Q: if (sg.fa.has_n) decode_stream_kernel<Q, true><<<tb, EM_THREADS, lds, ctx->stream>>>(g, sg, d_dna, d_qual, lens, nreads, d_offsets, d_out); \
-                    else decode_stream_kernel<Q, false><<<tb, EM_THREADS, lds, ctx->stream>>>(g, sg, d_dna, d_qual, lens, nreads, d_offsets, d_out); \
+            case Q: if (sg.fa.has_n) decode_stream_kernel<Q, true, DS_K><<<tb, EM_THREADS, lds, ctx->stream>>>(g, sg, d_dna, d_qual, lens, nreads, d_offsets, d_out); \
+                    else decode_stream_kernel<Q, false, DS_K><<<tb, EM_THREADS, lds, ctx->stream>>>(g, sg, d_dna, d_qual, lens, nreads, d_offsets, d_out); \
                     break;
             switch (sg.bq) {
                 UQ_STREAM_CASE(2) UQ_STREAM_CASE(3) UQ_STREAM_CASE(4) UQ_STREAM_CASE(5) UQ_STREAM_CASE(6)
@@ -1065,7 +1239,10 @@ extern "C" int uq_decode_fastq(uq_ctx* ctx, const uq_emit_params* hp, const uq_u
     const uint32_t tb = tile_blocks(tiles, lds, 4);
     const bool special = tg.fa.fast && !variable && tg.RS != 0 && tg.cap != 0;      // the instances with compile-time quality width
 #define UQ_EMIT_CASE(Q) \
-    case Q: if (tg.fa.has_n) emit_tile_kernel<true, Q, true><<<tb, EM_THREADS, lds, ctx->stream>>>(g, tg, lut, d_dna, d_qual, lens, nreads, d_offsets, d_out); \
+    case Q: if (tg.K > 1) { \
+                if (tg.fa.has_n) emit_tile_kernel<true, Q, true, DE_K><<<tb, EM_THREADS, lds, ctx->stream>>>(g, tg, lut, d_dna, d_qual, lens, nreads, d_offsets, d_out); \
+                else emit_tile_kernel<true, Q, false, DE_K><<<tb, EM_THREADS, lds, ctx->stream>>>(g, tg, lut, d_dna, d_qual, lens, nreads, d_offsets, d_out); \
+            } else if (tg.fa.has_n) emit_tile_kernel<true, Q, true><<<tb, EM_THREADS, lds, ctx->stream>>>(g, tg, lut, d_dna, d_qual, lens, nreads, d_offsets, d_out); \
             else emit_tile_kernel<true, Q, false><<<tb, EM_THREADS, lds, ctx->stream>>>(g, tg, lut, d_dna, d_qual, lens, nreads, d_offsets, d_out); \
             break;
     switch (special ? tg.bq : 0u) {
