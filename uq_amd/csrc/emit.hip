@@ -130,9 +130,6 @@ __device__ void emit_record_direct(const EmitGeom& g, const uint8_t* __restrict_
 //                  unpack_pipe_kernel).  The 2 x dna_max bytes per read of intermediate text never exist.
 //   3  the LDS image is stored to HBM: it mirrors the destination's 16-byte phase, so all interior stores are
 //      aligned uint4
-#ifndef UQ_EXP
-#define UQ_EXP 0
-#endif
 constexpr int EM_THREADS = 256;
 constexpr uint32_t EM_RMAX = 64;
 constexpr int DE_K = 5;                  // chunks per lane of the fixed-length instances
@@ -234,11 +231,7 @@ __device__ __forceinline__ void codes_piece(const uint8_t* tile, uint32_t end, i
         constexpr uint32_t M2 = (1u << (2 * B)) - 1u;
         const uint32_t t = (x & M2) | ((x << (16 - 2 * B)) & (M2 << 16));
         const uint32_t y = (t & (M * 0x00010001u)) | ((t << (8 - B)) & (M * 0x01000100u));
-#if UQ_EXP & 32
-        const uint32_t o = ((x >> (3 * B)) & M) | (((x >> (2 * B)) & M) << 8) | (((x >> B) & M) << 16) | ((x & M) << 24);
-#else
         const uint32_t o = __builtin_amdgcn_perm(0u, y, 0x00010203u);
-#endif
         if (f & 1) lo[K - 1 - f / 2] = o; else hi[K - 1 - f / 2] = o;
     }
 }
@@ -418,7 +411,6 @@ __global__ __launch_bounds__(EM_THREADS, 4) void emit_tile_kernel(EmitGeom g, Ti
         // ro(i + 1) - 2 L - 4 whatever the QNAME was: the three parts below need no barrier between them
         auto ro = [&](uint32_t i) { if constexpr (PACKED && BQ != 0) return cum[i]; else return (uint32_t)(s_off[i] - o0) + skew; };
         // ---- 1b: render the fields, the separators and (lane of the last field) the suffix + '\n'
-        if (!(UQ_EXP & 2))
         for (uint32_t idx = tid; idx < Rt * ncols; idx += EM_THREADS) {
             const uint32_t i = idx / ncols, c = idx - i * ncols;
             uint32_t pos = g.prefix_len;
@@ -442,7 +434,7 @@ __global__ __launch_bounds__(EM_THREADS, 4) void emit_tile_kernel(EmitGeom g, Ti
             }
         }
         if (one_item && ncols) {                          // the prefix: shared out among the record's field lanes
-            if (!(UQ_EXP & 4) && tid < Rt * ncols) {
+            if (tid < Rt * ncols) {
                 const uint32_t i = tid / ncols, c = tid - i * ncols;
                 uint8_t* o = tile + ro(i);
                 for (uint32_t k = c; k < g.prefix_len; k += ncols) o[k] = sg.prefix[k];
@@ -538,7 +530,7 @@ __global__ __launch_bounds__(EM_THREADS, 4) void emit_tile_kernel(EmitGeom g, Ti
                                     *(uint64_t*)(base + 8 * c) = ((uint64_t)(hi[c] + fa.qmin4) << 32) | (lo[c] + fa.qmin4);
                                 }
                             }
-                            if ((UQ_EXP & 64) || (over & 0x80808080u)) {                              // (no encoder writes such a table) those codes decode to 0, as through the tables
+                            if (over & 0x80808080u) {                              // (no encoder writes such a table) those codes decode to 0, as through the tables
 #pragma unroll
                                 for (int c = 0; c < K; ++c) {
                                     uint32_t qlo = lo[c], qhi = hi[c];
@@ -553,7 +545,7 @@ __global__ __launch_bounds__(EM_THREADS, 4) void emit_tile_kernel(EmitGeom g, Ti
                     }
                 };
                 if (K > 1) {
-                    if (!(UQ_EXP & 1) && my_slot < tg.RS) for (uint32_t r = my_slot; r < Rt; r += tg.RS) pieces(r, my_j, g.dna_max);
+                    if (my_slot < tg.RS) for (uint32_t r = my_slot; r < Rt; r += tg.RS) pieces(r, my_j, g.dna_max);
                 } else
                 if (BQ == 0 && (tg.variable || tg.RS == 0)) {  // (RS = 0: fixed-length reads of more chunks than the workgroup has lanes)
                     // flat over the tile: item = (read, chunk) in the order of cum[] (the running count of chunks, left by wave 0
@@ -565,7 +557,7 @@ __global__ __launch_bounds__(EM_THREADS, 4) void emit_tile_kernel(EmitGeom g, Ti
                         for (int it = 0; it < 6; ++it) { const uint32_t mid = (r + hi) >> 1; if (cum[mid] <= item) r = mid; else hi = mid; }
                         chunks(r, item - cum[r], s_len[r]);
                     }
-                } else if (!(UQ_EXP & 1) && my_slot < tg.RS) {
+                } else if (my_slot < tg.RS) {
                     // fixed length: a lane keeps its chunk number for the whole kernel (my_slot, my_j = tid / NC, tid % NC) and
                     // walks over the reads my_slot, my_slot + RS, ...
                     for (uint32_t r = my_slot; r < Rt; r += tg.RS) chunks(r, my_j, g.dna_max);
@@ -576,7 +568,7 @@ __global__ __launch_bounds__(EM_THREADS, 4) void emit_tile_kernel(EmitGeom g, Ti
                 static_assert(EM_THREADS == 4 * 64 && EM_RMAX <= 64, "the edge pass is one step of four waves");
                 do {
                     const uint32_t i = lane, w = tid >> 6;
-                    if ((UQ_EXP & 8) || i >= Rt) continue;
+                    if (i >= Rt) continue;
                     const uint32_t L = s_len[i], e = ro(i + 1);
                     const uint32_t d = w < 2 ? e - 2 * L - 4 : e - L - 1;
                     if (w == 0) { tile[d + L] = '\n'; tile[d + L + 1] = '+'; tile[d + L + 2] = '\n'; tile[d + 2 * L + 3] = '\n'; }
@@ -669,7 +661,7 @@ __global__ __launch_bounds__(EM_THREADS, 4) void emit_tile_kernel(EmitGeom g, Ti
             uint8_t* dst = out + o0 - skew;                            // 16-byte aligned
             const uint32_t endb = skew + (uint32_t)span;
             const uint32_t v0 = skew ? 1u : 0u, v1 = endb >> 4;         // full vectors [v0, v1)
-            if (!(UQ_EXP & 16)) for (uint32_t v = v0 + tid; v < v1; v += EM_THREADS) ((uint4*)dst)[v] = ((const uint4*)tile)[v];
+            for (uint32_t v = v0 + tid; v < v1; v += EM_THREADS) ((uint4*)dst)[v] = ((const uint4*)tile)[v];
             if (skew) for (uint32_t b = skew + tid; b < 16 && b < endb; b += EM_THREADS) dst[b] = tile[b];
             if (v1 >= v0) for (uint32_t b = (v1 << 4) + tid; b < endb; b += EM_THREADS) dst[b] = tile[b];
         }
@@ -822,7 +814,7 @@ __global__ __launch_bounds__(EM_THREADS, 4) void decode_stream_kernel(EmitGeom g
         __syncthreads();
         nx = fetch(t + gridDim.x);
         nr = fetch_rows(t + gridDim.x);
-        const bool staged = !(UQ_EXP & 256) && qst[Rt] <= tg.qcap;           // else (QNAME lines far beyond what the staging was sized for): a wave per line, straight out
+        const bool staged = qst[Rt] <= tg.qcap;           // else (QNAME lines far beyond what the staging was sized for): a wave per line, straight out
         // ---- QNAME lines -> staging: render the fields, the separators and (lane of the last field) the suffix + '\n'
         if (staged) {
             for (uint32_t idx = tid; idx < Rt * ncols; idx += EM_THREADS) {
@@ -868,7 +860,7 @@ __global__ __launch_bounds__(EM_THREADS, 4) void decode_stream_kernel(EmitGeom g
         const uint32_t od = tg.o_ind + skd + tg.Cd - 1, oq = tg.o_inq + skq + tg.Cq - 1;      // last byte of row 0
         if (tg.variable || tg.RS == 0) {                  // (RS = 0: fixed-length reads of more groups than the workgroup has lanes)
             // flat over the tile: item = (read, group) in the order of cum[]
-            const uint32_t total = (UQ_EXP & 128) ? 0u : cum[Rt];
+            const uint32_t total = cum[Rt];
             for (uint32_t item = tid; item < total; item += EM_THREADS) {
                 uint32_t r = 0, hi = Rt;                                 // largest r with cum[r] <= item
 #pragma unroll
@@ -903,7 +895,6 @@ __global__ __launch_bounds__(EM_THREADS, 4) void decode_stream_kernel(EmitGeom g
 #pragma unroll
                         for (int c = 0; c < K; ++c) { qlo[c] += fa.qmin4; qhi[c] += fa.qmin4; }
                     }
-                    if ((UQ_EXP & 1024) && over != 0x12345u) continue;
                     uint8_t* ts = out + s_off[r + 1] - (L + 8 * K * (wg + 1) + 4);      // chunk c of the piece: SEQ at ts + 8 c, QUAL at ts + L + 3 + 8 c
                     if (nv == (uint32_t)K) {
                         uint32_t vb[2 * K], vq[2 * K];
@@ -944,7 +935,6 @@ __global__ __launch_bounds__(EM_THREADS, 4) void decode_stream_kernel(EmitGeom g
         }
         // ---- a lane per read: the L % 8 characters at the front of the two lines (their row bytes are read like a group's: what
         // lies before them decodes to characters that are not stored), and the separators
-        if (!(UQ_EXP & 512))
         for (uint32_t i = tid; i < Rt; i += EM_THREADS) {
             const uint32_t L = s_len[i], nsym = L & 7u;
             uint8_t* ts = out + s_off[i + 1] - (2 * L + 4);
@@ -974,7 +964,7 @@ __global__ __launch_bounds__(EM_THREADS, 4) void decode_stream_kernel(EmitGeom g
                     else store_low_bytes(out + o + c, v, q - c);
                 }
             }
-        } else if (!(UQ_EXP & 256)) {
+        } else {
             for (uint32_t i = tid >> 6; i < Rt; i += EM_THREADS / 64) emit_qname_direct(g, out + s_off[i], r0 + i, lane);
         }
     }
