@@ -201,7 +201,9 @@ def main():
                     guess, rpb = g
                     cap_reads = int(fastq_bytes * rpb * 1.02) + 1024
                     guess.avg_record_bytes = int(1.0 / rpb)                     # tile sizing hint: the head's own records
-                    ls_cap = ls_async = ops.index_lines_async(ctx, d_buf, 4 * cap_reads)
+                    # the record index (8 B a line) is only expanded when a kernel of the step needs it: the pack kernel with the QNAME
+                    # phase and the QNAME sample walk the census's newline lists themselves (csrc/lines.h)
+                    ls_cap = ls_async = None if qname_in_step else ops.index_lines_async(ctx, d_buf, 4 * cap_reads)
                     if qname_in_step:
                         # the QNAME passes ride in the pack kernel: layout guessed on the device from a sample of the reads (queued here,
                         # behind the index), verified on every read while the fields are parsed; distinct counts queued behind it
@@ -221,7 +223,7 @@ def main():
                 if not ok: nlines = ops.count_lines(ctx, d_buf)         # a tile's newline list overflowed: the bitmap form
                 nreads = nlines // 4
                 if good:
-                    ls = queued[0][:nlines + 1]
+                    ls = queued[0][:nlines + 1] if queued[0] is not None else None      # None: expanded on demand (index() below)
                     dq = queued[1]
                     spec = (dq[0][:nreads * guess.dna_bytes_per_row], dq[1][:nreads * guess.quality_bytes_per_row], dq[2], dq[3])
                     st = dq[3]
@@ -242,9 +244,12 @@ def main():
                 st = ops.stats_new(ctx)
                 ops.stats_accumulate(ctx, st, d_buf, ls, 0, nreads)
                 hs = fetch(st)                                            # N > 1: the all-reduce of the statistics
+            def index():                                              # the expanded index, for the kernels that take one (fallbacks)
+                return ls if ls is not None else ops.index_lines(ctx, d_buf, nlines)
             if hs.incomplete:                                         # the speculative pass met something outside its guess
                 spec = None
                 st = ops.stats_new(ctx)
+                ls = index()
                 ops.stats_accumulate(ctx, st, d_buf, ls, 0, nreads)
                 hs = fetch(st)
             if hs.bad_plus is not None or hs.bad_len is not None:
@@ -258,6 +263,7 @@ def main():
                 qres = qname_device.analyse_fused(ctx, fq, nreads) if (fq is not None and spec is not None) else None
                 qpath = 'fused into the pack kernel'
                 if qres is None:
+                    ls = index()
                     qres = qname_device.analyse_device(ctx, d_buf, ls, nreads)
                     qpath = 'exact kernels (layout, tokeniser)'
                 if qres is None: raise RuntimeError('the synthetic QNAMEs are outside the device subset')
@@ -267,12 +273,13 @@ def main():
                 kernel = 'pack_tile_kernel<STATS> (pack + pass-1 statistics in one read of the stream)'
             else:
                 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                ls = index()
                 e0.record()
                 dna, qual, bad = ops.pack(ctx, d_buf, ls, 0, nreads, p)
                 e1.record()
                 kernel = 'pack_tile_kernel'
             if timed: pack_events.append((e0, e1, kernel))
-            state.update(dna=dna, qual=qual, bad=bad, d=d, nreads=nreads, ls=ls, params=p, qname=qres, qname_path=qpath)
+            state.update(dna=dna, qual=qual, bad=bad, d=d, nreads=nreads, nlines=nlines, ls=ls, params=p, qname=qres, qname_path=qpath)
 
         for _ in range(warmup):
             step(False)
@@ -282,6 +289,8 @@ def main():
             step(True)
         fence()
         dt = time.perf_counter() - t0
+        indexed = state['ls'] is not None                                   # did the step expand the record index?
+        if state['ls'] is None: state['ls'] = ops.index_lines(ctx, d_buf, ops.count_lines(ctx, d_buf))     # (for the checks below, outside the timed region)
         total_bytes, total_reads = fastq_bytes, state['nreads']
         if use_dist:
             t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
@@ -317,8 +326,8 @@ def main():
         # their final width, what an ideal pass would store)
         qcol_bytes = sum(x.element_size() for x in state['qname'][4]) if (state.get('qname') and 'fused' in (state.get('qname_path') or '')) else 0
         algo_bytes = fastq_bytes + nreads * (d['dna_bytes_per_row'] + d['quality_bytes_per_row'] + qcol_bytes)
-        step_bytes = fastq_bytes + nreads * (d['dna_bytes_per_row'] + d['quality_bytes_per_row'] + 32 + qcol_bytes)
-        return dict(d_buf=d_buf, fastq_bytes=fastq_bytes, state=state, dt_step=dt / steps, total_bytes=total_bytes, total_reads=total_reads,
+        step_bytes = fastq_bytes + nreads * (d['dna_bytes_per_row'] + d['quality_bytes_per_row'] + (32 if indexed else 0) + qcol_bytes)
+        return dict(indexed=indexed, d_buf=d_buf, fastq_bytes=fastq_bytes, state=state, dt_step=dt / steps, total_bytes=total_bytes, total_reads=total_reads,
                     qname_exact_ms=qname_exact_ms, kernel=kernel, pack_ms=pack_ms, algo_bytes=algo_bytes, step_bytes=step_bytes, d=d, nreads=nreads)
 
     def roofline_of(m, traffic=None):
@@ -368,7 +377,8 @@ def main():
                    'reads_per_gpu': nreads, 'read_length': args.length if args.workload == 'cfg2' else '36-301', 'fastq_bytes_per_gpu': fastq_bytes,
                    'sharding': 'record-parallel, %d shard(s)' % world},
         'step_roofline': {'algorithmic_bytes_per_step': int(m['step_bytes']),
-                          'note': 'one ideal pass: the records read once; both rows, the 32 B of line offsets and the QNAME columns written',
+                          'note': 'one ideal pass: the records read once; both rows and the QNAME columns written' + (', and the 32 B of line offsets per read' if m['indexed'] else
+                                  ' (no record index is expanded: the kernels walk the census lists)'),
                           'frac_of_8TBps': round(m['step_bytes'] / 1e9 / m['dt_step'] / HBM_PEAK_GBS, 4)},
         'roofline': roofline_of(m, traffic),
     }

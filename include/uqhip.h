@@ -356,6 +356,12 @@ typedef struct uq_qname_fused {
     uint64_t counts[UQ_QF_MAXC][UQ_QF_MAXT];
 } uq_qname_fused;
 int uq_qname_guess(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start, uint64_t nreads, uq_qname_fused* d_q);
+/* The two queued forms below accept d_line_start == NULL: no record index is expanded at all (uq_index_lines_async is left out of the
+ * step: 8 B per line written and read again).  The line starts then come from the newline lists the census queued in front left in the
+ * context (uq_count_lines_end_async for the same d_buf): the pack kernel finds each tile's place in them through one record per tile
+ * (a binary search over the per-tile counts, done by a small kernel in front), the QNAME sample is stratified by position in the stream
+ * instead of by read number.  Same tables, statistics and field values (tests/test_gpu_pack.py, tests/test_gpu_qname.py run both forms);
+ * a census whose lists overflowed (uq_count_lines_wait's *h_ok = 0) makes both stand down as the indexed forms do. */
 int uq_qname_guess_async(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start, uq_qname_fused* d_q);
 int uq_pack_stats_qname(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start, uint64_t first_read, uint64_t nreads,
                         const uq_pack_params* h_guess, uint8_t* d_dna, uint8_t* d_qual, uint64_t* d_bad, uq_stats* d_stats,

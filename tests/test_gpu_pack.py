@@ -522,6 +522,30 @@ def test_queued_census_index_pack_equals_the_plain_calls(ctx, length, kw):
         assert t.equal(got[0][:n * guess.dna_bytes_per_row], ref[0]) and t.equal(got[1][:n * guess.quality_bytes_per_row], ref[1])
         assert not hs.incomplete and np.array_equal(hs.counts, hs_ref.counts)
         assert (hs.len_min, hs.len_max, hs.max_record_bytes) == (hs_ref.len_min, hs_ref.len_max, hs_ref.max_record_bytes)
+    # the QNAME form without an expanded index (line_start = None): the pack kernel and the QNAME sample walk the census's lists
+    # (csrc/lines.h) -- same tables, same statistics, same field values as with the index
+    fa, fb = ops.FusedQname(ctx, n), ops.FusedQname(ctx, n + 1000)
+    ops.qname_guess(ctx, d_buf, ls, n, fa)
+    ref_q = ops.pack_stats(ctx, d_buf, ls, 0, n, guess, fq=fa)
+    assert ref_q is not None
+    ops.qname_fused_finish(ctx, fa)
+    qa = ops.qname_fused_fetch(ctx, fa)
+    cen = ops.ChunkedCensus(ctx, d_buf); cen.chunk(0, d_buf.numel()); cen.end_async()
+    ops.qname_guess_async(ctx, d_buf, None, fb)
+    got = ops.pack_stats_async(ctx, d_buf, None, n + 1000, guess, fq=fb)
+    assert got is not None
+    ops.qname_fused_finish(ctx, fb)
+    hs = ops.stats_fetch(ctx, got[3])
+    assert cen.wait() == (nl, True)
+    qb = ops.qname_fused_fetch(ctx, fb)
+    assert t.equal(got[0][:n * guess.dna_bytes_per_row], ref[0]) and t.equal(got[1][:n * guess.quality_bytes_per_row], ref[1])
+    assert not hs.incomplete and np.array_equal(hs.counts, hs_ref.counts)
+    assert (hs.len_min, hs.len_max, hs.max_record_bytes) == (hs_ref.len_min, hs_ref.len_max, hs_ref.max_record_bytes)
+    assert qa.ok and qb.ok and qa.flags == 0 and qb.flags == 0 and qa.nsep == qb.nsep and qa.nreads == qb.nreads == n
+    assert bytes(qa.seps) == bytes(qb.seps) and (qa.plen, qa.slen) == (qb.plen, qb.slen)
+    for c in range(qa.nsep + 1): assert t.equal(fa.column(c, n), fb.column(c, n))
+    with pytest.raises(Exception):                               # the plain form has no census to fall back on
+        ops.pack_stats(ctx, d_buf, None, 0, n, guess)
     # tables / index too small for the file: flagged, nothing written beyond them
     cen = ops.ChunkedCensus(ctx, d_buf); cen.chunk(0, d_buf.numel()); cen.end_async()
     cap = n // 2

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Start / duration of every kernel of ONE bench step (rocprofv3 --kernel-trace; the program itself follows `--`): where the device
-# idles between launches.   tools/step_timeline.sh <tag> [bench.py args...]   -> gpurun_out/<tag>_timeline.txt
+# idles between launches.   [TL_MATCH=kernel] tools/step_timeline.sh <tag> [bench.py args...]   -> gpurun_out/<tag>_timeline.txt
 tag=$1; shift
 R=${GRAFT_REPO_ROOT:-$PWD}; OUT=$R/gpurun_out; mkdir -p $OUT/$(dirname $tag)
 export TMPDIR=/tmp; cd /tmp; rm -rf /tmp/tl_$$
@@ -16,6 +16,12 @@ def short(k):
 starts = [i for i, (s, e, k) in enumerate(rows) if 'census_list_kernel' in k and e - s > 300000]
 if len(starts) < 4: sys.exit('no steps found')
 a, b = starts[-3], starts[-2]                      # a late, warmed-up step
+import os
+want = os.environ.get('TL_MATCH')                  # TL_MATCH=<kernel name>: the latest step that runs it (bench.py times several kinds of step)
+if want:
+    for i in range(len(starts) - 2, 0, -1):
+        if any(want in k for s, e, k in rows[starts[i - 1]:starts[i]]) and any(want in k for s, e, k in rows[starts[i]:starts[i + 1]]):
+            a, b = starts[i - 1], starts[i]; break
 t0 = rows[a][0]; prev_end = t0
 print('one step: %.3f ms from census start to the next census start' % ((rows[b][0] - t0) / 1e6))
 for s, e, k in rows[a:b]:

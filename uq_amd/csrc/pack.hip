@@ -23,6 +23,7 @@
 // thread-per-read big-integer addition so the bytes still match.
 #include "common.h"
 #include "swar.h"
+#include "lines.h"
 #include "histo.h"
 
 namespace {
@@ -230,6 +231,47 @@ constexpr int PKS_COPIES = 4;
 constexpr uint32_t pks_bins(int bd) { return bd == 3 ? 512u : 256u; }     // bin = base code << 6 | quality code (3-bit bases: nine bits)
 constexpr uint32_t pks_words(int bd) { return pks_bins(bd) * PKS_COPIES + 128; }
 
+// The queued QNAME forms take their line starts from the census's lists instead of an expanded index (lines.h): a record per pack tile (TileRec): the start of
+// the tile's first record (entry `ntiles`: the end of the last record), where the newline in front of it sits (census tile,
+// slot) and how many newlines that tile and its two successors hold -- left by tile_origin_kernel, one binary search per pack tile.  With
+// them a lane finds its list entry by arithmetic: ONE load per line start, nothing that waits for another load inside the prefetch (a walk
+// with dependent loads there stalls on the tile's bytes requested just before it: 1.62 -> 1.94 ms).
+// start of the tile's first record; T = census tile of the newline in front of it, A = its slot + 1 | newlines of T << 16, B = newlines of T + 1 | of T + 2 << 16
+struct TileRec { uint64_t start; uint32_t T, A, B, pad; };
+struct PackLists {
+    CensusView cv;                             // cv.list == nullptr: the expanded index (`ls`) is used
+    const uint32_t* over;                      // the census's overflow word: a tile held more newlines than its list (the lists are not usable)
+};
+
+__global__ __launch_bounds__(256) void tile_origin_kernel(CensusView cv, const unsigned long long* __restrict__ d_async, const uint32_t* __restrict__ over, uint64_t first,
+                                                          uint64_t n, uint64_t R, uint64_t entries, TileRec* __restrict__ rec) {
+    const uint64_t tt = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (tt >= entries) return;
+    uint64_t nlines = 4 * (first + n);
+    if (d_async) {                                  // the queued census: what it counted (pack_tile_kernel clips the same way)
+        nlines = d_async[0];
+        const uint64_t have = nlines / 4;
+        if (have < n) n = have;
+        if (d_async[1] || *over) n = 0;
+    }
+    uint64_t r = tt * R;
+    if (r > n) r = n;
+    uint32_t T, kk;
+    cv_locate(cv, (int64_t)(4 * (first + r)) - 1, T, kk);
+    bool ok;
+    TileRec out;
+    out.start = n ? cv_line_start(cv, nlines, T, kk, 0, ok) : 0;
+    uint32_t c[3];
+#pragma unroll
+    for (uint32_t k = 0; k < 3; ++k) {
+        const uint64_t t = (uint64_t)T + k;
+        c[k] = t < cv.nb ? (uint32_t)((t + 1 < cv.nb ? (uint64_t)cv.offs[t + 1] : nlines) - cv.offs[t]) : 0u;
+        if (c[k] > CV_LIST_CAP) c[k] = CV_LIST_CAP;          // (an overflowed census: the kernels stand down anyway)
+    }
+    out.T = T; out.A = kk | (c[0] << 16); out.B = c[1] | (c[2] << 16); out.pad = 0;
+    rec[tt] = out;
+}
+
 // LDS carve (dynamic): [16 B guard][stage][out_d | out_q][meta u32 x (4R+4)][luts 3 x 512 B]
 // Workgroups are persistent: each walks tiles b, b + S, b + 2S, ... with a software pipeline -- the
 // next tile's bytes and line offsets are loaded into registers (in flight) while the current tile is
@@ -243,14 +285,15 @@ constexpr uint32_t pks_words(int bd) { return pks_bins(bd) * PKS_COPIES + 128; }
 // was the long pole of every tile: 2.10 ms against 1.38 ms without the QNAME phase; a fifth wave for the QNAME lines leaves the CU
 // with workgroups of five waves, of which it places three at a time where four of four waves fit: 2.0 - 2.5 ms.)  Built for four
 // workgroups per CU: the parser's registers come on top of a tile in flight.
-template <int BD, int BQ, bool NTRICK, bool FAST, bool STATS, bool QN>
+template <int BD, int BQ, bool NTRICK, bool FAST, bool STATS, bool QN, bool LISTS = false>
 __global__ __launch_bounds__(PK_THREADS, (STATS && (NTRICK || QN)) ? 4 : 5) void pack_tile_kernel(const uint8_t* __restrict__ buf,
                                                                const uint64_t* __restrict__ ls, uint64_t first,
                                                                uint64_t n, PackLut lut, PackGeom g,
                                                                uint8_t* __restrict__ dna, uint8_t* __restrict__ qual,
                                                                unsigned long long* __restrict__ bad,
                                                                uq_stats* __restrict__ st, const unsigned long long* __restrict__ d_async,
-                                                               uq_qname_fused* __restrict__ qf, uint32_t* __restrict__ qvals, uint64_t qpitch) {
+                                                               uq_qname_fused* __restrict__ qf, uint32_t* __restrict__ qvals, uint64_t qpitch, PackLists pl,
+                                                               const TileRec* __restrict__ trec) {      // trec: [pack tiles + 1] with pl (a restrict parameter of its own: the records are read through the scalar cache, like `ls`)
     constexpr int NV = STATS ? PK_NV_STATS : PK_NV;
     extern __shared__ __align__(16) uint8_t smem[];
     uint8_t* stage = smem + 16;                       // reads of up to 8 bytes below offset 0 stay in bounds
@@ -293,22 +336,30 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && (NTRICK || QN)) ? 4 : 5) void
             for (uint32_t k = 0; k < 10; ++k) { qn->pow10[k] = pw; pw *= 10; }
         }
     }
+    uint64_t nl_total = 4 * (first + n);              // (list form: closes the last census tile's list)
+    constexpr bool lists = STATS && QN && LISTS;      // (instances of the QNAME forms only: the others have no registers to spare, and a run-time choice
+                                                      // between `ls` and `trec` turns the tile bounds' scalar loads into vector loads that wait for the tile's stores)
     if (d_async) {                                    // the queued form (uq_pack_stats_async): the census in front left the line count on the device;
+        nl_total = d_async[0];
         const uint64_t have = d_async[0] / 4;         // `n` is what the tables hold
         if (have > n) incomplete = true; else n = have;
-        if (d_async[1]) { incomplete = true; n = 0; }   // the queued index in front gave up (list or capacity overflow): its entries are not line starts
+        if (d_async[1] || (lists && *pl.over)) { incomplete = true; n = 0; }   // the queued index in front gave up (list or capacity overflow): its entries are not line starts
     }
 
     const uint64_t R = g.R;
     const uint64_t ntiles = (n + R - 1) / R;
     const uint64_t S = gridDim.x;
-    struct Bounds { uint64_t g0, g1; };
-    struct Regs { uint4 v[NV]; uint64_t m0; uint64_t g0; uint32_t skew, nvec, Rt; bool ok; };
+    struct Bounds { uint64_t g0, g1; uint32_t pT, pA, pB; };       // pT, pA, pB: PackLists::place
+    struct Regs { uint4 v[NV]; uint64_t m0; uint64_t g0; uint32_t skew, nvec, Rt, mrel, mraw; bool ok; };      // (lists: line start - g0 + skew = mrel + mraw)
     auto load_bounds = [&](uint64_t tt) {
-        Bounds b{0, 0};
+        Bounds b{0, 0, 0, 0, 0};
         if (tt < ntiles) {
             const uint32_t Rn = (uint32_t)((n - tt * R) < R ? (n - tt * R) : R);
-            b.g0 = ls[4 * (first + tt * R)]; b.g1 = ls[4 * (first + tt * R) + 4 * Rn];
+            if constexpr (lists) {                // (one round trip: the two records side by side)
+                const TileRec r0 = trec[tt];
+                b.g0 = r0.start; b.pT = r0.T; b.pA = r0.A; b.pB = r0.B; b.g1 = trec[tt + 1].start;
+            }
+            else { b.g0 = ls[4 * (first + tt * R)]; b.g1 = ls[4 * (first + tt * R) + 4 * Rn]; }
         }
         return b;
     };
@@ -316,7 +367,7 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && (NTRICK || QN)) ? 4 : 5) void
     // request the bytes and line offsets of reads [rfirst, rfirst + cnt) (their span is b); not ok = the span does not fit the stage
     auto issue = [&](uint64_t rfirst, uint32_t cnt, Bounds b) {
         Regs x;
-        x.ok = false; x.m0 = 0; x.g0 = b.g0; x.skew = 0; x.nvec = 0; x.Rt = 0;
+        x.ok = false; x.m0 = 0; x.g0 = b.g0; x.skew = 0; x.nvec = 0; x.Rt = 0; x.mrel = 0; x.mraw = 0;
 #pragma unroll
         for (int u = 0; u < NV; ++u) x.v[u] = make_uint4(0, 0, 0, 0);
         if (cnt == 0) return x;
@@ -326,11 +377,26 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && (NTRICK || QN)) ? 4 : 5) void
         const uint64_t span = b.g1 - b.g0 + x.skew;
         x.nvec = (uint32_t)((span + 15) >> 4);
         x.ok = span + 32 <= g.stage_bytes && x.nvec <= (uint32_t)(NV * PK_THREADS);
+        if constexpr (lists) {                   // the tile's 4 Rt + 1 newlines within the three census tiles the place describes?
+            const uint32_t kk = b.pA & 0xFFFFu, avail = (b.pA >> 16) + (b.pB & 0xFFFFu) + (b.pB >> 16);
+            if (kk + 4 * cnt > avail) x.ok = false;         // (lines of many KiB: the tile goes piece by piece, each with its own search)
+        }
         if (!x.ok) return x;                          // tiles are sized from the AVERAGE record: a long-winded one is split below
         const uint4* src = (const uint4*)(uintptr_t)a0;
 #pragma unroll
         for (int u = 0; u < NV; ++u) { const uint32_t i = u * PK_THREADS + tid; if (i < x.nvec) x.v[u] = src[i]; }
-        if (tid <= 4 * x.Rt) x.m0 = ls[4 * (first + rfirst) + tid];
+        if (tid <= 4 * x.Rt) {
+            if constexpr (lists) {
+                // the newline in front of line start `tid` of the tile: slot kk - 1 + tid of census tile T, counted on through T + 1, T + 2
+                uint32_t idx = (b.pA & 0xFFFFu) + tid, t = b.pT;          // (slot + 1)
+                const uint32_t c0 = b.pA >> 16, c1 = b.pB & 0xFFFFu;
+                if (idx > c0) { idx -= c0; ++t; if (idx > c1) { idx -= c1; ++t; } }
+                // the list entry stays as loaded until the next tile's phase A adds it up: arithmetic on it HERE would wait for the load -- and
+                // with it for the tile's bytes requested above
+                x.mrel = x.skew - (uint32_t)b.g0 + (idx == 0 ? 0u : (uint32_t)t * (uint32_t)CV_TILE - pl.cv.mis + 1u);      // (modulo 2^32: a tile spans less)
+                x.mraw = idx == 0 ? 0u : (uint32_t)pl.cv.list[(uint64_t)t * CV_LIST_CAP + (idx - 1)];
+            } else x.m0 = ls[4 * (first + rfirst) + tid];
+        }
         return x;
     };
 
@@ -344,7 +410,7 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && (NTRICK || QN)) ? 4 : 5) void
         uint8_t* out_q = out_d + ((Rt * g.Cd + 15) & ~15u);
         // ---- A: registers -> LDS
         if (cur.ok) {
-            if (tid <= 4 * Rt) meta[tid] = (uint32_t)(cur.m0 - cur.g0) + cur.skew;
+            if (tid <= 4 * Rt) meta[tid] = lists ? cur.mrel + cur.mraw : (uint32_t)(cur.m0 - cur.g0) + cur.skew;
 #pragma unroll
             for (int u = 0; u < NV; ++u) { const uint32_t i = u * PK_THREADS + tid; if (i < cur.nvec) ((uint4*)stage)[i] = cur.v[u]; }
         } else {
@@ -524,8 +590,20 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && (NTRICK || QN)) ? 4 : 5) void
             for (uint32_t sub = 0; sub < Rt; sub += g.Rs) {
                 const uint32_t cnt = Rt - sub < g.Rs ? Rt - sub : g.Rs;
                 const uint64_t rf = t * R + sub;
-                Bounds sb;
-                sb.g0 = ls[4 * (first + rf)]; sb.g1 = ls[4 * (first + rf) + 4 * cnt];
+                Bounds sb{0, 0, 0, 0, 0};
+                if constexpr (lists) {                  // (rare: a search per piece, and the counts of its three census tiles)
+                    uint32_t T, kk; bool found;
+                    cv_locate(pl.cv, (int64_t)(4 * (first + rf)) - 1, T, kk);
+                    sb.g0 = cv_line_start(pl.cv, nl_total, T, kk, 0, found); sb.g1 = cv_line_start(pl.cv, nl_total, T, kk, 4 * cnt, found);
+                    uint32_t c[3];
+#pragma unroll
+                    for (uint32_t k = 0; k < 3; ++k) {
+                        const uint64_t tq = (uint64_t)T + k;
+                        c[k] = tq < pl.cv.nb ? (uint32_t)((tq + 1 < pl.cv.nb ? (uint64_t)pl.cv.offs[tq + 1] : nl_total) - pl.cv.offs[tq]) : 0u;
+                        if (c[k] > CV_LIST_CAP) c[k] = CV_LIST_CAP;
+                    }
+                    sb.pT = T; sb.pA = kk | (c[0] << 16); sb.pB = c[1] | (c[2] << 16);
+                } else { sb.g0 = ls[4 * (first + rf)]; sb.g1 = ls[4 * (first + rf) + 4 * cnt]; }
                 const Regs piece = issue(rf, cnt, sb);
                 do_tile(rf, piece, [] {});
                 __syncthreads();                      // the next piece overwrites the stage and the out tile
@@ -605,7 +683,7 @@ __global__ __launch_bounds__(256) void pack_carry_kernel(const uint8_t* __restri
 }
 
 typedef void (*PackKernel)(const uint8_t*, const uint64_t*, uint64_t, uint64_t, PackLut, PackGeom, uint8_t*, uint8_t*, unsigned long long*,
-                           uq_stats*, const unsigned long long*, uq_qname_fused*, uint32_t*, uint64_t);
+                           uq_stats*, const unsigned long long*, uq_qname_fused*, uint32_t*, uint64_t, PackLists, const TileRec*);
 
 template <int BD, int BQ>
 PackKernel pick_nt(bool ntrick, bool fast) {
@@ -614,13 +692,14 @@ PackKernel pick_nt(bool ntrick, bool fast) {
 }
 
 // the fused pack + statistics kernels exist for the lookup-free path only (2-bit A/C/G/T, contiguous qualities)
-template <int BD, bool QN>
+template <int BD, bool QN, bool LISTS = false>
 PackKernel pick_stats_kernel_q(int bq, bool ntrick) {
-#define UQ_PS(B) case B: return ntrick ? pack_tile_kernel<BD, B, true, true, true, QN> : pack_tile_kernel<BD, B, false, true, true, QN>;
-    switch (bq) { UQ_PS(1) UQ_PS(2) UQ_PS(3) UQ_PS(4) UQ_PS(5) default: return ntrick ? pack_tile_kernel<BD, 6, true, true, true, QN> : pack_tile_kernel<BD, 6, false, true, true, QN>; }
+#define UQ_PS(B) case B: return ntrick ? pack_tile_kernel<BD, B, true, true, true, QN, LISTS> : pack_tile_kernel<BD, B, false, true, true, QN, LISTS>;
+    switch (bq) { UQ_PS(1) UQ_PS(2) UQ_PS(3) UQ_PS(4) UQ_PS(5) default: return ntrick ? pack_tile_kernel<BD, 6, true, true, true, QN, LISTS> : pack_tile_kernel<BD, 6, false, true, true, QN, LISTS>; }
 #undef UQ_PS
 }
-PackKernel pick_stats_kernel(int bd, int bq, bool ntrick, bool qn) {
+PackKernel pick_stats_kernel(int bd, int bq, bool ntrick, bool qn, bool lists) {
+    if (qn && lists) return bd == 3 ? pick_stats_kernel_q<3, true, true>(bq, ntrick) : pick_stats_kernel_q<2, true, true>(bq, ntrick);
     if (bd == 3) return qn ? pick_stats_kernel_q<3, true>(bq, ntrick) : pick_stats_kernel_q<3, false>(bq, ntrick);
     return qn ? pick_stats_kernel_q<2, true>(bq, ntrick) : pick_stats_kernel_q<2, false>(bq, ntrick);
 }
@@ -649,7 +728,10 @@ static int pack_impl(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_s
                      uint64_t nreads, const uq_pack_params* hp, uint8_t* d_dna, uint8_t* d_qual, uint64_t* d_bad,
                      uq_stats* d_stats, int* h_fused, const unsigned long long* d_async = nullptr, uq_qname_fused* d_q = nullptr,
                      uint32_t* d_vals = nullptr, uint64_t vals_pitch = 0) {
-    UQ_REQUIRE(ctx && d_buf && d_line_start && hp && d_dna && d_qual && d_bad, "uq_pack: null argument");
+    // d_line_start == nullptr (queued forms only): the line starts come from the lists of the census queued in front (lines.h)
+    const bool use_lists = d_line_start == nullptr && d_async != nullptr && d_stats != nullptr && d_q != nullptr;
+    UQ_REQUIRE(ctx && d_buf && (d_line_start || use_lists) && hp && d_dna && d_qual && d_bad, "uq_pack: null argument");
+    UQ_REQUIRE(!use_lists || (ctx->async_buf == d_buf && ctx->async_nbytes > 0), "uq_pack_stats_qname_async: no line index given and no census of this buffer queued in front");
     if (h_fused) *h_fused = 0;
     UQ_REQUIRE(hp->bits_per_base >= 1 && hp->bits_per_base <= 8 && hp->bits_per_quality >= 1 && hp->bits_per_quality <= 8,
                "uq_pack: bits per symbol must be 1..8");
@@ -779,7 +861,7 @@ static int pack_impl(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_s
     const size_t lds = 16 + (size_t)g.stage_bytes + g.out_bytes + (4 * R + 4) * 4 + 3 * 512 + (d_stats ? pks_words((int)bd) * 4 + sizeof(QnLds) : 0);
     UQ_REQUIRE(lds <= 160 * 1024, "uq_pack: tile needs %zu bytes of LDS", lds);
     const uint64_t tiles = (nreads + R - 1) / R;
-    PackKernel k = d_stats ? pick_stats_kernel((int)bd, (int)bq, ntrick, d_q != nullptr) : pick_kernel((int)bd, (int)bq, ntrick, fast);
+    PackKernel k = d_stats ? pick_stats_kernel((int)bd, (int)bq, ntrick, d_q != nullptr, use_lists) : pick_kernel((int)bd, (int)bq, ntrick, fast);
     if (lds > 48 * 1024) UQ_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // persistent workgroups: exactly as many as are resident at once (LDS and registers both limit that: a grid sized from the LDS
     // alone would leave the kernels built for four waves per SIMD with a second, quarter-full round of workgroups)
@@ -802,8 +884,24 @@ static int pack_impl(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_s
     if (per_cu > 6) per_cu = 6;
     if (per_cu < 1) per_cu = 1;
     const uint64_t blocks = tiles < (uint64_t)UQ_NUM_CU * per_cu ? tiles : (uint64_t)UQ_NUM_CU * per_cu;
+    PackLists pl;
+    memset(&pl, 0, sizeof(pl));
+    const TileRec* trec = nullptr;
+    if (use_lists) {
+        const uint32_t mis = (uint32_t)((uintptr_t)d_buf & 15);
+        pl.cv.list = ctx->idx_bitmap; pl.cv.offs = ctx->idx_partials; pl.cv.mis = mis;
+        pl.cv.nb = (((ctx->async_nbytes + mis + 15) / 16) * 16 + CV_TILE - 1) / CV_TILE;
+        const uint64_t entries = tiles + 1;
+        void* scr;
+        UQ_TRY(uq_scratch(ctx, entries * sizeof(TileRec) + 64, &scr));
+        TileRec* rec = (TileRec*)scr;
+        pl.over = (const uint32_t*)(ctx->idx_bitmap + pl.cv.nb * CV_LIST_CAP);        // index.hip: the 16 spare bytes behind the slots
+        tile_origin_kernel<<<(uint32_t)((entries + 255) / 256), 256, 0, ctx->stream>>>(pl.cv, d_async, pl.over, first_read, nreads, R, entries, rec);
+        UQ_LAUNCH_CHECK();
+        trec = rec;
+    }
     k<<<(uint32_t)blocks, PK_THREADS, lds, ctx->stream>>>(d_buf, d_line_start, first_read, nreads, lut, g, d_dna, d_qual,
-                                                         (unsigned long long*)d_bad, d_stats, d_async, d_q, d_vals, vals_pitch);
+                                                         (unsigned long long*)d_bad, d_stats, d_async, d_q, d_vals, vals_pitch, pl, trec);
     UQ_LAUNCH_CHECK();
     if (h_fused) *h_fused = 1;
     return 0;

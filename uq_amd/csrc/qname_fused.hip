@@ -13,6 +13,7 @@
 //                         checkpoints of uq.py:586-602 (first occurrence per value by atomic minima; no sort).
 // Nothing here waits for the host: the read count is taken from the queued census (ctx->d_async) or from the structure itself.
 #include "common.h"
+#include "lines.h"
 
 namespace {
 constexpr int QF_THREADS = 256;
@@ -53,16 +54,21 @@ __device__ __forceinline__ void stage_line(uint8_t* row, const uint8_t* q, uint3
 constexpr uint32_t QF_SPW = 8;
 __global__ __launch_bounds__(64) void qname_sample_kernel(const uint8_t* __restrict__ buf, const uint64_t* __restrict__ ls, uint64_t n,
                                                                    const unsigned long long* __restrict__ d_async, uq_qname_layout_result* __restrict__ lay,
-                                                                   DevLine1* __restrict__ l1_out, uint32_t* __restrict__ step_out) {
+                                                                   DevLine1* __restrict__ l1_out, uint32_t* __restrict__ step_out, CensusView cv, uint64_t nbytes,
+                                                                   const uint32_t* __restrict__ over) {
     __shared__ __align__(16) uint8_t stage[64 * QF_STRIDE];
     __shared__ DevLine1 l1;
     __shared__ unsigned long long s_entry[QF_MAXCH], s_viol[QF_MAXCH];
     __shared__ uint32_t s_lcp, s_lcs, s_flags;
     const uint32_t tid = threadIdx.x;
-    if (d_async) n = d_async[1] ? 0 : d_async[0] / 4;
+    // cv.list: no expanded index (`ls` is null) -- the line starts come from the lists of the census queued in front (lines.h), and the
+    // sample is stratified by POSITION: the first record that starts in a census tile picked from every stratum of tiles
+    const bool lists = cv.list != nullptr;
+    uint64_t nlines = 4 * n;
+    if (d_async) { nlines = d_async[0]; n = (d_async[1] || (lists && *over)) ? 0 : d_async[0] / 4; }
     // ---- line 1 and its character table (every workgroup builds its own copy: 255 bytes, one lane)
     uint32_t len = 0;
-    if (n) { const uint64_t e = ls[1]; len = e >= 1 && e <= 256 ? (uint32_t)(e - 1) : 0xFFFFFFFFu; }
+    if (n) { bool ok; const uint64_t e = lists ? cv_line_start(cv, nlines, 0, 0, 1, ok) : ls[1]; len = e >= 1 && e <= 256 ? (uint32_t)(e - 1) : 0xFFFFFFFFu; }
     for (uint32_t x = tid; x < 256; x += 64) { l1.text[x] = (len != 0xFFFFFFFFu && x < len) ? buf[x] : 0; l1.slot[x] = 0xFF; }
     if (tid < QF_MAXCH) { l1.ch[tid] = 0; l1.cnt[tid] = 0; l1.lastpos[tid] = 0; s_entry[tid] = UQ_NONE; s_viol[tid] = 0; }
     if (tid == 0) { s_lcp = 0xFFFFFFFFu; s_lcs = 0xFFFFFFFFu; s_flags = 0; }
@@ -106,7 +112,8 @@ __global__ __launch_bounds__(64) void qname_sample_kernel(const uint8_t* __restr
         if (tid == 0) *step_out = step;
     }
     if (l1.bad) return;
-    const uint8_t* buf_end = buf + ls[4 * n];
+    const uint8_t* buf_end = lists ? buf + nbytes : buf + ls[4 * n];
+    const uint64_t ks = lists ? (uint64_t)QF_SAMPLES : 0;           // sample k: a record out of a census tile of the k-th of ks strata of the stream
     uint32_t my_lcp = 0xFFFFFFFFu, my_lcs = 0xFFFFFFFFu;         // (wave-uniform below: every lane holds the same value)
     const uint32_t lane = lane_id();
     const uint32_t my_ch = lane < l1.nch ? l1.ch[lane] : 0x100u;   // lane c speaks for candidate character c of line 1
@@ -116,18 +123,31 @@ __global__ __launch_bounds__(64) void qname_sample_kernel(const uint8_t* __restr
     // a wave: (1) every lane fetches ITS sample's line into its LDS row (64 index and line loads in flight at once); (2) the wave goes
     // through the 64 lines one by one with a lane per BYTE: common prefix / suffix with line 1 and the per-character counts are a
     // few ballots each, no loop over the bytes (a lane per sample walking its line byte by byte took 72 us for 4096 samples).
-    for (uint64_t k0 = (uint64_t)blockIdx.x * QF_SPW; k0 * step < n; k0 += (uint64_t)gridDim.x * QF_SPW) {
+    for (uint64_t k0 = (uint64_t)blockIdx.x * QF_SPW; lists ? k0 < ks : k0 * step < n; k0 += (uint64_t)gridDim.x * QF_SPW) {
         const uint64_t k = k0 + lane;
         uint64_t h = (k + 0x9E3779B97F4A7C15ull) * 0xBF58476D1CE4E5B9ull;
         h ^= h >> 29; h *= 0x94D049BB133111EBull; h ^= h >> 32;
-        uint64_t i = k * step + h % step;
+        uint64_t i = lists ? 0 : k * step + h % step;
+        uint64_t q0 = 0, q1 = 0;
+        if (lists) {
+            if (lane < QF_SPW && k < ks) {
+                const uint64_t T = (((k << 16) | (h & 0xFFFFu)) * cv.nb) / (ks << 16);
+                const uint64_t o = cv.offs[T], c = (T + 1 < cv.nb ? (uint64_t)cv.offs[T + 1] : nlines) - o;
+                uint32_t slot = (3u - (uint32_t)o) & 3u;                // the newlines of the tile that close a record: rank = 3 mod 4
+                if (c > slot) slot += 4u * (uint32_t)((h >> 16) % ((c - slot + 3) / 4));       // ... one of them (a tile without any: the next one behind it)
+                const uint64_t rank = o + slot;
+                bool ok0, ok1;
+                q0 = cv_line_start(cv, nlines, (uint32_t)T, slot + 1, 0, ok0); q1 = cv_line_start(cv, nlines, (uint32_t)T, slot + 1, 1, ok1);
+                if (ok0 && ok1) i = (rank + 1) / 4;
+            }
+        } else if (lane < QF_SPW && i && i < n) { q0 = ls[4 * i]; q1 = ls[4 * i + 1]; }
         if (lane >= QF_SPW || i >= n) i = 0;                            // (0 = no sample in this lane)
         const uint8_t* q = buf;
         uint32_t ql = 0;
         uint8_t* row = stage + tid * QF_STRIDE;
         if (i) {
-            q = buf + ls[4 * i];
-            ql = (uint32_t)(ls[4 * i + 1] - ls[4 * i] - 1);
+            q = buf + q0;
+            ql = (uint32_t)(q1 - q0 - 1);
             if (ql <= QF_ROW) stage_line(row, q, ql, buf_end);
         }
         for (uint32_t sidx = 0; sidx < QF_SPW; ++sidx) {
@@ -384,7 +404,19 @@ __global__ void encode_u32_kernel(const uint32_t* __restrict__ val, uint64_t n, 
 }
 
 int guess_impl(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start, uint64_t nreads, const unsigned long long* d_async, uq_qname_fused* d_q) {
-    UQ_REQUIRE(ctx && d_buf && d_line_start && d_q, "uq_qname_guess: null argument");
+    // d_line_start == nullptr (the queued form only): the census queued in front serves as the index
+    const bool use_lists = d_line_start == nullptr && d_async != nullptr;
+    UQ_REQUIRE(ctx && d_buf && (d_line_start || use_lists) && d_q, "uq_qname_guess: null argument");
+    UQ_REQUIRE(!use_lists || ctx->async_nbytes > 0, "uq_qname_guess_async: no line index given and no census of this buffer queued in front");
+    CensusView cv;
+    memset(&cv, 0, sizeof(cv));
+    const uint32_t* over = nullptr;
+    if (use_lists) {
+        cv.mis = (uint32_t)((uintptr_t)d_buf & 15);
+        cv.list = ctx->idx_bitmap; cv.offs = ctx->idx_partials;
+        cv.nb = (((ctx->async_nbytes + cv.mis + 15) / 16) * 16 + CV_TILE - 1) / CV_TILE;
+        over = (const uint32_t*)(ctx->idx_bitmap + cv.nb * CV_LIST_CAP);
+    }
     ScratchPlan sp;
     const size_t o_lay = sp.add(sizeof(uq_qname_layout_result)), o_l1 = sp.add(sizeof(DevLine1)), o_step = sp.add(16);
     void* scr;
@@ -395,7 +427,8 @@ int guess_impl(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start, 
     layout_init_kernel<<<1, 256, 0, ctx->stream>>>(d_lay);             // (one launch instead of three fills)
     UQ_LAUNCH_CHECK();
     const uint32_t grid = QF_SAMPLES / QF_SPW;
-    qname_sample_kernel<<<grid, 64, 0, ctx->stream>>>(d_buf, d_line_start, nreads, d_async, d_lay, (DevLine1*)(base + o_l1), (uint32_t*)(base + o_step));
+    qname_sample_kernel<<<grid, 64, 0, ctx->stream>>>(d_buf, d_line_start, nreads, d_async, d_lay, (DevLine1*)(base + o_l1), (uint32_t*)(base + o_step), cv,
+                                                      use_lists ? ctx->async_nbytes : 0, over);
     UQ_LAUNCH_CHECK();
     qname_guess_kernel<<<1, 64, 0, ctx->stream>>>((const DevLine1*)(base + o_l1), d_lay, (const uint32_t*)(base + o_step), d_q);
     UQ_LAUNCH_CHECK();
