@@ -70,7 +70,7 @@ __device__ __forceinline__ uint32_t pack4(uint32_t x) {
 }
 
 // LDS tile (16-byte aligned) -> global span, with the widest stores the destination alignment allows.
-__device__ __noinline__ void store_tile(uint8_t* gdst, const uint8_t* lsrc, uint32_t nb, uint32_t tid) {
+__device__ __noinline__ void store_tile_any(uint8_t* gdst, const uint8_t* lsrc, uint32_t nb, uint32_t tid) {
     const uint32_t mis = (uint32_t)(uintptr_t)gdst;
     if ((mis & 15) == 0) {
         const uint32_t nv = nb >> 4;
@@ -87,6 +87,14 @@ __device__ __noinline__ void store_tile(uint8_t* gdst, const uint8_t* lsrc, uint
     } else {
         for (uint32_t i = tid; i < nb; i += 256) gdst[i] = lsrc[i];
     }
+}
+// The usual case inline -- R is a multiple of 16 wherever that wastes little, so a tile's rows start 16-byte aligned: a call costs two full
+// waits (the callee waits for everything in flight on entry -- the next tile's bytes -- and for its own stores before it returns).
+__device__ __forceinline__ void store_tile(uint8_t* gdst, const uint8_t* lsrc, uint32_t nb, uint32_t tid) {
+    if ((((uint32_t)(uintptr_t)gdst) & 15u) == 0 && (nb & 15u) == 0) {
+#pragma unroll 1
+        for (uint32_t i = tid; i < (nb >> 4); i += 256) ((uint4*)gdst)[i] = ((const uint4*)lsrc)[i];
+    } else store_tile_any(gdst, lsrc, nb, tid);
 }
 
 // ---- the QNAME phase of the fused pack + statistics kernel (uq_pack_stats_qname; SURVEY.md 8 row f1 inside rows a3 / a4).
@@ -570,8 +578,13 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && (NTRICK || QN)) ? 4 : 5) void
         __syncthreads();
         if (ok) {
             // ---- C: coalesced stores of the two packed tiles (widest vector the tile's byte offset allows)
-            store_tile(dna + r0 * g.Cd, out_d, Rt * g.Cd, tid);
-            store_tile(qual + r0 * g.Cq, out_q, Rt * g.Cq, tid);
+            if constexpr (STATS && (NTRICK || QN)) {            // (the forms built for four workgroups per CU have the registers for the inline loop)
+                store_tile(dna + r0 * g.Cd, out_d, Rt * g.Cd, tid);
+                store_tile(qual + r0 * g.Cq, out_q, Rt * g.Cq, tid);
+            } else {
+                store_tile_any(dna + r0 * g.Cd, out_d, Rt * g.Cd, tid);
+                store_tile_any(qual + r0 * g.Cq, out_q, Rt * g.Cq, tid);
+            }
         }
     };
 
