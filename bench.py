@@ -355,7 +355,8 @@ def main():
         except Exception:
             traffic = None
 
-    mode = ((' [TWO reads of the stream, queued back to back (the line count stays on the device for the index and the pack kernel): census + index, then pack + statistics in one kernel with decisions guessed from the shard\'s first '
+    mode = ((' [TWO reads of the stream, queued back to back (the line count stays on the device): census' + (' + index' if m['indexed'] else ' (no record index: the kernels walk its newline lists)') +
+             ', then pack + statistics in one kernel with decisions guessed from the shard\'s first '
              '8192 reads; the tables were kept because the whole shard\'s statistics gave the same decisions]' if two_reads else
              ' [three reads of the stream: census, statistics, pack]'))
     qmode = ' + QNAME layout / typing / column encoding (%s)' % state.get('qname_path') if qname_in_step else ' (QNAME passes not in the step)'

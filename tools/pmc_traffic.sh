@@ -15,6 +15,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   cp /tmp/pmc_$c/p_counter_collection.csv $OUT/${tag}_pmc_$(echo $c | tr A-Z a-z).csv
 done
 cd $R
-python3 profiles/traffic.py $OUT/${tag}_pmc_fetch_size.csv $OUT/${tag}_pmc_write_size.csv "$pat" $OUT/${tag}_traffic.json
-# the per-dispatch csv files are large: keep only the rows of the kernels asked for
+# the per-dispatch csv files are large: keep only the rows of the kernels asked for (the regex sees the whole kernel name, template
+# arguments included: one instance of a kernel can be told from the others), then sum per kernel
 for c in fetch_size write_size; do head -1 $OUT/${tag}_pmc_$c.csv > $OUT/t.csv; grep -E "$pat" $OUT/${tag}_pmc_$c.csv >> $OUT/t.csv || true; mv $OUT/t.csv $OUT/${tag}_pmc_$c.csv; done
+python3 profiles/traffic.py $OUT/${tag}_pmc_fetch_size.csv $OUT/${tag}_pmc_write_size.csv "" $OUT/${tag}_traffic.json

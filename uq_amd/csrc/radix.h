@@ -19,3 +19,7 @@ int radix_sort_pairs32(uq_ctx* ctx, uint32_t* keys, uint32_t* vals, uint32_t* ke
 // keys[i] = the 32 bits of keys64[i] behind its z leading bits, vals[i] = i, h_hist = the census of the new keys,
 // and the first pass's per-tile counts left in `ws`: one pass over keys64.
 int radix_prefix_census32(uq_ctx* ctx, const uint64_t* keys64, uint64_t n, uint32_t z, uint32_t* keys, uint32_t* vals, void* ws, uint32_t* h_hist);
+// The same from the table itself (rows of C >= 8 bytes, chunk = their first eight bytes as a big-endian number; the 64-bit values are never
+// written out), with z from a sample: h_andor[0 .. 1] = AND / OR over every row's chunk, so that the caller can tell whether z holds.
+int radix_rows_prefix_census32(uq_ctx* ctx, const uint8_t* table, uint32_t C, uint64_t n, uint32_t z, uint32_t* keys, uint32_t* vals, void* ws,
+                               uint32_t* h_hist, uint64_t* h_andor);

@@ -74,6 +74,59 @@ __global__ __launch_bounds__(RS_THREADS) void rs_prefix_census_kernel(const uint
         if (h[i]) atomicAdd(&ghist[i], h[i]);
 }
 
+// The same straight from the TABLE: the 64-bit chunk values (the first eight bytes of every row, as a big-endian number) are never written out.
+// z comes from a sample of the rows (sort.hip); the AND / OR over every row's chunk, left in andor[0 .. 1], tells the caller whether the
+// sample's z holds (every row agrees on its z leading bits) -- if not, it runs this again with the true one.
+__global__ __launch_bounds__(RS_THREADS) void rs_rows_prefix_census_kernel(const uint8_t* __restrict__ table, uint32_t C, uint64_t n, uint32_t z,
+                                                                           uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t nb,
+                                                                           uint32_t* __restrict__ ghist, uint32_t* __restrict__ block_hist,
+                                                                           unsigned long long* __restrict__ andor) {
+    constexpr int ITEMS = RsGeom<uint32_t>::ITEMS, TILE = RsGeom<uint32_t>::TILE;
+    __shared__ uint32_t h[4 * 256];
+    __shared__ uint32_t h0[256];
+    __shared__ unsigned long long sa[RS_THREADS / 64], so[RS_THREADS / 64];
+    const uint32_t tid = threadIdx.x;
+    for (int i = tid; i < 4 * 256; i += RS_THREADS) h[i] = 0;
+    unsigned long long a = ~0ull, o = 0ull;
+    for (uint32_t tile = blockIdx.x; tile < nb; tile += gridDim.x) {
+        h0[tid] = 0;
+        __syncthreads();
+        const uint64_t base = (uint64_t)tile * TILE;
+        uint64_t c64[ITEMS];
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {                  // (rows of at least eight bytes: the caller's 32-bit round 0 is for wider tables)
+            const uint64_t idx = base + (uint64_t)i * RS_THREADS + tid;
+            c64[i] = 0;
+            if (idx < n) { uint64_t v; __builtin_memcpy(&v, table + idx * C, 8); c64[i] = __builtin_bswap64(v); }
+        }
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const uint64_t idx = base + (uint64_t)i * RS_THREADS + tid;
+            if (idx < n) {
+                a &= c64[i]; o |= c64[i];
+                const uint32_t k = (uint32_t)((c64[i] << z) >> 32);
+                keys[idx] = k; vals[idx] = (uint32_t)idx;
+                atomicAdd(&h0[k & 255u], 1u);
+                atomicAdd(&h[256 + ((k >> 8) & 255u)], 1u); atomicAdd(&h[512 + ((k >> 16) & 255u)], 1u); atomicAdd(&h[768 + (k >> 24)], 1u);
+            }
+        }
+        __syncthreads();
+        const uint32_t c = h0[tid];
+        block_hist[(uint64_t)tid * nb + tile] = c;
+        h[tid] += c;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { a &= __shfl_xor(a, d, 64); o |= __shfl_xor(o, d, 64); }
+    if ((tid & 63) == 0) { sa[tid >> 6] = a; so[tid >> 6] = o; }
+    __syncthreads();
+    for (int i = tid; i < 4 * 256; i += RS_THREADS)
+        if (h[i]) atomicAdd(&ghist[i], h[i]);
+    if (tid == 0) {
+        for (int w = 1; w < RS_THREADS / 64; ++w) { a &= sa[w]; o |= so[w]; }
+        atomicAnd(andor, a); atomicOr(andor + 1, o);
+    }
+}
+
 template <typename K>
 __global__ __launch_bounds__(RS_THREADS) void rs_count_kernel(const K* __restrict__ keys, uint64_t n, int shift,
                                                               uint32_t nb, uint32_t* __restrict__ block_hist) {
@@ -244,5 +297,24 @@ int radix_prefix_census32(uq_ctx* ctx, const uint64_t* keys64, uint64_t n, uint3
     UQ_TRY(uq_read_back(ctx, ctx->h_pinned + 4096, ghist, 4 * 256 * 4));
     UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     memcpy(h_hist, ctx->h_pinned + 4096, 4 * 256 * 4);
+    return 0;
+}
+
+int radix_rows_prefix_census32(uq_ctx* ctx, const uint8_t* table, uint32_t C, uint64_t n, uint32_t z, uint32_t* keys, uint32_t* vals, void* ws,
+                               uint32_t* h_hist, uint64_t* h_andor) {
+    uint32_t* ghist = (uint32_t*)ws;
+    uint32_t* block_hist = ghist + 8 * 256 + 64;
+    unsigned long long* andor = (unsigned long long*)(ghist + 8 * 256);        // the 64 spare words between the census and the per-tile counts
+    UQ_CHECK_HIP(hipMemsetAsync(ghist, 0, 4 * 256 * 4, ctx->stream));
+    UQ_CHECK_HIP(hipMemsetAsync(andor, 0xFF, 8, ctx->stream));
+    UQ_CHECK_HIP(hipMemsetAsync(andor + 1, 0, 8, ctx->stream));
+    const uint32_t nb = (uint32_t)((n + RsGeom<uint32_t>::TILE - 1) / RsGeom<uint32_t>::TILE);
+    rs_rows_prefix_census_kernel<<<nb < 2048 ? (nb ? nb : 1) : 2048, RS_THREADS, 0, ctx->stream>>>(table, C, n, z, keys, vals, nb, ghist, block_hist, andor);
+    UQ_LAUNCH_CHECK();
+    UQ_TRY(uq_read_back(ctx, ctx->h_pinned + 4096, ghist, 4 * 256 * 4));
+    UQ_TRY(uq_read_back(ctx, ctx->h_pinned + 4096 + 512, andor, 16));
+    UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(h_hist, ctx->h_pinned + 4096, 4 * 256 * 4);
+    h_andor[0] = ctx->h_pinned[4096 + 512]; h_andor[1] = ctx->h_pinned[4096 + 513];
     return 0;
 }

@@ -33,43 +33,20 @@ __device__ __forceinline__ uint64_t load_chunk_be(const uint8_t* row, uint32_t C
     return v;
 }
 
-// chunk 0 of every row; `andor` (optional): AND and OR over all of them -- the leading bits on which every row agrees carry no order
+// chunk 0 of every row (the 64-bit round 0) and the rows' numbers
 __global__ __launch_bounds__(ST) void extract_all_kernel(const uint8_t* __restrict__ table, uint64_t n, uint32_t C, uint64_t* __restrict__ keys,
-                                                         uint32_t* __restrict__ vals, unsigned long long* __restrict__ andor) {
-    uint64_t i = (uint64_t)blockIdx.x * ST + threadIdx.x;
-    unsigned long long a = ~0ull, o = 0ull;
-    if (i < n) {
-        const uint64_t k = load_chunk_be(table + i * C, C, 0);
-        keys[i] = k;
-        if (vals) vals[i] = (uint32_t)i;                 // (the 32-bit round 0 numbers the rows itself)
-        a = o = k;
-    }
-    if (andor) {      // per-workgroup partials (780 000 waves x 2 atomics on one word were 19 ms), folded by and_or_fold_kernel
-        __shared__ unsigned long long sa[ST / 64], so[ST / 64];
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) { a &= __shfl_xor(a, d, 64); o |= __shfl_xor(o, d, 64); }
-        if (lane_id() == 0) { sa[threadIdx.x >> 6] = a; so[threadIdx.x >> 6] = o; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            for (int w = 1; w < ST / 64; ++w) { a &= sa[w]; o |= so[w]; }
-            andor[2 * (uint64_t)blockIdx.x] = a; andor[2 * (uint64_t)blockIdx.x + 1] = o;
-        }
-    }
+                                                         uint32_t* __restrict__ vals) {
+    const uint64_t i = (uint64_t)blockIdx.x * ST + threadIdx.x;
+    if (i < n) { keys[i] = load_chunk_be(table + i * C, C, 0); vals[i] = (uint32_t)i; }
 }
-// (one workgroup walking all the partials was 0.3 ms of latency for 3 MB: a grid of them, two atomics each, on words the caller
-// has set to ~0 and 0)
-__global__ __launch_bounds__(ST) void and_or_fold_kernel(const unsigned long long* __restrict__ part, uint64_t nblocks, unsigned long long* __restrict__ out) {
-    __shared__ unsigned long long sa[ST / 64], so[ST / 64];
+// AND / OR over chunk 0 of `samples` rows spread evenly over the table: the guess for the leading bits every row agrees on
+__global__ __launch_bounds__(ST) void sample_andor_kernel(const uint8_t* __restrict__ table, uint64_t n, uint32_t C, uint64_t samples, unsigned long long* __restrict__ out) {
+    const uint64_t j = (uint64_t)blockIdx.x * ST + threadIdx.x;
     unsigned long long a = ~0ull, o = 0ull;
-    for (uint64_t i = (uint64_t)blockIdx.x * ST + threadIdx.x; i < nblocks; i += (uint64_t)gridDim.x * ST) { a &= part[2 * i]; o |= part[2 * i + 1]; }
+    if (j < samples) { const uint64_t row = samples > 1 ? j * (n - 1) / (samples - 1) : 0; a = o = load_chunk_be(table + row * C, C, 0); }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { a &= __shfl_xor(a, d, 64); o |= __shfl_xor(o, d, 64); }
-    if (lane_id() == 0) { sa[threadIdx.x >> 6] = a; so[threadIdx.x >> 6] = o; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < ST / 64; ++w) { a &= sa[w]; o |= so[w]; }
-        atomicAnd(out, a); atomicOr(out + 1, o);
-    }
+    if (lane_id() == 0) { atomicAnd(out, a); atomicOr(out + 1, o); }
 }
 __global__ void iota_kernel(uint32_t* __restrict__ v, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * ST + threadIdx.x;
@@ -326,28 +303,24 @@ int sort_rows_core(uq_ctx* ctx, const uint8_t* table, uint64_t n, uint32_t C, ui
 
     // ---- round 0: all rows by (a prefix of) chunk 0
     bool mode32 = C > 8 && n >= (1u << 16);
-    unsigned long long* part = (unsigned long long*)keysB;                      // free until the sort: 16 B per workgroup
-    const bool numbered = !mode32;
-    extract_all_kernel<<<blocks_for(n), ST, 0, s>>>(table, n, C, keysA, mode32 ? nullptr : valsA, mode32 ? part : nullptr);
-    UQ_LAUNCH_CHECK();
-    if (mode32) {
-        UQ_CHECK_HIP(hipMemsetAsync(tot + 4, 0xFF, 8, s));
-        UQ_CHECK_HIP(hipMemsetAsync(tot + 5, 0, 8, s));
-        const uint32_t fb = blocks_for(n) / (4 * ST) + 1;
-        and_or_fold_kernel<<<fb < 512 ? fb : 512, ST, 0, s>>>(part, blocks_for(n), (unsigned long long*)(tot + 4));
-        UQ_LAUNCH_CHECK();
-    }
     // A 64-bit LSD sort moves 32 B per pair and pass, eight passes.  Rows wider than a chunk go to refinement rounds anyway
     // when they tie, so round 0 may as well sort on FEWER bits: the 32 bits of chunk 0 behind its constant leading bits
     // (a 2-bit DNA row of 150 bases starts with four zero bits) as u32 keys -- 20 B per pair and pass, four passes -- and
     // leave the few rows that collide on them (n^2 / 2^33 pairs for random reads) to the first refinement round together
     // with the true duplicates.  Tables whose rows crowd on few prefixes (the digit census says so) keep the 64-bit sort.
+    // The number z of constant leading bits is guessed from 4096 rows spread over the table; the pass that makes the keys checks
+    // it on every row (AND / OR over all chunks) and runs again in the rare case that the sample agreed on more bits than the table.
+    auto leading_same = [](uint64_t a, uint64_t o) { const uint64_t same = ~(a ^ o); uint32_t z = 0; while (z < 64 && ((same >> (63 - z)) & 1)) ++z; return z; };
     uint32_t z = 0;
     if (mode32) {
+        UQ_CHECK_HIP(hipMemsetAsync(tot + 4, 0xFF, 8, s));
+        UQ_CHECK_HIP(hipMemsetAsync(tot + 5, 0, 8, s));
+        const uint64_t samples = n < 4096 ? n : 4096;
+        sample_andor_kernel<<<(uint32_t)((samples + ST - 1) / ST), ST, 0, s>>>(table, n, C, samples, (unsigned long long*)(tot + 4));
+        UQ_LAUNCH_CHECK();
         UQ_TRY(uq_read_back(ctx, ctx->h_pinned + 4, tot + 4, 16));
         UQ_CHECK_HIP(hipStreamSynchronize(s));
-        const uint64_t same = ~(ctx->h_pinned[4] ^ ctx->h_pinned[5]);           // bits every key agrees on
-        while (z < 64 && ((same >> (63 - z)) & 1)) ++z;
+        z = leading_same(ctx->h_pinned[4], ctx->h_pinned[5]);
         mode32 = z <= 32;
     }
     int alt = 0;
@@ -356,8 +329,14 @@ int sort_rows_core(uq_ctx* ctx, const uint8_t* table, uint64_t n, uint32_t C, ui
         uint32_t* k32b = k32a + n;
         static thread_local uint32_t h_hist[4 * 256];
         // keys, values (d_perm is the sort's value buffer: an even number of passes ends there), digit census and the first pass's
-        // per-tile counts in one pass over the chunk values
-        UQ_TRY(radix_prefix_census32(ctx, keysA, n, z, k32a, d_perm, rws, h_hist));
+        // per-tile counts in one pass over the rows' first eight bytes
+        for (;;) {
+            uint64_t h_andor[2];
+            UQ_TRY(radix_rows_prefix_census32(ctx, table, C, n, z, k32a, d_perm, rws, h_hist, h_andor));
+            const uint32_t zt = leading_same(h_andor[0], h_andor[1]);
+            if (zt >= z) break;
+            z = zt;                                                             // the sample agreed on more bits than the table does: once more
+        }
         // expected share of rows that tie on the prefix if its bytes were independent: n * prod_p sum_d (h[p][d] / n)^2
         double coll = (double)n;
         for (int p = 0; p < 4; ++p) {
@@ -388,7 +367,8 @@ int sort_rows_core(uq_ctx* ctx, const uint8_t* table, uint64_t n, uint32_t C, ui
         }
     }
     if (!mode32) {
-        if (!numbered) { iota_kernel<<<blocks_for(n), ST, 0, s>>>(valsA, n); UQ_LAUNCH_CHECK(); }
+        extract_all_kernel<<<blocks_for(n), ST, 0, s>>>(table, n, C, keysA, valsA);
+        UQ_LAUNCH_CHECK();
         UQ_TRY(radix_sort_pairs(ctx, keysA, valsA, keysB, valsB, n, 0, 64, rws, &alt));
         const uint64_t* K = alt ? keysB : keysA;
         const uint32_t* V = alt ? valsB : valsA;
