@@ -578,6 +578,62 @@ def test_queued_census_index_pack_equals_the_plain_calls(ctx, length, kw):
     assert cen.wait()[0] == nl
 
 
+@pytest.mark.parametrize('shape', ['ragged', 'long-reads', 'mixed', 'short-lines', 'offset-buffer'])
+def test_pack_from_the_census_lists_on_awkward_streams(ctx, shape):
+    """The queued QNAME form without an index (line_start = None) against the indexed form on streams that stress the walk through the
+    census's lists: reads from a few bases to the longest a tile holds (census tiles with a newline or two, pack tiles packed piece by piece,
+    places found by the per-piece search), a few hundred newlines per census tile (just under a list's capacity), and a buffer that
+    does not start 16-byte aligned.  Same tables, same statistics, same QNAME field values -- or both forms flagged incomplete."""
+    t = ctx.torch
+    rng = np.random.default_rng(hash(shape) % 1000)
+    if shape == 'ragged': lens = rng.integers(1, 400, 6000)
+    elif shape == 'long-reads': lens = rng.integers(2500, 7800, 300)             # records of 5 - 16 KB: a pack tile holds one or two, often packed piece by piece
+    elif shape == 'mixed': lens = np.where(rng.random(3000) < 0.03, rng.integers(3000, 7500, 3000), rng.integers(20, 300, 3000))
+    elif shape == 'short-lines': lens = rng.integers(27, 35, 40000)          # ~ 78 bytes a record: ~ 840 newlines per 16 KiB tile, under a list's 1024
+    else: lens = rng.integers(50, 260, 5000)
+    recs = []
+    for i, L in enumerate(lens):
+        L = int(L)
+        recs.append(b'@r%d:%d:%d\n' % (i % 4, i, int(rng.integers(0, 100000))) + bytes(rng.choice(np.frombuffer(b'ACGT', np.uint8), L)) + b'\n+\n' +
+                    bytes(rng.integers(40, 75, L).astype(np.uint8)) + b'\n')
+    text = np.frombuffer(b''.join(recs), dtype=np.uint8)
+    n = len(lens)
+    if shape == 'offset-buffer':
+        back = ctx.empty(text.size + 16)
+        d_buf = back[5:5 + text.size]
+        d_buf.copy_(t.from_numpy(text.copy()))
+    else:
+        d_buf = ctx.to_device(text)
+    nl = ops.count_lines(ctx, d_buf)
+    assert nl == 4 * n
+    ls = ops.index_lines(ctx, d_buf, nl)
+    assert np.array_equal(ctx.to_numpy(ls, np.uint64), oracle_c.index_lines(text))
+    guess = ops.head_guess_indexed(ctx, d_buf, ls, n)
+    assert guess is not None
+    guess.avg_record_bytes = int(text.size // n)
+    fa, fb = ops.FusedQname(ctx, n), ops.FusedQname(ctx, n + 9)
+    ops.qname_guess(ctx, d_buf, ls, n, fa)
+    ref = ops.pack_stats(ctx, d_buf, ls, 0, n, guess, fq=fa)
+    assert ref is not None
+    ops.qname_fused_finish(ctx, fa); qa = ops.qname_fused_fetch(ctx, fa)
+    cen = ops.ChunkedCensus(ctx, d_buf); cen.chunk(0, d_buf.numel()); cen.end_async()
+    ops.qname_guess_async(ctx, d_buf, None, fb)
+    got = ops.pack_stats_async(ctx, d_buf, None, n + 9, guess, fq=fb)
+    assert got is not None
+    ops.qname_fused_finish(ctx, fb)
+    nl2, ok = cen.wait()
+    qb = ops.qname_fused_fetch(ctx, fb)
+    assert nl2 == nl
+    ha, hb = ops.stats_fetch(ctx, ref[3]), ops.stats_fetch(ctx, got[3])
+    assert ok and not ha.incomplete and not hb.incomplete    # (the guess saw every read: nothing may fall outside it; no list overflows)
+    if True:
+        assert t.equal(got[0][:n * guess.dna_bytes_per_row], ref[0]) and t.equal(got[1][:n * guess.quality_bytes_per_row], ref[1])
+        assert np.array_equal(ha.counts, hb.counts) and (ha.len_min, ha.len_max, ha.max_record_bytes) == (hb.len_min, hb.len_max, hb.max_record_bytes)
+        if qa.ok and qb.ok and qa.flags == 0 and qb.flags == 0:
+            assert (qa.plen, qa.slen, qa.nsep, qa.nreads) == (qb.plen, qb.slen, qb.nsep, qb.nreads)
+            for c in range(qa.nsep + 1): assert t.equal(fa.column(c, n), fb.column(c, n))
+
+
 @pytest.mark.parametrize('bases', [b'ACGNT', b'ACGTRYKM', b'ACGTacg', b'ACGTBDH', b'ACGTIJ'], ids=lambda b: b.decode())
 def test_pack_three_bit_alphabets(ctx, bases):
     """3-bit base alphabets: the lookup-free pack path when three bits of the characters tell the bases apart ((c >> s) & 7 for

@@ -808,6 +808,12 @@ static int pack_impl(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_s
         if (R > (PK_THREADS - 1) / 4) R = (PK_THREADS - 1) / 4;
         if (R < Rs) R = Rs;
     }
+    // ... but the rows of a tile are sized for the LONGEST read: a file of short reads with a few long ones among them must not ask for
+    // R rows of the long kind in LDS (a request beyond the CU's 160 KiB ended the call with an error instead of a slower tile)
+    {
+        const uint32_t out_cap = stage_cap * 3 / 4, fit = out_cap / (Cd + Cq);
+        if (R > fit) R = fit > Rs ? fit : Rs;
+    }
     // R a multiple of 16 keeps every tile's output offset 16-byte aligned (uint4 stores); when that would waste
     // more than ~15 % of the tile, settle for a multiple of 8 or 4 (8- / 4-byte stores)
     if (R >= 4) {
