@@ -39,14 +39,11 @@ __global__ __launch_bounds__(ST) void extract_all_kernel(const uint8_t* __restri
     const uint64_t i = (uint64_t)blockIdx.x * ST + threadIdx.x;
     if (i < n) { keys[i] = load_chunk_be(table + i * C, C, 0); vals[i] = (uint32_t)i; }
 }
-// AND / OR over chunk 0 of `samples` rows spread evenly over the table: the guess for the leading bits every row agrees on
-__global__ __launch_bounds__(ST) void sample_andor_kernel(const uint8_t* __restrict__ table, uint64_t n, uint32_t C, uint64_t samples, unsigned long long* __restrict__ out) {
+// chunk 0 of `samples` rows spread evenly over the table, straight into the pinned staging: the host guesses from them how many leading bits
+// every row agrees on and whether the rows crowd on few prefixes
+__global__ __launch_bounds__(ST) void sample_chunks_kernel(const uint8_t* __restrict__ table, uint64_t n, uint32_t C, uint64_t samples, uint64_t* __restrict__ out) {
     const uint64_t j = (uint64_t)blockIdx.x * ST + threadIdx.x;
-    unsigned long long a = ~0ull, o = 0ull;
-    if (j < samples) { const uint64_t row = samples > 1 ? j * (n - 1) / (samples - 1) : 0; a = o = load_chunk_be(table + row * C, C, 0); }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { a &= __shfl_xor(a, d, 64); o |= __shfl_xor(o, d, 64); }
-    if (lane_id() == 0) { atomicAnd(out, a); atomicOr(out + 1, o); }
+    if (j < samples) out[j] = load_chunk_be(table + (samples > 1 ? j * (n - 1) / (samples - 1) : 0) * C, C, 0);
 }
 __global__ void iota_kernel(uint32_t* __restrict__ v, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * ST + threadIdx.x;
@@ -312,16 +309,35 @@ int sort_rows_core(uq_ctx* ctx, const uint8_t* table, uint64_t n, uint32_t C, ui
     // it on every row (AND / OR over all chunks) and runs again in the rare case that the sample agreed on more bits than the table.
     auto leading_same = [](uint64_t a, uint64_t o) { const uint64_t same = ~(a ^ o); uint32_t z = 0; while (z < 64 && ((same >> (63 - z)) & 1)) ++z; return z; };
     uint32_t z = 0;
+    auto collisions = [](const uint32_t* hist, double total, double rows) {      // expected share of rows that tie on the 32-bit prefix if its bytes were independent: n * prod_p sum_d (h[p][d] / n)^2
+        double coll = rows;
+        for (int p = 0; p < 4; ++p) {
+            double c2 = 0;
+            for (int d = 0; d < 256; ++d) { const double q = (double)hist[p * 256 + d] / total; c2 += q * q; }
+            coll *= c2;
+        }
+        return coll;
+    };
     if (mode32) {
-        UQ_CHECK_HIP(hipMemsetAsync(tot + 4, 0xFF, 8, s));
-        UQ_CHECK_HIP(hipMemsetAsync(tot + 5, 0, 8, s));
-        const uint64_t samples = n < 4096 ? n : 4096;
-        sample_andor_kernel<<<(uint32_t)((samples + ST - 1) / ST), ST, 0, s>>>(table, n, C, samples, (unsigned long long*)(tot + 4));
+        const uint64_t samples = 4096;                                           // (n >= 65536 here)
+        sample_chunks_kernel<<<(uint32_t)((samples + ST - 1) / ST), ST, 0, s>>>(table, n, C, samples, (uint64_t*)ctx->d_pinned);
         UQ_LAUNCH_CHECK();
-        UQ_TRY(uq_read_back(ctx, ctx->h_pinned + 4, tot + 4, 16));
         UQ_CHECK_HIP(hipStreamSynchronize(s));
-        z = leading_same(ctx->h_pinned[4], ctx->h_pinned[5]);
+        uint64_t a = ~0ull, o = 0;
+        for (uint64_t j = 0; j < samples; ++j) { a &= ctx->h_pinned[j]; o |= ctx->h_pinned[j]; }
+        z = leading_same(a, o);
         mode32 = z <= 32;
+        if (mode32) {
+            // crowded tables (a QUAL table of 200 M rows on its first 32 bits) go to the 64-bit round 0 without the pass below: the sample's own digit
+            // census overestimates the collisions of spread-out keys by a quarter (a sample of 4096 adds 1 / 4096 to each sum of squares), far from the threshold
+            static thread_local uint32_t s_hist[4 * 256];
+            memset(s_hist, 0, sizeof(s_hist));
+            for (uint64_t j = 0; j < samples; ++j) {
+                const uint32_t k = (uint32_t)((ctx->h_pinned[j] << z) >> 32);
+                ++s_hist[k & 255u]; ++s_hist[256 + ((k >> 8) & 255u)]; ++s_hist[512 + ((k >> 16) & 255u)]; ++s_hist[768 + (k >> 24)];
+            }
+            if (collisions(s_hist, (double)samples, (double)n) > 0.6) mode32 = false;
+        }
     }
     int alt = 0;
     if (mode32) {
@@ -337,13 +353,7 @@ int sort_rows_core(uq_ctx* ctx, const uint8_t* table, uint64_t n, uint32_t C, ui
             if (zt >= z) break;
             z = zt;                                                             // the sample agreed on more bits than the table does: once more
         }
-        // expected share of rows that tie on the prefix if its bytes were independent: n * prod_p sum_d (h[p][d] / n)^2
-        double coll = (double)n;
-        for (int p = 0; p < 4; ++p) {
-            double c2 = 0;
-            for (int d = 0; d < 256; ++d) { const double q = (double)h_hist[p * 256 + d] / (double)n; c2 += q * q; }
-            coll *= c2;
-        }
+        const double coll = collisions(h_hist, (double)n, (double)n);
         if (coll > 0.3) mode32 = false;
         else {
             UQ_TRY(radix_sort_pairs32(ctx, k32a, d_perm, k32b, valsB, n, 0, 32, rws, &alt, h_hist, 1));
