@@ -206,6 +206,24 @@ def test_200M_x150_single_gpu_encode(ctx):
         assert bool((ls[a + 1:b + 1] > ls[a:b]).all()) and bool((buf[ls[a + 1:b + 1] - 1] == 10).all())
     assert _payload(s, 'DNA.raw').numel() == N * 38 and _payload(s, 'QUAL.raw').numel() == N * 113
     (dna, _, Cd), (qual, _, Cq) = s.tables['DNA'], s.tables['QUAL']
+    # the queued step without a record index (bench.py's step: the pack kernel and the QNAME sample walk the census's newline lists; 4.1 M
+    # census tiles, positions beyond 2^32): the same tables, every QNAME field value what the session's columns hold
+    guess = ops.head_guess_indexed(ctx, buf, ls, N)
+    cen = ops.ChunkedCensus(ctx, buf); cen.chunk(0, buf.numel()); cen.end_async()
+    fq = ops.FusedQname(ctx, N + 1000)
+    ops.qname_guess_async(ctx, buf, None, fq)
+    got = ops.pack_stats_async(ctx, buf, None, N + 1000, guess, fq=fq)
+    assert got is not None
+    ops.qname_fused_finish(ctx, fq)
+    assert cen.wait() == (4 * N, True)
+    hq = ops.stats_fetch(ctx, got[3])
+    assert not hq.incomplete and np.array_equal(hq.counts, hs.counts)
+    assert t.equal(got[0][:N * Cd], dna.view(-1)[:N * Cd]) and t.equal(got[1][:N * Cq], qual.view(-1)[:N * Cq])
+    from uq_amd import qname_device
+    qres = qname_device.analyse_fused(ctx, fq, N)
+    assert qres is not None and list(qres[:3]) == [s.config['QNAME_prefix'], s.config['QNAME_suffix'], s.config['QNAME_separators']]
+    assert qres[3] == s.config['QNAME_columns']
+    del got, fq, qres, cen
     s.d_ls = s.d_stats = ls = None
     _free(ctx)
     text = s.decode_text(dict(s.config), (dna, N, Cd), (qual, N, Cq), s.tables['QNAME'])
