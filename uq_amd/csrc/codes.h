@@ -31,6 +31,7 @@ static inline FastAlphabet fast_alphabet(const uq_unpack_params* hp) {
     a.qmin4 = 0x01010101u * hp->qual_char[0];
     a.q_over = 0x01010101u * (uint32_t)(0x80 - nq);
     a.has_n = (uint32_t)ncodes; a.n_code4 = 0x01010101u * (uint32_t)ncode; a.n_char4 = 0x01010101u * hp->qual_n_base[ncode];
+    if (bd == 2 && ncodes) a.base_tab_hi = a.n_char4;        // selectors 4 .. 7 (no base of a 2-bit alphabet): the N-trick's character (emit.hip: n_selectors)
     return a;
 }
 

@@ -153,6 +153,10 @@ __device__ __forceinline__ uint32_t load_u32_any(const uint8_t* p) { uint32_t v;
 // ---- packed form, fast alphabet: eight symbols per lane without per-symbol work
 // byte k of the result = bits (7 - 2k .. 6 - 2k) of x: the four 2-bit base codes of one row byte, in text order
 __device__ __forceinline__ uint32_t spread2(uint32_t x) { return ((x >> 6) | (x << 4) | (x << 14) | (x << 24)) & 0x03030303u; }
+// 2-bit alphabets with the N-trick: where the quality code (one per byte, below 128) is the N-trick's, the base's selector becomes 4 + code -- and
+// base_tab_hi, unused by four bases, holds the N character four times (fast_alphabet): the N replaces the base inside the v_perm that looks the
+// bases up (five instructions per four characters; comparing, widening the flags to byte masks and blending took ten)
+__device__ __forceinline__ uint32_t n_selectors(uint32_t codes, uint32_t q, uint32_t n_code4) { return codes | ((~((q ^ n_code4) + 0x7F7F7F7Fu) & 0x80808080u) >> 5); }
 // ---- LDS access on gfx950 (tools/ldsbench.hip, profiles/r02_l_ldsbench.txt): a wave-instruction at its natural alignment
 // takes 3 - 7 cycles; the same instruction at a misaligned address takes 40 (reads) or 128 (writes) -- the lanes go one
 // by one.  So the decoder works from the DESTINATION: a lane produces one 8-byte-aligned chunk of the text image, and
@@ -509,8 +513,9 @@ __global__ __launch_bounds__(EM_THREADS, 4) void emit_tile_kernel(EmitGeom g, Ti
                             uint8_t* base = tile + (ds & ~7u) + 8 * K * m;
 #pragma unroll
                             for (int c = 0; c < K; ++c) {
+                                if (HASN && fa.bd == 2) { lo[c] = n_selectors(lo[c], nlo[c], fa.n_code4); hi[c] = n_selectors(hi[c], nhi[c], fa.n_code4); }
                                 uint32_t blo = __builtin_amdgcn_perm(fa.base_tab_hi, fa.base_tab, lo[c]), bhi = __builtin_amdgcn_perm(fa.base_tab_hi, fa.base_tab, hi[c]);
-                                if constexpr (HASN) {
+                                if (HASN && fa.bd != 2) {
                                     const uint32_t mlo = ~nonzero_bytes(nlo[c] ^ fa.n_code4), mhi = ~nonzero_bytes(nhi[c] ^ fa.n_code4);
                                     blo = bfi(mlo, fa.n_char4, blo); bhi = bfi(mhi, fa.n_char4, bhi);
                                 }
@@ -877,8 +882,9 @@ __global__ __launch_bounds__(EM_THREADS, 4) void decode_stream_kernel(EmitGeom g
                     uint32_t over = 0;
 #pragma unroll
                     for (int c = 0; c < K; ++c) {
+                        if (HASN && fa.bd == 2) { blo[c] = n_selectors(blo[c], qlo[c], fa.n_code4); bhi[c] = n_selectors(bhi[c], qhi[c], fa.n_code4); }
                         blo[c] = __builtin_amdgcn_perm(fa.base_tab_hi, fa.base_tab, blo[c]); bhi[c] = __builtin_amdgcn_perm(fa.base_tab_hi, fa.base_tab, bhi[c]);
-                        if constexpr (HASN) {
+                        if (HASN && fa.bd != 2) {
                             const uint32_t mlo = ~nonzero_bytes(qlo[c] ^ fa.n_code4), mhi = ~nonzero_bytes(qhi[c] ^ fa.n_code4);
                             blo[c] = bfi(mlo, fa.n_char4, blo[c]); bhi[c] = bfi(mhi, fa.n_char4, bhi[c]);
                         }
