@@ -237,10 +237,16 @@ __global__ void qname_guess_kernel(const DevLine1* __restrict__ g_l1, const uq_q
     bool mine = false, special = false;
     if (t < l1->nch && lay->entry[t] != UQ_NONE && lay->lastviol[t] < lay->entry[t]) {
         const uint8_t c = l1->ch[t];
-        int mid = 0;                                          // l1[plen:].count(c) - suffix.count(c)
-        for (uint32_t p = plen; p < len - slen; ++p) mid += l1->text[p] == c;
+        int mid = 0, ord = 0;                                 // l1[plen:].count(c) - suffix.count(c); its occurrences in the slice the ORDER is read from
+        for (uint32_t p = plen; p < len - slen; ++p) { mid += l1->text[p] == c; ord += (p + 1 < len - slen) && l1->text[p] == c; }
         mine = mid != 0;
         special = mine && regex_special(c);                   // '[seps]+' and '(.*)'.join(seps) are regexes in the reference: the host's `re` path
+        // The pack kernel holds every read to the ORDERED separators, which the reference reads from l1[plen : len - 1 - slen] (Q14: one
+        // character short) -- while its per-read rule counts each separator over the whole middle.  A separator whose occurrences the slice
+        // does not all show (it is line 1's last character before the suffix: `@q_0=1`, `@q_1=4` make '1' one) is in the reference's set but
+        // not in the order: what the reference then does depends on the LAST read (uq.py:438-444), which no per-read check reproduces.  A
+        // digit as separator is left to the exact path as well (the fields are decimal numbers here).
+        if (mine && (ord != mid || (c >= '0' && c <= '9'))) special = true;
     }
     s_sep[t] = mine ? 1 : 0;
     const uint32_t nsepch = (uint32_t)__popcll(__ballot(mine));
