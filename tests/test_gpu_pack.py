@@ -634,6 +634,50 @@ def test_pack_from_the_census_lists_on_awkward_streams(ctx, shape):
             for c in range(qa.nsep + 1): assert t.equal(fa.column(c, n), fb.column(c, n))
 
 
+@pytest.mark.parametrize('seed', range(int(__import__('os').environ.get('UQ_LIST_FUZZ_N', '40'))))        # UQ_LIST_FUZZ_N=2000 for a longer hunt
+def test_pack_from_the_census_lists_fuzz(ctx, seed):
+    """The CLI fuzz's random FASTQ files (alphabets of 2 - 14 bases, quality alphabets with gaps, fixed / variable lengths from 1 bp, QNAME
+    families the reference copes with or refuses) through both queued QNAME forms: with the expanded index and from the census's lists.
+    Where the pack kernel has a fused form for the file's alphabets: same tables, same statistics (complete or not), and -- when both
+    QNAME guesses stand -- the same field values."""
+    from test_gpu_e2e import _fuzz_case
+    t = ctx.torch
+    fq, _ = _fuzz_case(np.random.default_rng(770_000 + seed))
+    text = np.frombuffer(fq, dtype=np.uint8)
+    d_buf = ctx.to_device(text)
+    nl = ops.count_lines(ctx, d_buf)
+    n = nl // 4
+    ls = ops.index_lines(ctx, d_buf, nl)
+    guess = ops.head_guess_indexed(ctx, d_buf, ls, n)
+    if guess is None: return                                  # (Q9 alphabets, malformed heads: no speculative kernel)
+    fa, fb = ops.FusedQname(ctx, n), ops.FusedQname(ctx, n + 3)
+    ops.qname_guess(ctx, d_buf, ls, n, fa)
+    ref = ops.pack_stats(ctx, d_buf, ls, 0, n, guess, fq=fa)
+    cen = ops.ChunkedCensus(ctx, d_buf); cen.chunk(0, d_buf.numel()); cen.end_async()
+    ops.qname_guess_async(ctx, d_buf, None, fb)
+    got = ops.pack_stats_async(ctx, d_buf, None, n + 3, guess, fq=fb)
+    assert (ref is None) == (got is None)
+    if got is not None: ops.qname_fused_finish(ctx, fb)
+    nl2, ok = cen.wait()
+    assert nl2 == nl
+    if ref is None: return                                    # no fused kernel for these alphabets
+    if not ok:                                                # reads of a few bases: more than 1024 newlines in a census tile, the list form stands down
+        assert ops.stats_fetch(ctx, got[3]).incomplete
+        return
+    qb = ops.qname_fused_fetch(ctx, fb)
+    ops.qname_fused_finish(ctx, fa); qa = ops.qname_fused_fetch(ctx, fa)
+    ha, hb = ops.stats_fetch(ctx, ref[3]), ops.stats_fetch(ctx, got[3])
+    assert ha.incomplete == hb.incomplete
+    if not ha.incomplete:
+        assert t.equal(got[0][:n * guess.dna_bytes_per_row], ref[0]) and t.equal(got[1][:n * guess.quality_bytes_per_row], ref[1])
+        assert np.array_equal(ha.counts, hb.counts) and (ha.len_min, ha.len_max, ha.max_record_bytes) == (hb.len_min, hb.len_max, hb.max_record_bytes)
+        st = oracle_c.stats(text, oracle_c.index_lines(text), 0, n)
+        assert np.array_equal(hb.counts, st['counts'])
+    if qa.ok and qb.ok and qa.flags == 0 and qb.flags == 0:
+        assert (qa.plen, qa.slen, qa.nsep, qa.nreads, bytes(qa.seps)) == (qb.plen, qb.slen, qb.nsep, qb.nreads, bytes(qb.seps))
+        for c in range(qa.nsep + 1): assert t.equal(fa.column(c, n), fb.column(c, n))
+
+
 @pytest.mark.parametrize('bases', [b'ACGNT', b'ACGTRYKM', b'ACGTacg', b'ACGTBDH', b'ACGTIJ'], ids=lambda b: b.decode())
 def test_pack_three_bit_alphabets(ctx, bases):
     """3-bit base alphabets: the lookup-free pack path when three bits of the characters tell the bases apart ((c >> s) & 7 for

@@ -110,6 +110,45 @@ def test_argsort_rows_stable(ctx, n, C, nd, prefix):
     assert np.array_equal(got, O.argsort_rows(T))
 
 
+@pytest.mark.parametrize('C', [12, 38, 113])
+@pytest.mark.parametrize('shape', ['constant-lead', 'lead-the-sample-misses', 'crowded', 'crowded-behind-the-sample', 'two-values', 'sorted-input'])
+def test_argsort_round0_paths(ctx, shape, C):
+    """The 32-bit round 0 of the row sort (tables of 65 536 rows and more, rows wider than 8 bytes) takes the number of constant leading bits and
+    the crowding of the prefixes from a sample of 4096 rows and checks the former on every row: tables whose leading bits are constant, whose only
+    rows with another leading bit the sample misses (the pass runs again with the true count), that crowd on few prefixes (64-bit round 0 at once),
+    that crowd but look spread in the sample (64-bit round 0 after the 32-bit pass), of two row values, and already sorted ones."""
+    rng = np.random.RandomState(len(shape) * 131 + C)
+    n = 100_003
+    T = rng.randint(0, 256, size=(n, C)).astype(np.uint8)
+    sampled = set(int(j * (n - 1) // 4095) for j in range(4096))
+    if shape == 'constant-lead':
+        T[:, 0] = 0x00; T[:, 1] = (T[:, 1] & 0x0F) | 0x30
+    elif shape == 'lead-the-sample-misses':
+        T[:, 0] = 0x00; T[:, 1] &= 0x0F
+        odd = [i for i in (12345, 77777, 3, n - 2) if i not in sampled]
+        assert odd
+        T[odd, 0] = 0x80
+    elif shape == 'crowded':
+        heads = rng.randint(0, 256, size=(50, 8)).astype(np.uint8)
+        T[:, :8] = heads[rng.randint(0, 50, size=n)]
+    elif shape == 'crowded-behind-the-sample':
+        # every sampled row has a prefix of its own, everything else crowds on three
+        heads = rng.randint(0, 256, size=(3, 8)).astype(np.uint8)
+        rest = np.array([i for i in range(n) if i not in sampled])
+        T[rest, :8] = heads[rng.randint(0, 3, size=len(rest))]
+    elif shape == 'two-values':
+        two = rng.randint(0, 256, size=(2, C)).astype(np.uint8)
+        two[1, :C - 1] = two[0, :C - 1]; two[1, C - 1] ^= 1
+        T = two[rng.randint(0, 2, size=n)]
+    else:
+        T = T[O.argsort_rows(T)]
+    perm = ops.argsort_rows(ctx, _dev(ctx, T.ravel()), n, C)
+    assert np.array_equal(ctx.to_numpy(perm, np.uint32).astype(np.int64), O.argsort_rows(T))
+    p2, key, skey, uniq, nu = ops.unique_rows(ctx, _dev(ctx, T.ravel()), n, C)
+    ru, rkey = O.unique_rows(T)
+    assert nu == len(ru) and np.array_equal(ctx.to_numpy(uniq).reshape(nu, C), ru) and np.array_equal(ctx.to_numpy(key, np.uint32).astype(np.int64), rkey)
+
+
 @pytest.mark.parametrize('n,C,nd,prefix', SORT_CASES, ids=lambda v: str(v))
 def test_unique_rows(ctx, n, C, nd, prefix):
     rng = np.random.RandomState(n * 3 + C)
