@@ -435,6 +435,52 @@ def test_decode_fixed_lengths_chunks_per_lane(ctx, L, with_n):
         assert a[offs[r]:offs[r + 1]].tobytes() == host[offs[r]:offs[r + 1]].tobytes()
 
 
+@pytest.mark.parametrize('seed', range(int(__import__('os').environ.get('UQ_DECODE_FUZZ_N', '40'))))       # UQ_DECODE_FUZZ_N=1000 for a longer hunt
+def test_decode_fixed_lengths_random(ctx, seed):
+    """Random fixed-length tables for the tile kernel's multi-chunk instances (the CLI fuzz keeps fixed lengths below 40): lengths 40 - 600 on
+    both sides of the switch at 66, 3 - 64 qualities (2 - 6 bits), 2- and 3-bit base alphabets, with and without the N-trick, one to several
+    tiles with a ragged last one, QNAME columns of one to four fields -- decode(pack(x)) == x through uq_decode_fastq and the two-pass decoder."""
+    from uq_amd import qname
+    rng = np.random.default_rng(424_200 + seed)
+    L = int(rng.integers(40, 600))
+    n = int(rng.integers(1, max(2, 120_000 // L)))
+    nq = int(rng.choice([3, 4, 7, 8, 15, 16, 20, 31, 41, 64]))
+    six = rng.random() < 0.25
+    with_n = (not six) and rng.random() < 0.5
+    nf = int(rng.integers(1, 5))
+    B = np.frombuffer(b'ACGTRY' if six else b'ACGT', np.uint8)
+    recs = []
+    for i in range(n):
+        seq = rng.choice(B, L)
+        q = rng.integers(40, 40 + nq, L).astype(np.uint8)
+        if with_n:
+            at = rng.random(L) < 0.03
+            seq[at] = ord('N'); q[at] = 35
+        name = b'@r' + b':'.join(b'%d' % int(rng.integers(0, 10 ** int(rng.integers(1, 9)))) for _ in range(nf)) + b':%d' % i
+        recs.append(name + b'\n' + bytes(seq) + b'\n+\n' + bytes(q) + b'\n')
+    host = np.frombuffer(b''.join(recs), dtype=np.uint8)
+    hls = oracle_c.index_lines(host)
+    st = oracle_c.stats(host, hls, 0, n)
+    d = O.decide(O.histogram_to_static_qualities(st['counts'], st['first_seen']), st['len_min'], st['len_max'])
+    if d['N_qual'] and max(d['N_qual'].values()) >= len(d['qualities']): return          # Q9: not decodable by the reference either
+    rd, rq, _ = oracle_c.pack(host, hls, 0, n, d['bases'], d['qualities'], d['N_qual'], d['bits_per_base'], d['bits_per_quality'],
+                              d['variable_read_lengths'], d['dna_bytes_per_row'], d['quality_bytes_per_row'])
+    try:
+        prefix, suffix, separators, columns, arrays = qname.analyse(qname.qname_lines(host, hls, n))
+    except qname.QnameError:
+        return
+    cfg = dict(bases=d['bases'], qualities=d['qualities'], N_qual=d['N_qual'], bits_per_base=d['bits_per_base'],
+               bits_per_quality=d['bits_per_quality'], variable_read_lengths=d['variable_read_lengths'], dna_max=d['dna_max'],
+               QNAME_prefix=prefix, QNAME_suffix=suffix, QNAME_separators=separators, QNAME_columns=columns)
+    cols = [_dev(ctx, np.ascontiguousarray(a)) for a in arrays]
+    ops.scribble_lds(ctx, 0x3C3C3C3C ^ seed)
+    dna, qual = _dev(ctx, rd.ravel()), _dev(ctx, rq.ravel())
+    text, bad = ops.decode_fastq(ctx, cfg, cols, dna, qual, n)
+    assert bad is None and ctx.to_numpy(text).tobytes() == host.tobytes(), (L, n, nq, six, with_n)
+    seq, qt, ln, ubad = ops.unpack(ctx, dna, qual, n, ops.make_unpack_params(cfg))
+    assert ctx.to_numpy(ops.emit_fastq(ctx, cfg, cols, seq, qt, ln, n)).tobytes() == host.tobytes()
+
+
 @pytest.mark.parametrize('variable', [False, True], ids=['fixed', 'variable'])
 @pytest.mark.parametrize('with_n', [False, True, 'six'], ids=['acgt', 'n-trick', 'six-bases'])
 @pytest.mark.parametrize('nq', [3, 4, 6, 12, 20, 41, 70], ids=lambda v: 'q%d' % v)
