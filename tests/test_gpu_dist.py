@@ -90,7 +90,7 @@ def test_sharded_encode_with_idle_ranks(tmp_path):
     _check(tmp_path, 3, ['--raw', 'DNA', 'QUAL', 'QNAME'], fq=fq)
 
 
-@pytest.mark.parametrize('seed', [1000, 1007, 1013, 1021, 1034, 1046])
+@pytest.mark.parametrize('seed', [1000, 1007, 1013, 1021, 1034, 1046] + list(range(int(os.environ.get('UQ_DIST_FUZZ_FROM', '5000')), int(os.environ.get('UQ_DIST_FUZZ_FROM', '5000')) + int(os.environ.get('UQ_DIST_FUZZ_N', '0')))))      # UQ_DIST_FUZZ_N=100: a longer hunt
 def test_sharded_encode_fuzz(tmp_path, seed):
     """Random alphabets / widths / lengths / flag mixes (the generator of test_gpu_e2e's CLI fuzz) through 2 or 3 ranks;
     tiny files leave ranks without reads."""
@@ -102,7 +102,7 @@ def test_sharded_encode_fuzz(tmp_path, seed):
         O.encode(fq, **_oracle_flags(flags))
     except (O.UqError, ValueError, IndexError, re.error):
         pytest.skip('the reference refuses this input')
-    _check(tmp_path, 2 + seed % 2, flags, fq=fq)
+    _check(tmp_path, 2 + seed % (2 if seed < 5000 else 3), flags, fq=fq)
 
 
 def _check(tmp_path, world, flags, backend='gloo', fq=None):
