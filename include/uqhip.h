@@ -322,7 +322,10 @@ int uq_scatter_rows(uq_ctx* ctx, const uint8_t* d_values, uint64_t n, uint32_t c
  *   uq_qname_guess[_async]  line 1 of the file and the layout reductions of uq_qname_layout (min lcp / lcs, entry / lastviol per
  *       character of line 1) over a stratified pseudo-random sample of ~4096 reads -> prefix / suffix lengths and the ordered separators, left in
  *       *d_q (ok = 1), or ok = 0 when the guess declines (no separator, regex metacharacters, > UQ_QF_MAXC columns, a first line
- *       beyond 255 bytes, ...): the pack kernel then leaves the QNAME lines alone and the caller runs uq_qname_layout / _tokenise.
+ *       beyond 255 bytes, a digit among the separators, a separator that occurs in line 1 outside the slice the reference reads the ORDER
+ *       from -- uq.py:433-436 drops the last character before the suffix, its per-read rule (410-413) counts over the whole middle: such a
+ *       character is in the reference's set but not in its order, and what happens then hangs on the LAST read alone -- ...): the pack
+ *       kernel then leaves the QNAME lines alone and the caller runs uq_qname_layout / _tokenise.
  *   uq_pack_stats_qname[_async]  = uq_pack_stats[_async] + per read: the line starts with line1[:plen] and ends with
  *       line1[l1len - slen:], its middle holds exactly the separators in order, every field is the canonical decimal of a value
  *       below 10^9 (digits only, no sign, no leading zero), the line is no proper prefix / suffix of line 1; d_vals[c * pitch + r]
