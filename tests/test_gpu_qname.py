@@ -319,6 +319,40 @@ def test_fused_pass_demotion_and_offsets(ctx):
         assert _fused(ctx, _fastq(names))[0] == 'declined', bad
 
 
+@pytest.mark.parametrize('seed', range(int(__import__('os').environ.get('UQ_TYPING_FUZZ_N', '10'))))      # UQ_TYPING_FUZZ_N=300 for a longer hunt
+def test_fused_pass_typing_random(ctx, seed):
+    """Column typing across the reference's checkpoints (10 000, 20 000, 40 000 reads and the last one: uq.py:586-602): random files of 9 000 -
+    45 000 reads whose columns grow their sets of distinct values in different ways -- constant, cyclic with a random period, serial, random
+    in a random range, cyclic up to a random read and serial after it, a few values with a late newcomer.  Whatever the fused pass answers
+    is the oracle's answer (descriptions, dtypes, offsets, arrays); the exact device path likewise."""
+    rng = np.random.default_rng(31_000 + seed)
+    n = int(rng.integers(9000, 45000))
+    nf = int(rng.integers(1, 5))
+    kinds = []
+    for _ in range(nf):
+        k = ['const', 'cyc', 'serial', 'rand', 'late', 'newcomer'][int(rng.integers(0, 6))]
+        kinds.append((k, int(rng.choice([2, 7, 64, 255, 256, 257, 900, 1100, 3000, 4095, 4097, 70000, 1 << 20, (1 << 20) + 5, 3_000_000])),
+                      int(rng.integers(0, n)), int(rng.choice([0, 1, 1000, 65000, 10 ** 6]))))
+    seps = [':_/#;'[int(rng.integers(0, 5))] for _ in range(nf)]
+    cols = []
+    for k, p, t0, base in kinds:
+        i = np.arange(n, dtype=np.int64)
+        if k == 'const': v = np.full(n, base)
+        elif k == 'cyc': v = base + i % p
+        elif k == 'serial': v = base + i
+        elif k == 'rand': v = base + rng.integers(0, p, n)
+        elif k == 'late': v = base + np.where(i < t0, i % min(p, 997), i)
+        else: v = base + np.where(i == t0, p, i % 3)
+        cols.append(v)
+    names = []
+    for r in range(n):
+        name = b'@run'
+        for c in range(nf):
+            name += seps[c].encode() + b'%d' % int(cols[c][r])
+        names.append(name)
+    assert _check(ctx, _fastq(names)) in ('ok', 'error', 'declined')
+
+
 def test_mutated_names_differential(ctx):
     """Adversarial for the closed form of uq.py:394-413: names are point mutations of line 1 over a tiny alphabet,
     so characters enter the separator table at different records and are knocked out before / after entering."""
