@@ -288,6 +288,29 @@ def test_cli_fuzz_against_oracle(ctx, tmp_path, seed):
     if of['sort'] is None: assert text == fq
 
 
+@pytest.mark.parametrize('shape', ['few-long-among-short', 'one-beyond-a-tile', 'all-long'])
+def test_cli_mixed_read_lengths(ctx, tmp_path, shape):
+    """Files whose longest read is far above the average: the pack kernel sizes its tiles from the average record and its rows from the longest one
+    (a file of short reads with a few of 5 - 8 kbp once asked for more LDS than a CU has and the encode ended in an error); a read beyond one
+    tile (30 kbp) takes the exact thread-per-read kernels.  Members == oracle, decode == input."""
+    rng = np.random.default_rng(len(shape))
+    if shape == 'few-long-among-short': lens = [int(x) for x in np.where(rng.random(1500) < 0.02, rng.integers(5000, 7800, 1500), rng.integers(30, 200, 1500))]
+    elif shape == 'one-beyond-a-tile': lens = [int(x) for x in rng.integers(50, 150, 400)] + [30_000] + [int(x) for x in rng.integers(50, 150, 100)]
+    else: lens = [int(x) for x in rng.integers(4000, 7900, 120)]
+    recs = []
+    for i, L in enumerate(lens):
+        recs.append(b'@r:%d:%d\n' % (i % 5, i) + bytes(rng.choice(np.frombuffer(b'ACGT', np.uint8), L)) + b'\n+\n' + bytes(rng.integers(40, 75, L).astype(np.uint8)) + b'\n')
+    fq = b''.join(recs)
+    for flags in ([], ['--sort', 'DNA', '--raw', 'QUAL']):
+        ocfg, omembers, _ = O.encode(fq, **_oracle_flags(flags))
+        cfg, members, names, path = _run_encode(ctx, tmp_path, fq, flags)
+        assert set(members) == set(omembers)
+        for k in omembers: assert members[k] == omembers[k], (k, flags)
+        text = _run_decode(ctx, path)
+        assert text.decode('latin-1') == O.decode(ocfg, omembers)
+        if not flags: assert text == fq
+
+
 def test_cli_speculative_pack(ctx, tmp_path):
     """The encoder packs speculatively with decisions guessed from the head of the file itself, in the kernel that also counts the
     statistics (uq_pack_stats: two reads of the stream); a wrong guess falls back to the separate pack; --multi-pass never
