@@ -236,6 +236,9 @@ def _fuzz_case(rng):
     quals = [bytes(range(33, 74)), b'#-<F', bytes(range(64, 105)), b'!I', bytes(range(35, 127, 3)), b'5'][int(rng.integers(0, 6))]
     fixed = rng.random() < 0.4
     lo = int(rng.integers(1, 40)); hi = lo if fixed else lo + int(rng.integers(1, 120 if scale == 1 else 460))
+    if os.environ.get('UQ_FUZZ_LONG'):                          # few reads, up to 9 kbp: tiles packed piece by piece, reads beyond a tile (the exact kernels)
+        n = int(rng.integers(1, 60))
+        lo = int(rng.integers(1, 3000)); hi = lo if fixed else lo + int(rng.integers(1, 6000))
     n_single_quality = rng.random() < 0.5            # N always with one quality (the N-trick applies)
     fam = int(rng.integers(0, 8))                    # 0-5: separators the reference copes with; 6, 7: families it tends to refuse
     s1, s2 = b':_#;='[int(rng.integers(0, 5))], b':_#;='[int(rng.integers(0, 5))]
