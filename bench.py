@@ -201,9 +201,9 @@ def main():
                     guess, rpb = g
                     cap_reads = int(fastq_bytes * rpb * 1.02) + 1024
                     guess.avg_record_bytes = int(1.0 / rpb)                     # tile sizing hint: the head's own records
-                    # the record index (8 B a line) is only expanded when a kernel of the step needs it: the pack kernel with the QNAME
-                    # phase and the QNAME sample walk the census's newline lists themselves (csrc/lines.h)
-                    ls_cap = ls_async = None if qname_in_step else ops.index_lines_async(ctx, d_buf, 4 * cap_reads)
+                    # no record index (8 B a line) is expanded: the pack kernel and the QNAME sample walk the census's newline lists
+                    # themselves (csrc/lines.h); a fallback that needs the index expands it then (index() below)
+                    ls_cap = ls_async = None
                     if qname_in_step:
                         # the QNAME passes ride in the pack kernel: layout guessed on the device from a sample of the reads (queued here,
                         # behind the index), verified on every read while the fields are parsed; distinct counts queued behind it

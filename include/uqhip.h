@@ -359,7 +359,7 @@ typedef struct uq_qname_fused {
     uint64_t counts[UQ_QF_MAXC][UQ_QF_MAXT];
 } uq_qname_fused;
 int uq_qname_guess(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_start, uint64_t nreads, uq_qname_fused* d_q);
-/* The two queued forms below accept d_line_start == NULL: no record index is expanded at all (uq_index_lines_async is left out of the
+/* The two queued forms below -- and uq_pack_stats_async -- accept d_line_start == NULL: no record index is expanded at all (uq_index_lines_async is left out of the
  * step: 8 B per line written and read again).  The line starts then come from the newline lists the census queued in front left in the
  * context (uq_count_lines_end_async for the same d_buf): the pack kernel finds each tile's place in them through one record per tile
  * (a binary search over the per-tile counts, done by a small kernel in front), the QNAME sample is stratified by position in the stream

@@ -544,6 +544,14 @@ def test_queued_census_index_pack_equals_the_plain_calls(ctx, length, kw):
     assert qa.ok and qb.ok and qa.flags == 0 and qb.flags == 0 and qa.nsep == qb.nsep and qa.nreads == qb.nreads == n
     assert bytes(qa.seps) == bytes(qb.seps) and (qa.plen, qa.slen) == (qb.plen, qb.slen)
     for c in range(qa.nsep + 1): assert t.equal(fa.column(c, n), fb.column(c, n))
+    # ... and the form without the QNAME phase
+    cen = ops.ChunkedCensus(ctx, d_buf); cen.chunk(0, d_buf.numel()); cen.end_async()
+    got = ops.pack_stats_async(ctx, d_buf, None, n + 1000, guess)
+    assert got is not None
+    hs = ops.stats_fetch(ctx, got[3])
+    assert cen.wait() == (nl, True)
+    assert t.equal(got[0][:n * guess.dna_bytes_per_row], ref[0]) and t.equal(got[1][:n * guess.quality_bytes_per_row], ref[1])
+    assert not hs.incomplete and np.array_equal(hs.counts, hs_ref.counts)
     with pytest.raises(Exception):                               # the plain form has no census to fall back on
         ops.pack_stats(ctx, d_buf, None, 0, n, guess)
     # tables / index too small for the file: flagged, nothing written beyond them
@@ -668,11 +676,16 @@ def test_pack_from_the_census_lists_fuzz(ctx, seed):
     ops.qname_fused_finish(ctx, fa); qa = ops.qname_fused_fetch(ctx, fa)
     ha, hb = ops.stats_fetch(ctx, ref[3]), ops.stats_fetch(ctx, got[3])
     assert ha.incomplete == hb.incomplete
+    cen = ops.ChunkedCensus(ctx, d_buf); cen.chunk(0, d_buf.numel()); cen.end_async()         # ... and the form without the QNAME phase
+    plain = ops.pack_stats_async(ctx, d_buf, None, n + 3, guess)
+    hp = ops.stats_fetch(ctx, plain[3])
+    assert cen.wait() == (nl, True) and hp.incomplete == ha.incomplete
     if not ha.incomplete:
         assert t.equal(got[0][:n * guess.dna_bytes_per_row], ref[0]) and t.equal(got[1][:n * guess.quality_bytes_per_row], ref[1])
+        assert t.equal(plain[0][:n * guess.dna_bytes_per_row], ref[0]) and t.equal(plain[1][:n * guess.quality_bytes_per_row], ref[1])
         assert np.array_equal(ha.counts, hb.counts) and (ha.len_min, ha.len_max, ha.max_record_bytes) == (hb.len_min, hb.len_max, hb.max_record_bytes)
         st = oracle_c.stats(text, oracle_c.index_lines(text), 0, n)
-        assert np.array_equal(hb.counts, st['counts'])
+        assert np.array_equal(hb.counts, st['counts']) and np.array_equal(hp.counts, st['counts'])
     if qa.ok and qb.ok and qa.flags == 0 and qb.flags == 0:
         assert (qa.plen, qa.slen, qa.nsep, qa.nreads, bytes(qa.seps)) == (qb.plen, qb.slen, qb.nsep, qb.nreads, bytes(qb.seps))
         for c in range(qa.nsep + 1): assert t.equal(fa.column(c, n), fb.column(c, n))

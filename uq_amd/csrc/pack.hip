@@ -239,7 +239,7 @@ constexpr int PKS_COPIES = 4;
 constexpr uint32_t pks_bins(int bd) { return bd == 3 ? 512u : 256u; }     // bin = base code << 6 | quality code (3-bit bases: nine bits)
 constexpr uint32_t pks_words(int bd) { return pks_bins(bd) * PKS_COPIES + 128; }
 
-// The queued QNAME forms take their line starts from the census's lists instead of an expanded index (lines.h): a record per pack tile (TileRec): the start of
+// The queued forms take their line starts from the census's lists instead of an expanded index (lines.h): a record per pack tile (TileRec): the start of
 // the tile's first record (entry `ntiles`: the end of the last record), where the newline in front of it sits (census tile,
 // slot) and how many newlines that tile and its two successors hold -- left by tile_origin_kernel, one binary search per pack tile.  With
 // them a lane finds its list entry by arithmetic: ONE load per line start, nothing that waits for another load inside the prefetch (a walk
@@ -345,8 +345,8 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && (NTRICK || QN)) ? 4 : 5) void
         }
     }
     uint64_t nl_total = 4 * (first + n);              // (list form: closes the last census tile's list)
-    constexpr bool lists = STATS && QN && LISTS;      // (instances of the QNAME forms only: the others have no registers to spare, and a run-time choice
-                                                      // between `ls` and `trec` turns the tile bounds' scalar loads into vector loads that wait for the tile's stores)
+    constexpr bool lists = STATS && LISTS;            // (instances of their own: a run-time choice between `ls` and `trec` turns the tile bounds' scalar loads into vector
+                                                      // loads that wait for the tile's stores -- and spills the kernels built for five workgroups per CU)
     if (d_async) {                                    // the queued form (uq_pack_stats_async): the census in front left the line count on the device;
         nl_total = d_async[0];
         const uint64_t have = d_async[0] / 4;         // `n` is what the tables hold
@@ -713,6 +713,7 @@ PackKernel pick_stats_kernel_q(int bq, bool ntrick) {
 }
 PackKernel pick_stats_kernel(int bd, int bq, bool ntrick, bool qn, bool lists) {
     if (qn && lists) return bd == 3 ? pick_stats_kernel_q<3, true, true>(bq, ntrick) : pick_stats_kernel_q<2, true, true>(bq, ntrick);
+    if (lists) return bd == 3 ? pick_stats_kernel_q<3, false, true>(bq, ntrick) : pick_stats_kernel_q<2, false, true>(bq, ntrick);
     if (bd == 3) return qn ? pick_stats_kernel_q<3, true>(bq, ntrick) : pick_stats_kernel_q<3, false>(bq, ntrick);
     return qn ? pick_stats_kernel_q<2, true>(bq, ntrick) : pick_stats_kernel_q<2, false>(bq, ntrick);
 }
@@ -742,9 +743,9 @@ static int pack_impl(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_s
                      uq_stats* d_stats, int* h_fused, const unsigned long long* d_async = nullptr, uq_qname_fused* d_q = nullptr,
                      uint32_t* d_vals = nullptr, uint64_t vals_pitch = 0) {
     // d_line_start == nullptr (queued forms only): the line starts come from the lists of the census queued in front (lines.h)
-    const bool use_lists = d_line_start == nullptr && d_async != nullptr && d_stats != nullptr && d_q != nullptr;
+    const bool use_lists = d_line_start == nullptr && d_async != nullptr && d_stats != nullptr;
     UQ_REQUIRE(ctx && d_buf && (d_line_start || use_lists) && hp && d_dna && d_qual && d_bad, "uq_pack: null argument");
-    UQ_REQUIRE(!use_lists || (ctx->async_buf == d_buf && ctx->async_nbytes > 0), "uq_pack_stats_qname_async: no line index given and no census of this buffer queued in front");
+    UQ_REQUIRE(!use_lists || (ctx->async_buf == d_buf && ctx->async_nbytes > 0), "uq_pack_stats_async: no line index given and no census of this buffer queued in front");
     if (h_fused) *h_fused = 0;
     UQ_REQUIRE(hp->bits_per_base >= 1 && hp->bits_per_base <= 8 && hp->bits_per_quality >= 1 && hp->bits_per_quality <= 8,
                "uq_pack: bits per symbol must be 1..8");

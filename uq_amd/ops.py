@@ -191,7 +191,7 @@ def pack_stats(ctx, buf, line_start, first_read, nreads, guess, fq=None):
 def pack_stats_async(ctx, buf, line_start, capacity_reads, guess, st=None, fq=None):
     """pack_stats of every read of `buf` behind ChunkedCensus.end_async() + index_lines_async: tables of capacity_reads rows (the
     caller narrows them once wait() has told it the count; `st`: a stats_new() made earlier, so that its initialisation is not queued
-    between the index and the pack kernel).  With `fq`, line_start may be None: no index is expanded, the kernel takes the line starts
+    between the index and the pack kernel).  line_start may be None: no index is expanded, the kernel takes the line starts
     from the census's newline lists (include/uqhip.h).  Returns (dna, qual, bad, d_stats) or None (no fused kernel)."""
     t = ctx.torch
     dna = t.empty(capacity_reads * guess.dna_bytes_per_row, dtype=t.uint8, device=ctx.device)
