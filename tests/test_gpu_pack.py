@@ -554,6 +554,14 @@ def test_queued_census_index_pack_equals_the_plain_calls(ctx, length, kw):
     assert not hs.incomplete and np.array_equal(hs.counts, hs_ref.counts)
     with pytest.raises(Exception):                               # the plain form has no census to fall back on
         ops.pack_stats(ctx, d_buf, None, 0, n, guess)
+    # a census of ANOTHER buffer in between overwrites the lists: the index-free forms refuse instead of walking them
+    cen = ops.ChunkedCensus(ctx, d_buf); cen.chunk(0, d_buf.numel()); cen.end_async()
+    assert cen.wait() == (nl, True)
+    cen = ops.ChunkedCensus(ctx, d_buf); cen.chunk(0, d_buf.numel()); cen.end_async()
+    other_buf = ops.synth_fastq(ctx, synth.Spec(77, 60), 0, 500)
+    assert ops.count_lines(ctx, other_buf) == 2000
+    with pytest.raises(Exception):
+        ops.pack_stats_async(ctx, d_buf, None, n + 1000, guess)
     # tables / index too small for the file: flagged, nothing written beyond them
     cen = ops.ChunkedCensus(ctx, d_buf); cen.chunk(0, d_buf.numel()); cen.end_async()
     cap = n // 2

@@ -183,6 +183,7 @@ int run_count(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint64_t* nblo
     const uint64_t nvec = (nbytes + mis + 15) / 16;
     const uint64_t nb = (nvec * 16 + IDX_TILE - 1) / IDX_TILE;
     UQ_REQUIRE(nb <= 0x7fffffffu, "uq_count_lines: buffer too large for one launch");
+    ctx->async_buf = nullptr;                              // the lists of a queued census (if any) are about to be overwritten: its index-free consumers must refuse
     UQ_TRY(census_buffers(ctx, nb));
     if (list_form) {
         uint32_t* d_over = (uint32_t*)(ctx->idx_bitmap + nb * IDX_TILE_VECS);          // the 16 spare bytes behind the slots
@@ -231,6 +232,7 @@ static int finish_count(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint
 extern "C" int uq_count_lines_begin(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes) {
     UQ_REQUIRE(ctx && (d_buf || nbytes == 0), "uq_count_lines_begin: null argument");
     ctx->idx_buf = nullptr;
+    ctx->async_buf = nullptr;
     if (nbytes == 0) return 0;
     const uint32_t mis = (uint32_t)((uintptr_t)d_buf & 15);
     const uint64_t nb = (((nbytes + mis + 15) / 16) * 16 + IDX_TILE - 1) / IDX_TILE;
