@@ -117,7 +117,7 @@ def run_reference(argv, workdir, stable=False):
     return p.returncode, p.stdout
 
 
-def make_case(name, fastq_bytes, flags, stable=False, decode=True, outdir=HERE):
+def make_case(name, fastq_bytes, flags, stable=False, decode=True, outdir=HERE, refuses=False):
     work = tempfile.mkdtemp(prefix='uq_golden_')
     try:
         inp = os.path.join(work, 'in.fastq')
@@ -125,12 +125,25 @@ def make_case(name, fastq_bytes, flags, stable=False, decode=True, outdir=HERE):
         tmpd = os.path.join(work, 'tmp'); os.mkdir(tmpd)
         out = os.path.join(work, 'out.uQ')
         rc, log = run_reference(['-i', inp, '-o', out, '--temp', tmpd] + flags, work, stable)
-        if rc != 0 or not os.path.isfile(out):
+        refused = rc != 0 or not os.path.isfile(out)
+        if refused and not refuses:
             raise RuntimeError('reference failed for %s:\n%s' % (name, log[-3000:]))
+        if refuses and not refused:
+            raise RuntimeError('the reference was expected to refuse %s and wrote a file' % name)
         meta = {'name': name, 'flags': flags, 'stable_patch': stable,
                 'input_sha256': hashlib.sha256(fastq_bytes).hexdigest(),
                 'reference_sha256': hashlib.sha256(open(REFERENCE, 'rb').read()).hexdigest(),
                 'generator': 'tests/golden/make_golden.py'}
+        if refused:
+            # the fixture IS the refusal: what the reference printed last before it gave up (its exit message, or the
+            # exception that ended it), no .uQ
+            says = [l for l in log.strip().splitlines() if l.strip()][-1]
+            meta['reference_refuses'] = True
+            meta['reference_says'] = says.strip()[:200]
+            with open(os.path.join(outdir, name + '.fastq'), 'wb') as f: f.write(fastq_bytes)
+            with open(os.path.join(outdir, name + '.json'), 'w') as f: json.dump(meta, f, indent=1, sort_keys=True)
+            print('wrote', name, 'REFUSED:', meta['reference_says'])
+            return
         if decode:
             # the reference's own decoder on the file the reference wrote: its stdout is kept as <name>.refdecode.fastq
             # (data: the decoder's output) so that lines 2 and 4 of every record pin our decoder to it
@@ -174,10 +187,24 @@ def describe_decode(rc, got, fastq_bytes, flags):
     return d
 
 
+def rename(fastq_bytes, name_of):
+    """The same reads under other names: line 1 of read i becomes name_of(i) (bytes, with its '@')."""
+    lines = fastq_bytes.split(b'\n')
+    for i in range(0, len(lines) - 1, 4):
+        lines[i] = name_of(i // 4)
+    return b'\n'.join(lines)
+
+
+def case_refuses(name):
+    """Cases named *_refused are inputs the reference gives up on (exit message or exception): the fixture is the refusal."""
+    return name.endswith('_refused')
+
+
 def cases():
     sys.path.insert(0, REPO)
     from uq_amd import synth
     S = 20261003
+    RAW = ['--raw', 'DNA', 'QUAL', 'QNAME']
     # 1. config 1 of BASELINE.json: 10k x 100bp, raw, no sort, pattern 0.1 0.1
     yield 'cfg1_10k_100bp', synth.fastq(S + 1, 10000, 100), ['--sort', 'None', '--raw', 'DNA', 'QUAL', 'QNAME', '--pattern', '0.1', '0.1'], False
     # 2. fixed length, N gets a NEW quality code (its one quality is shared) -- Q9 corner, 41+1 quals
@@ -208,6 +235,69 @@ def cases():
     yield 'sort_qname_keyed', dup, ['--sort', 'QNAME', '--pattern', '2.1', '3.2'], False
     yield 'sort_dna_raw_all', dup, ['--sort', 'DNA', '--raw', 'DNA', 'QUAL', 'QNAME'], False
 
+    # ---- round 4: other QNAME grammars (uq.py:394-444, 555-678, 717-736).  Everything above shares ONE grammar
+    # (@SIM001:42:FCX01:a:b:x:y -- ':' separators, four integer columns of one or two bytes).
+    # 12. Illumina 1.8 names with the comment: a space among the separators, two `mapping` columns (filter flag, barcode)
+    BC = [b'ATCACG', b'CGATGT', b'TTAGGC', b'TGACCA']
+    illumina = lambda i: b'@M01234:17:000000000-A1B2C:1:%d:%d:%d %d:%s:0:%s' % (
+        1101 + 1000 * (i % 2) + i % 19, 1000 + (i * 7919) % 28000, 1000 + (i * 104729) % 28000, 1 + i % 2, b'Y' if i % 10 == 3 else b'N', BC[(i // 3) % 4])
+    ill = rename(synth.fastq(S + 20, 500, 36), illumina)
+    yield 'qn_illumina_comment', ill, RAW, False
+    #     ... and the same names as the sorted-on, keyed table: mapping codes and integers stacked into one table (uq.py:808-851)
+    yield 'qn_illumina_sort_qname_keyed_stable', ill, ['--sort', 'QNAME', '--pattern', '1.1', '2.2'], True
+    # 13. suffixes: '/1' behind a barcode; a constant ' length=30' whose characters (space, '=') must leave the separator set (uq.py:428-431)
+    yield 'qn_suffix_mate', rename(synth.fastq(S + 21, 400, 30), lambda i: b'@ERR0042_%d_%d#ACGT/1' % (i + 1, (5 * i + 3) % 977)), RAW, False
+    yield 'qn_suffix_length', rename(synth.fastq(S + 21, 400, 30), lambda i: b'@SRR001666:%d:%d length=30' % (i + 1, (5 * i + 3) % 977)), RAW, False
+    # 14. four different separators in one name ('-', '=', ';' after a prefix that ends in '_'), a mapping of strings between integers,
+    #     an integer column that needs an offset
+    yield 'qn_seps_mixed', rename(synth.fastq(S + 22, 300, 25), lambda i: b'@run7_%d-%d=%s;%d' % (
+        i % 50, 100000 + 37 * i, [b'fwd', b'rev', b'unk'][i % 3], i % 2)), RAW, False
+    # 15. a separator that is also a minus sign: its count is not constant, the fields around it merge into a column of strings -> the reference exits
+    yield 'qn_strings_refused', rename(synth.fastq(S + 22, 300, 25), lambda i: b'@run7_%d-%d_%s' % (
+        i % 50 - 25, 100000 + 37 * i, [b'fwd', b'rev'][i % 2])), RAW, False
+    # 16. Q14 (the family the CLI fuzz found, fd9f468): a separator candidate that is line 1's last character before the suffix sits in the
+    #     separator set but not in the order; what happens depends on the LAST read alone
+    q14 = synth.fastq(S + 23, 41, 20)
+    yield 'qn_q14_two_refused', rename(synth.fastq(S + 23, 2, 20), lambda i: [b'@q_0=1', b'@q_1=4'][i]), RAW, False
+    yield 'qn_q14_three', rename(synth.fastq(S + 23, 3, 20), lambda i: [b'@q_0=1', b'@q_1=4', b'@q_2=1'][i]), RAW, False
+    yield 'qn_q14_many', rename(q14, lambda i: (b'@q_%d=1' % (i % 7)) if i < 40 else b'@q_1=4'), RAW, False
+    # 17. Q13: no constant-count separator at all / only line 1's last character -> re.error inside order_seps (uq.py:433-438)
+    yield 'qn_no_separator_refused', rename(synth.fastq(S + 23, 5, 20), lambda i: b'@r%d' % (i + 1)), RAW, False
+    yield 'qn_q14_const_refused', rename(synth.fastq(S + 23, 30, 20), lambda i: b'@r:7:%d:7' % i), RAW, False
+    # 18. Q15: '.' goes into the regexes unescaped
+    yield 'qn_dot_separator_refused', rename(synth.fastq(S + 23, 5, 20), lambda i: b'@a.%d.%s' % (i + 1, b'xyzuv'[i:i + 1])), RAW, False
+    # 19. column widths and offsets (uq.py:641-670): negative values (offset), a uint32 and a uint64 range, a small range far from zero (offset),
+    #     four wide-spread numbers that stay a mapping of strings; and the same columns as the sorted-on raw table (one common dtype, uq.py:812-816)
+    wide = rename(synth.fastq(S + 24, 600, 24), lambda i: b'@s:%d:%d:%d:%d:%d' % (
+        i % 50 - 25, 100000 + 37000 * i, 5000000000 * (i % 300) + 7 * i, 1000 + i % 90, [5, 70000, 12345678, 31][i % 4]))
+    yield 'qn_u4_u8_negative', wide, RAW, False
+    yield 'qn_u4_u8_sort_qname_raw_stable', wide, ['--sort', 'QNAME', '--raw', 'QNAME', '--pattern', '0.1', '3.2'], True
+    # 20. the checkpoints of uq.py:586-602 at 22 000 reads: column 1 is a mapping at read 10 000 (900 values) and integers at 20 000;
+    #     column 2 integers at once; column 3 two strings; column 4 three far-apart numbers until read 21 000, then one per read -- still a
+    #     mapping at the last check (1 002 values <= 2 199), stored as uint16 codes of strings
+    def demote(i):
+        a = i % 900 if i < 10000 else i
+        d = [12, 999999, 70000][i % 3] if i < 21000 else i
+        return b'@d:%d:%d:%s:%d' % (a, 3 * i, [b'L', b'R'][i % 2], d)
+    yield 'qn_demote_20000', rename(synth.fastq(S + 25, 22000, 12), demote), RAW, False
+    #     a column that became integers at read 10 000 meets a non-number at read 15 000 -> strings -> the reference exits
+    yield 'qn_demoted_then_string_refused', rename(synth.fastq(S + 25, 15200, 10),
+                                                   lambda i: b'@d:%d:%s' % (i % 5, (b'%d' % i) if i != 15000 else b'x15000')), RAW, False
+
+    # ---- round 4: sort x geometry (uq.py:765-851).  Every sorted fixture above is fixed-length 40 bp with the default tricks.
+    # 21. variable lengths (sentinel rows) + --sort DNA keyed; + --sort QUAL raw
+    var = synth.fastq(S + 26, 700, (31, 58), n_rate=2, skip_len_mod4=True, dup='both', dup_templates=30)
+    yield 'var_sort_dna_keyed_stable', var, ['--sort', 'DNA', '--pattern', '2.2', '1.1'], True
+    yield 'var_sort_dna_keyed', var, ['--sort', 'DNA', '--pattern', '2.2', '1.1'], False
+    yield 'var_sort_qual_raw_stable', var, ['--sort', 'QUAL', '--raw', 'DNA', 'QUAL', 'QNAME', '--pattern', '3.2', '1.1'], True
+    # 22. --pad (4-bit DNA, 8-bit QUAL) + --sort QUAL, QUAL raw and DNA / QNAME keyed
+    yield 'pad_sort_qual_stable', synth.fastq(S + 27, 500, 33, n_rate=2, dup='qual', dup_templates=20), \
+        ['--notricks', '--pad', '--sort', 'QUAL', '--raw', 'QUAL', '--pattern', '0.2', '3.1'], True
+    # 23. --notricks (3-bit ACGNT) keyed, unsorted and sorted, two non-trivial patterns each
+    nt = synth.fastq(S + 28, 500, 45, n_rate=3, dup='dna', dup_templates=25)
+    yield 'notricks_keyed', nt, ['--notricks', '--sort', 'None', '--pattern', '1.1', '2.2'], False
+    yield 'notricks_sort_dna_keyed_stable', nt, ['--notricks', '--sort', 'DNA', '--pattern', '3.2', '2.1'], True
+
 
 if __name__ == '__main__':
     only = set(a for a in sys.argv[1:] if not a.startswith('--'))
@@ -216,4 +306,4 @@ if __name__ == '__main__':
         if a.startswith('--outdir='): outdir = a.split('=', 1)[1]
     for name, fq, flags, stable in cases():
         if only and name not in only: continue
-        make_case(name, fq, flags, stable, outdir=outdir)
+        make_case(name, fq, flags, stable, outdir=outdir, refuses=case_refuses(name))

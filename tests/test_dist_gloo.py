@@ -232,6 +232,10 @@ def _qname_cases():
         names.append(b'@q:%d:%d:%s/%d' % ((i % 1001) * 3, b * 1000, [b'x', b'yy', b'zzz'][i % 3], 1 + i % 2))
     cases['checkpoints'] = b''.join(n + b'\nACGT\n+\nIIII\n' for n in names)
     cases['strings'] = b''.join(b'@q:%d:%s\nA\n+\nI\n' % (i % 7, b'abc' if i == 11000 else b'%d' % i) for i in range(12000))   # refused
+    # heavy ties: a string value that is heavier than a rank's share is dealt over several ranks by the global sort; the
+    # distinct counts must count it once (a filter flag N / Y at 90 %, and a constant string in mid-name)
+    cases['heavy_flag'] = b''.join(b'@q:%d:%s:%d\nA\n+\nI\n' % (i % 40, b'Y' if i % 10 == 3 else b'N', i % 9) for i in range(3000))
+    cases['heavy_const'] = b''.join(b'@q:%d:%s:lane:%s\nA\n+\nI\n' % (i, [b'a', b'b', b'c'][(i * i) % 3], b'x' if i < 2990 else b'w') for i in range(3000))
     cases['nosep'] = b''.join(b'@r%d\nA\n+\nI\n' % (i % 10) for i in range(50))                                               # refused (Q13)
     return cases
 
@@ -262,7 +266,7 @@ def _qname_job(rank, world):
     return out
 
 
-@pytest.mark.parametrize('world', [2, 3])
+@pytest.mark.parametrize('world', [2, 3, 4])
 def test_sharded_qname_passes_match_oracle(world):
     """The device QNAME path over shards (MIN/MAX/SUM of its reductions + a distributed sort of the field keys for
     the distinct counts) reaches the single-process oracle's answer -- or its refusal -- on every rank."""

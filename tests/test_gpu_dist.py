@@ -83,6 +83,18 @@ def test_sharded_encode_with_a_heavy_tie_group(tmp_path, world, flags):
     _check(tmp_path, world, flags, fq=b''.join(out))
 
 
+@pytest.mark.parametrize('world', [3, 4])
+def test_sharded_encode_with_heavy_qname_strings(tmp_path, world):
+    """a QNAME string field heavier than a rank's share (a filter flag that is 'N' for 90 % of the reads, a constant word in
+    mid-name) is dealt over several ranks by the sort of the field keys; the distinct counts and the sorted map must count it once."""
+    from test_gpu_e2e import _records
+    base = _records(synth.fastq(20261003 + 48, 3000, 30, n_rate=1))
+    name = lambda i: b'@q:%d:%s:lane:%s:%d' % (i % 40, b'Y' if i % 10 == 3 else b'N', b'x' if i < 2990 else b'w', i % 9)
+    fq = b''.join(name(i) + b'\n' + b'\n'.join(r.split(b'\n')[1:]) + b'\n' for i, r in enumerate(base))
+    _check(tmp_path, world, ['--raw', 'DNA', 'QUAL', 'QNAME'], fq=fq)
+    _check(tmp_path, world, ['--sort', 'QNAME'], fq=fq)
+
+
 def test_sharded_encode_with_idle_ranks(tmp_path):
     """Two reads over three ranks: a rank without reads still takes part in every exchange."""
     fq = b'@a:1:7\nACGTN\n+\nIHIH#\n@a:2:9\nACGTA\n+\nHIHII\n'

@@ -13,6 +13,8 @@ import uq_oracle as O
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 GOLDEN = sorted(os.path.basename(f)[:-5] for f in glob.glob(os.path.join(GOLD, '*.json')))
+REFUSED = [n for n in GOLDEN if n.endswith('_refused')]        # inputs the reference itself gives up on: the fixture is the refusal
+WRITTEN = [n for n in GOLDEN if n not in REFUSED]
 
 
 def flags_to_kwargs(flags):
@@ -30,13 +32,40 @@ def flags_to_kwargs(flags):
 
 
 def test_golden_set_is_complete():
-    assert len(GOLDEN) >= 16
+    assert len(WRITTEN) >= 32 and len(REFUSED) >= 6
     for name in GOLDEN:
-        for ext in ('.fastq', '.uQ', '.json'):
+        for ext in ('.fastq', '.json') + (() if name in REFUSED else ('.uQ',)):
             assert os.path.exists(os.path.join(GOLD, name + ext))
+    for name in REFUSED:
+        meta = json.load(open(os.path.join(GOLD, name + '.json')))
+        assert meta['reference_refuses'] and meta['reference_says'] and not os.path.exists(os.path.join(GOLD, name + '.uQ'))
 
 
-@pytest.mark.parametrize('name', GOLDEN)
+def test_golden_set_covers_more_than_one_qname_grammar():
+    """the fixtures of rounds 1-3 all shared ':' separators and four small integer columns.  The set must hold mapping
+    columns, a suffix, other separators (a space among them), uint32 / uint64 columns, offsets, and more than one column count."""
+    seps, fmts, dtypes, suffixes, offsets, ncols = set(), set(), set(), set(), set(), set()
+    for name in WRITTEN:
+        cfg, _ = O.read_tar(os.path.join(GOLD, name + '.uQ'))
+        seps |= set(cfg['QNAME_separators']); suffixes.add(cfg['QNAME_suffix']); ncols.add(len(cfg['QNAME_columns']))
+        for c in cfg['QNAME_columns']:
+            fmts.add(c['format']); dtypes.add(c['dtype']); offsets.add(c.get('offset'))
+    assert seps >= set(': _-=;') and fmts == {'integers', 'mapping'} and dtypes >= {'uint8', 'uint16', 'uint32', 'uint64'}
+    assert len(suffixes) >= 3 and {True, False} <= offsets and len(ncols) >= 4
+
+
+@pytest.mark.parametrize('name', REFUSED)
+def test_oracle_refuses_what_the_reference_refuses(name):
+    meta = json.load(open(os.path.join(GOLD, name + '.json')))
+    fq = open(os.path.join(GOLD, name + '.fastq'), 'rb').read()
+    with pytest.raises(O.UqError) as e:
+        O.encode(fq, **flags_to_kwargs(meta['flags']))
+    # where the reference says why in its own words, the restatement says the same
+    if not meta['reference_says'].startswith('re.error'):
+        assert meta['reference_says'][:40] in str(e.value) or str(e.value)[:40] in meta['reference_says'] or 'Sorry' in str(e.value)
+
+
+@pytest.mark.parametrize('name', WRITTEN)
 def test_oracle_matches_reference_members(name):
     meta = json.load(open(os.path.join(GOLD, name + '.json')))
     fq = open(os.path.join(GOLD, name + '.fastq'), 'rb').read()
@@ -93,7 +122,7 @@ def test_tie_rule_is_not_vacuous():
     """The unpatched sorted fixtures do contain tie groups, and for at least one of them the reference's unstable order
     differs from file order -- so the multiset rule is exercised, not just satisfied by identical bytes."""
     seen_groups = seen_moved = 0
-    for name in GOLDEN:
+    for name in WRITTEN:
         meta = json.load(open(os.path.join(GOLD, name + '.json')))
         if meta['stable_patch'] or '--sort' not in meta['flags'] or meta['flags'][meta['flags'].index('--sort') + 1] == 'None': continue
         fq = open(os.path.join(GOLD, name + '.fastq'), 'rb').read()
@@ -104,7 +133,7 @@ def test_tie_rule_is_not_vacuous():
     assert seen_groups > 20 and seen_moved > 0, (seen_groups, seen_moved)
 
 
-@pytest.mark.parametrize('name', GOLDEN)
+@pytest.mark.parametrize('name', WRITTEN)
 def test_reference_decoder_output_pins_seq_and_qual(name):
     """What the reference's OWN decoder printed for the file the reference wrote (<name>.refdecode.fastq): lines 2 and 4 of
     every record equal the oracle decoder's, position by position.  Line 1 is excluded where the json says why (Q6: the
@@ -135,9 +164,12 @@ def test_fixtures_regenerate_from_the_reference(tmp_path):
     names = []
     for name, fq, flags, stable in mg.cases():
         if name == 'cfg1_10k_100bp' and os.environ.get('UQ_SKIP_SLOW_GOLDEN'): continue
-        mg.make_case(name, fq, flags, stable, outdir=str(tmp_path))
+        mg.make_case(name, fq, flags, stable, outdir=str(tmp_path), refuses=mg.case_refuses(name))
         names.append(name)
         assert open(os.path.join(GOLD, name + '.fastq'), 'rb').read() == fq, name
+        if mg.case_refuses(name):
+            assert json.load(open(os.path.join(GOLD, name + '.json'))) == json.load(open(str(tmp_path / (name + '.json')))), name
+            continue
         cfg_a, mem_a = O.read_tar(os.path.join(GOLD, name + '.uQ'))
         cfg_b, mem_b = O.read_tar(str(tmp_path / (name + '.uQ')))
         assert set(mem_a) == set(mem_b), name
@@ -156,7 +188,7 @@ def test_fixtures_regenerate_from_the_reference(tmp_path):
     assert sorted(names) == GOLDEN or os.environ.get('UQ_SKIP_SLOW_GOLDEN')
 
 
-@pytest.mark.parametrize('name', [n for n in GOLDEN if n != 'fixed_n_newcode'])
+@pytest.mark.parametrize('name', [n for n in WRITTEN if n != 'fixed_n_newcode'])
 def test_oracle_decode_roundtrip(name):
     fq = open(os.path.join(GOLD, name + '.fastq'), 'rb').read()
     ref_cfg, ref_members = O.read_tar(os.path.join(GOLD, name + '.uQ'))

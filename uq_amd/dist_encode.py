@@ -10,10 +10,12 @@ The result is byte-for-byte the file the single-GPU CLI writes (members and conf
   pass 1    local `uq_stats`, all-reduced (one collective) -> identical decisions everywhere
   QNAME     the device QNAME passes over shards (uq_amd.qname_device with a `Shard`)
   pass 3    local pack
-  tables    `--sort`: sample sort over the ranks (dist.global_sort_rows: all-to-all(v) of rows by key range, equal
-            rows never straddle ranks); the other tables follow with dist.dist_gather_rows; unique + key:
-            head flags of the sorted shard, exclusive offset of the group counts, keys returned to file order
-            with dist.dist_scatter_rows
+  tables    `--sort`: sample sort over the ranks (dist.global_sort_rows: all-to-all(v) of rows by key range; equal
+            rows share a rank unless their value is heavier than a rank's share -- then it is dealt over several
+            ranks by file position and every consumer that counts groups stitches them at the rank boundaries:
+            `_unique` here, `qname_device._distinct_counts`); the other tables follow with dist.dist_gather_rows;
+            unique + key: head flags of the sorted shard, exclusive offset of the group counts, keys returned to
+            file order with dist.dist_scatter_rows
   write     every member's global size is known after an all-gather of the shard sizes; ranks `pwrite` their
             pieces into place (pinned staging), rank 0 writes the tar / .npy headers and config.json
 
@@ -182,7 +184,7 @@ class ShardedSession(Session):
 
     # ------------------------------------------------------------------ table builds over shards
     def _sorted(self, t, n, cols):
-        gs = uqdist.global_sort_rows(self.be, t, n, cols, self.read_offset, self.group)
+        gs = uqdist.global_sort_rows(self.be, t, n, cols, self.read_offset, self.group, total_rows=self.total_reads)
         return gs, {'gidx': gs['gidx'], 'offset': gs['offset'], 'rows': gs['rows']}
 
     def _unique(self, gs, cols):

@@ -128,14 +128,28 @@ def _distinct_counts(ctx, keys, n, thresholds, shard):
         perm, key, skey, uniq, nu = ops.unique_rows(ctx, keys, n, 8)
         return ops.prefix_distinct(ctx, perm, skey, n, thresholds), nu, key, uniq
     from .dist import global_sort_rows
-    gs = global_sort_rows(shard.be, keys.view(ctx.torch.uint8), n, 8, shard.read_offset, shard.group)
+    gs = global_sort_rows(shard.be, keys.view(ctx.torch.uint8), n, 8, shard.read_offset, shard.group, total_rows=shard.total)
     m = gs['rows']
-    counts, nu, uniq = [0] * len(thresholds), 0, ctx.empty(0)
+    counts, nu, uniq, edge, first0 = [0] * len(thresholds), 0, ctx.empty(0), b'', 0
     if m:
         perm, _, skey, uniq, nu = ops.unique_rows(ctx, gs['table'], m, 8, want_key=False)
         first = ops.gather_rows(ctx, gs['gidx'].view(ctx.torch.uint8), m, 8, perm).view(ctx.torch.int64)   # file-wide read numbers
         counts = ops.prefix_distinct(ctx, first, skey, m, thresholds)
-    red = shard.reduce(counts + [nu], 'sum')       # equal keys all live on one rank: counts simply add up
+        edge = bytes(ctx.to_numpy(gs['table'][:8]).tobytes()) + bytes(ctx.to_numpy(gs['table'][(m - 1) * 8:m * 8]).tobytes())
+        first0 = int(ctx.to_numpy(gs['gidx'][:1], np.int64)[0])          # the shard's first row is the first of its group in file order (stable sort)
+    # Equal keys share a rank -- except a value heavier than a rank's share, which global_sort_rows deals over several ranks by file
+    # position.  Such a group is counted by every rank that holds a piece of it; its true first occurrence sits on the EARLIEST of them.
+    # So a rank whose first key equals the last key in front of it (first + last row of every rank, as dist_encode._unique does) drops
+    # that row from its unique slice and takes the group off nu and off every checkpoint at or after its own first occurrence of it.
+    edges = shard.gather_bytes(edge)
+    last, cont = None, 0
+    for r in range(shard.world):
+        if r == shard.rank: cont = 1 if (edges[r] and last is not None and edges[r][:8] == last) else 0
+        if edges[r]: last = edges[r][8:]
+    if cont:
+        uniq, nu = uniq[8:], nu - 1
+        counts = [c - (1 if first0 <= T else 0) for c, T in zip(counts, thresholds)]
+    red = shard.reduce(list(counts) + [nu], 'sum')
     return red[:-1], red[-1], None, shard.gather_rows(uniq)
 
 
