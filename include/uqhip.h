@@ -166,6 +166,13 @@ int uq_unpattern(uq_ctx* ctx, const uint8_t* d_payload, uint64_t rows, uint32_t 
 /* ---- a5: stable argsort of rows in memcmp order.  Replaces table.view('V<C>') +
  * numpy.argsort(axis=0) (uq.py:773-775).  d_perm[j] = index of the j-th smallest row. */
 int uq_argsort_rows(uq_ctx* ctx, const uint8_t* d_table, uint64_t rows, uint32_t cols, uint32_t* d_perm);
+/* How the row sorts of this context run their round 0 (tuning and tests; the result is the same order either way).  Tables of
+ * msd_min_rows rows and more whose heads spread take the MSD partition finished in LDS (csrc/msd.hip), the others the LSD passes
+ * (csrc/radix.hip): 0 = the built-in threshold (2^18), < 0 = never.  h_level_bits[nlevels] (1 .. 10 bits a level, at most 24 in all;
+ * nlevels = 0: chosen from the row count) = the digits of the partition's levels.
+ * uq_sort_counters: how many sorts of this context finished round 0 the one way and the other. */
+int uq_sort_config(uq_ctx* ctx, int64_t msd_min_rows, const int* h_level_bits, int nlevels);
+int uq_sort_counters(uq_ctx* ctx, uint64_t* h_msd_rounds, uint64_t* h_lsd_rounds);
 
 /* ---- multi-GPU --sort: d_pos[k] = index of the first row of the memcmp-SORTED table that is
  * >= probe row k (numpy.searchsorted(side='left') on void rows).  Splits a locally sorted shard at the

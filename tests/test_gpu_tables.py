@@ -110,9 +110,10 @@ def test_argsort_rows_stable(ctx, n, C, nd, prefix):
     assert np.array_equal(got, O.argsort_rows(T))
 
 
+@pytest.mark.parametrize('form', ['lsd', 'msd'])
 @pytest.mark.parametrize('C', [12, 38, 113])
 @pytest.mark.parametrize('shape', ['constant-lead', 'lead-the-sample-misses', 'crowded', 'crowded-behind-the-sample', 'two-values', 'sorted-input'])
-def test_argsort_round0_paths(ctx, shape, C):
+def test_argsort_round0_paths(ctx, shape, C, form):
     """The 32-bit round 0 of the row sort (tables of 65 536 rows and more, rows wider than 8 bytes) takes the number of constant leading bits and
     the crowding of the prefixes from a sample of 4096 rows and checks the former on every row: tables whose leading bits are constant, whose only
     rows with another leading bit the sample misses (the pass runs again with the true count), that crowd on few prefixes (64-bit round 0 at once),
@@ -121,6 +122,7 @@ def test_argsort_round0_paths(ctx, shape, C):
     n = 100_003
     T = rng.randint(0, 256, size=(n, C)).astype(np.uint8)
     sampled = set(int(j * (n - 1) // 4095) for j in range(4096))
+    ops.sort_config(ctx, msd_min_rows=1 if form == 'msd' else -1)      # (the MSD partition checks z the same way and hands crowded tables back)
     if shape == 'constant-lead':
         T[:, 0] = 0x00; T[:, 1] = (T[:, 1] & 0x0F) | 0x30
     elif shape == 'lead-the-sample-misses':
@@ -145,6 +147,7 @@ def test_argsort_round0_paths(ctx, shape, C):
     perm = ops.argsort_rows(ctx, _dev(ctx, T.ravel()), n, C)
     assert np.array_equal(ctx.to_numpy(perm, np.uint32).astype(np.int64), O.argsort_rows(T))
     p2, key, skey, uniq, nu = ops.unique_rows(ctx, _dev(ctx, T.ravel()), n, C)
+    ops.sort_config(ctx)
     ru, rkey = O.unique_rows(T)
     assert nu == len(ru) and np.array_equal(ctx.to_numpy(uniq).reshape(nu, C), ru) and np.array_equal(ctx.to_numpy(key, np.uint32).astype(np.int64), rkey)
 
@@ -185,6 +188,104 @@ def test_unique_sorted_rows(ctx, n, C, nd, prefix):
     assert none is None and nu2 == nu and ctx.torch.equal(g2, group)
 
 
+@pytest.fixture
+def msd(ctx):
+    """Round 0 of every row sort as the MSD partition (csrc/msd.hip) whatever the row count -- the product takes it from 2^18 rows --, so that
+    the shapes of this file go through it; yields a function that says how many sorts did since the last call."""
+    ops.sort_config(ctx, msd_min_rows=1)
+    last = [ops.sort_counters(ctx)[0]]
+
+    def took():
+        now = ops.sort_counters(ctx)[0]
+        d, last[0] = now - last[0], now
+        return d
+    yield took
+    ops.sort_config(ctx)
+
+
+@pytest.mark.parametrize('n,C,nd,prefix', SORT_CASES, ids=lambda v: str(v))
+def test_msd_round0_small_shapes(ctx, msd, n, C, nd, prefix):
+    """The shapes of test_argsort_rows_stable / test_unique_rows through the MSD partition: order, stability, unique, inverse == numpy.
+    Tables of few distinct heads are handed back to the LSD passes (the counters say which way a sort went); the answer is the same."""
+    rng = np.random.RandomState(n + 7 * C)
+    T = _rows_with_dups(rng, n, C, nd, prefix)
+    d_T = _dev(ctx, T.ravel())
+    perm = ctx.to_numpy(ops.argsort_rows(ctx, d_T, n, C), np.uint32).astype(np.int64)
+    assert np.array_equal(perm, O.argsort_rows(T))
+    went = msd()
+    spread = nd >= 5000 and prefix == 0
+    assert went == (1 if spread else went), 'a table of %d distinct random rows did not take the MSD partition' % nd
+    perm2, key, skey, uniq, nu = ops.unique_rows(ctx, d_T, n, C)
+    ru, rkey = O.unique_rows(T)
+    assert nu == len(ru) and np.array_equal(ctx.to_numpy(uniq).reshape(nu, C), ru)
+    assert np.array_equal(ctx.to_numpy(key, np.uint32).astype(np.int64), rkey)
+    assert np.array_equal(ctx.to_numpy(perm2, np.uint32).astype(np.int64), np.argsort(rkey, kind='stable'))
+
+
+MSD_CASES = [
+    # n, C, kind, level bits (None: the plan for n)
+    (300_000, 38, 'random', None), (300_000, 113, 'random', None), (1_000_003, 38, 'dups', None), (1_000_003, 38, 'dups', [8, 4]),
+    (600_000, 113, 'qual', None), (600_000, 113, 'qual', [8, 5]), (524_288, 8, 'random', None), (400_000, 4, 'random', None),
+    (400_000, 6, 'dups', None), (300_000, 38, 'lead', None), (700_000, 38, 'collide32', None), (700_000, 16, 'dups', [6, 6]),
+    (300_000, 38, 'random', [10, 2]), (300_000, 38, 'random', [3, 3, 3, 3]), (2_100_000, 38, 'dups', None), (300_000, 38, 'heavy', None),
+    (300_000, 12, 'steps', None),
+]
+
+
+@pytest.mark.parametrize('n,C,kind,bits', MSD_CASES, ids=lambda v: str(v).replace(' ', ''))
+def test_msd_round0(ctx, n, C, kind, bits):
+    """Row sort / unique at the sizes where round 0 is the MSD partition (csrc/msd.hip): random DNA-like rows, a tenth of them copies of n / 16
+    templates (configs[2]'s rule), QUAL-like rows (6-bit symbols from 41 values: crowded heads, 64-bit keys), 8-byte and narrower rows (the head
+    IS the row), constant leading bits, rows that collide on their 32-bit prefix and differ behind, level plans of one to four levels, one value
+    heavier than a chunk (handed back to the LSD passes), heads in few steps (QNAME-like).  Against numpy's stable order."""
+    rng = np.random.RandomState(n % 1000 + C)
+    if kind == 'qual':
+        sym = rng.randint(0, 41, size=(n, (C * 8) // 6 + 1)).astype(np.uint8)
+        bitsarr = ((sym[:, :, None] >> np.arange(5, -1, -1)) & 1).astype(np.uint8).reshape(n, -1)[:, :C * 8]
+        T = np.packbits(bitsarr, axis=1)
+    else:
+        T = rng.randint(0, 256, size=(n, C)).astype(np.uint8)
+    if kind in ('dups', 'collide32'):
+        nt = max(1, n // 16)
+        tmpl = rng.randint(0, 256, size=(nt, C)).astype(np.uint8)
+        pick = rng.rand(n) < 0.1
+        T[pick] = tmpl[rng.randint(0, nt, size=int(pick.sum()))]
+    if kind == 'collide32' and C > 9:
+        # pairs and triples that agree on their first 6 bytes and differ behind: in the last byte, right behind the head, in the middle
+        src = rng.randint(0, n, size=n // 20)
+        dst = rng.randint(0, n, size=n // 20)
+        T[dst, :6] = T[src, :6]
+        T[dst[::3], 6:] = T[src[::3], 6:]; T[dst[::3], -1] ^= 1
+    if kind == 'lead':
+        T[:, 0] = 0; T[:, 1] = (T[:, 1] & 0x0F) | 0x50
+    if kind == 'heavy':
+        T[rng.rand(n) < 0.3] = T[5]
+    if kind == 'steps':
+        T[:, 0] = 0; T[:, 1] = rng.randint(1, 5, size=n); T[:, 2] = 4; T[:, 3] = rng.randint(0x4D, 0x8D, size=n)
+    ops.sort_config(ctx, level_bits=bits)
+    try:
+        before = ops.sort_counters(ctx)
+        d_T = _dev(ctx, T.ravel())
+        perm = ctx.to_numpy(ops.argsort_rows(ctx, d_T, n, C), np.uint32).astype(np.int64)
+        after = ops.sort_counters(ctx)
+        want = O.argsort_rows(T)
+        assert np.array_equal(perm, want)
+        if kind == 'heavy': assert after[1] == before[1] + 1, 'a value heavier than a chunk must go to the LSD passes'
+        elif kind != 'steps': assert after[0] == before[0] + 1, 'the MSD partition did not run'
+        perm2, key, skey, uniq, nu = ops.unique_rows(ctx, d_T, n, C)
+        assert np.array_equal(ctx.to_numpy(perm2, np.uint32).astype(np.int64), want)
+        S = T[want]
+        head = np.ones(n, dtype=bool); head[1:] = (S[1:] != S[:-1]).any(axis=1)
+        gid = np.cumsum(head) - 1
+        assert nu == int(head.sum())
+        assert np.array_equal(ctx.to_numpy(skey, np.uint32).astype(np.int64), gid)
+        rkey = np.empty(n, dtype=np.int64); rkey[want] = gid
+        assert np.array_equal(ctx.to_numpy(key, np.uint32).astype(np.int64), rkey)
+        assert np.array_equal(ctx.to_numpy(uniq).reshape(nu, C), S[head])
+    finally:
+        ops.sort_config(ctx)
+
+
 def _rows_in_prefix_groups(rng, n, C, sizes):
     """Rows that tie on their first 6 bytes in groups of the given sizes (the 32-bit round 0 of the sort cannot separate them),
     members differing anywhere behind -- the last byte, the middle, right behind the prefix -- or not at all; shuffled."""
@@ -202,9 +303,10 @@ def _rows_in_prefix_groups(rng, n, C, sizes):
     return T[rng.permutation(n)]
 
 
+@pytest.mark.parametrize('form', ['lsd', 'msd'])
 @pytest.mark.parametrize('C', [9, 13, 38, 113])
 @pytest.mark.parametrize('sizes', [(1, 2), (2, 3, 5, 31, 32), (33, 40, 2), (200,)], ids=['pairs', 'to-32', 'beyond-32', 'long'])
-def test_sort_groups_that_tie_on_the_prefix(ctx, C, sizes):
+def test_sort_groups_that_tie_on_the_prefix(ctx, C, sizes, form, request):
     """Enough rows for the 32-bit round 0 (>= 65536): groups of up to 32 rows are settled a lane per group by whole rows
     (segment_sort_kernel), longer ones by the radix refinement rounds, mixed in one table; order, duplicate flags (through unique /
     inverse) and stability against numpy."""
@@ -212,6 +314,8 @@ def test_sort_groups_that_tie_on_the_prefix(ctx, C, sizes):
     rng = np.random.RandomState(C * 7 + len(sizes))
     T = _rows_in_prefix_groups(rng, n, C, sizes)
     d_T = _dev(ctx, T.ravel())
+    ops.sort_config(ctx, msd_min_rows=1 if form == 'msd' else -1)
+    request.addfinalizer(lambda: ops.sort_config(ctx))
     perm = ctx.to_numpy(ops.argsort_rows(ctx, d_T, n, C), np.uint32).astype(np.int64)
     assert np.array_equal(perm, O.argsort_rows(T))
     perm2, key, skey, uniq, nu = ops.unique_rows(ctx, d_T, n, C)

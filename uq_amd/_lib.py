@@ -137,6 +137,8 @@ SIGNATURES = {
     'uq_encode_u32_columns': [_vp, _vp, _u64, _u64, _int, _P(_u32), _P(_int), _P(_vp)],
     'uq_emit_fastq': [_vp, _P(EmitParams), _P(_vp), _P(_vp), _P(_vp), _vp, _vp, _vp, _u64, _vp, _vp, _u64, _P(_u64)],
     'uq_debug_scribble_lds': [_vp, C.c_uint32],
+    'uq_sort_config': [_vp, C.c_int64, _P(_int), _int],
+    'uq_sort_counters': [_vp, _P(_u64), _P(_u64)],
     'uq_decode_fastq': [_vp, _P(EmitParams), _P(UnpackParams), _P(_vp), _P(_vp), _P(_vp), _vp, _vp, _u64, _vp, _vp, _vp, _vp, _u64, _P(_u64), _P(_u64)],
     'uq_synth_size': [_vp, _P(SynthSpec), _u64, _u64, _P(_u64)],
     'uq_synth_fastq': [_vp, _P(SynthSpec), _u64, _u64, _vp, _u64],

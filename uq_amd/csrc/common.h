@@ -31,6 +31,10 @@ struct uq_ctx {
     unsigned long long* d_async;           // [0] line count  [1] line_start capacity exceeded
     const uint8_t* async_buf; uint64_t async_nbytes; bool async_read;
     const void* qf_sent;                   // the uq_qname_fused whose read-back uq_qname_fused_finish has queued ([5200, 5520) of h_pinned)
+    // the row sort's round 0 (uq_sort_config / uq_sort_counters): tables of msd_min_rows rows and more take the MSD partition (0 = the default
+    // threshold, < 0 = never); msd_levels > 0: the digits of its levels instead of the automatic plan; how many sorts went which way
+    long long msd_min_rows; int msd_levels; int msd_bits[4];
+    unsigned long long n_msd_rounds, n_lsd_rounds;
 };
 
 void uq_set_error(const char* fmt, ...);

@@ -1,0 +1,454 @@
+// msd.hip -- round 0 of the row sort as an MSD radix partition finished in LDS (round 4; replaces the LSD passes of radix.hip for
+// tables whose keys spread: numpy.argsort(table.view('V<C>'), axis=0), uq.py:773-777, 786-798).
+//
+// A table of n rows needs about log2(n) bits of sorting, not 32 or 64.  The rows' heads (their first eight bytes behind the z leading
+// bits every row shares, as a big-endian number; the top 32 bits of that for tables that do not crowd on them) are partitioned
+// MSD-first on T = log2(n / 256) .. bits in two or three levels of at most eight bits, then every run of neighbouring buckets that fits
+// a workgroup's LDS is put in its final order there:
+//   extract   rows -> keys, the level-1 histogram, AND / OR over all heads (the check of z)                    reads the row heads once
+//   level l   per-parent histograms of the next digit (count: reads the keys), exclusive scan = the buckets' first slots, then the
+//             scatter: a tile of one parent bucket, ONE returning LDS atomic per key = its rank among the tile's keys of that digit,
+//             one returning global atomic per (tile, digit) on the bucket's cursor = where the tile's run goes, the tile regrouped in
+//             LDS and stored in runs.  The order INSIDE a bucket is whatever the atomics gave -- no workgroup waits for another
+//             (no look-back, no dispatch-order assumption), and nothing has to be stable, because ...
+//   finish    ... the pairs (key, row number) of a chunk (neighbouring buckets, < 2048 pairs) are sorted in LDS by (key, row number):
+//             binned by the key's position in the chunk's key range, ranked inside the bin by counting.  Row number as the tie-break
+//             IS the stable order (uq.py's argsort under the Q17 rule), whatever the levels did.  The head flags (key differs from the
+//             key in front) fall out of the same counting loop.
+// Tables whose buckets come out heavier than a chunk (few distinct heads: QNAME columns, a read copied a million times) are
+// reported back (*status = 1) before the last scatter and take the LSD passes as before.
+#include "radix.h"
+
+namespace {
+constexpr int MT = 256;
+constexpr uint32_t MSD_G = 1024;            // chunk c = the buckets that start in slots [c G, (c + 1) G): fewer than G + the largest bucket pairs
+constexpr uint32_t MSD_CAP = 2048;          // pairs a finishing workgroup holds in LDS
+constexpr uint32_t MSD_NB = 2048;           // bins of the in-LDS step
+constexpr uint32_t MSD_MAXCHILD = 1024;     // widest digit: ten bits
+constexpr int MSD_MAXLEVELS = 4;
+
+template <typename K> struct MsdGeom { static constexpr int ITEMS = sizeof(K) == 4 ? 16 : 12; static constexpr int TILE = MT * ITEMS; };
+
+__device__ __forceinline__ uint64_t msd_chunk0(const uint8_t* __restrict__ row, uint32_t C) {
+    uint64_t v;
+    if (C >= 8) { __builtin_memcpy(&v, row, 8); return __builtin_bswap64(v); }
+    v = 0;
+    for (uint32_t i = 0; i < 8; ++i) v = (v << 8) | (i < C ? row[i] : 0);
+    return v;
+}
+
+template <typename K>
+__device__ __forceinline__ K msd_min(K a, K b) { return a < b ? a : b; }
+template <typename K>
+__device__ __forceinline__ K msd_max(K a, K b) { return a > b ? a : b; }
+
+// rows -> keys[i] = the top 8 sizeof(K) bits of (head << z); ghist[d] += keys whose top digit is d; andor[0 .. 1] = AND / OR over the heads
+template <typename K>
+__global__ __launch_bounds__(MT) void msd_extract_kernel(const uint8_t* __restrict__ table, uint32_t C, uint64_t n, uint32_t z, K* __restrict__ keys,
+                                                         uint32_t shift, uint32_t nchild, uint32_t* __restrict__ ghist, unsigned long long* __restrict__ andor) {
+    constexpr int ITEMS = MsdGeom<K>::ITEMS, TILE = MsdGeom<K>::TILE;
+    __shared__ uint32_t h[MSD_MAXCHILD];
+    __shared__ unsigned long long sa[MT / 64], so[MT / 64];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < nchild; i += MT) h[i] = 0;
+    __syncthreads();
+    unsigned long long a = ~0ull, o = 0ull;
+    const uint64_t ntiles = (n + TILE - 1) / TILE;
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint64_t base = tile * TILE;
+        uint64_t c64[ITEMS];
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const uint64_t idx = base + (uint64_t)i * MT + tid;
+            c64[i] = idx < n ? msd_chunk0(table + idx * C, C) : 0;
+        }
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const uint64_t idx = base + (uint64_t)i * MT + tid;
+            if (idx < n) {
+                a &= c64[i]; o |= c64[i];
+                const K k = (K)((c64[i] << z) >> (64 - 8 * sizeof(K)));
+                keys[idx] = k;
+                atomicAdd(&h[(uint32_t)(k >> shift)], 1u);
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { a &= __shfl_xor(a, d, 64); o |= __shfl_xor(o, d, 64); }
+    if ((tid & 63) == 0) { sa[tid >> 6] = a; so[tid >> 6] = o; }
+    __syncthreads();
+    for (uint32_t i = tid; i < nchild; i += MT)
+        if (h[i]) atomicAdd(&ghist[i], h[i]);
+    if (tid == 0) {
+        for (int w = 1; w < MT / 64; ++w) { a &= sa[w]; o |= so[w]; }
+        atomicAnd(andor, a); atomicOr(andor + 1, o);
+    }
+}
+
+// tiles per parent bucket (entry np: 0, so that the exclusive scan over np + 1 entries ends in the total)
+__global__ __launch_bounds__(MT) void msd_parent_tiles_kernel(const uint32_t* __restrict__ parent_end, uint32_t np, uint32_t tile, uint32_t* __restrict__ ntiles) {
+    const uint32_t p = blockIdx.x * MT + threadIdx.x;
+    if (p > np) return;
+    if (p == np) { ntiles[p] = 0; return; }
+    const uint32_t lo = p ? parent_end[p - 1] : 0u;
+    ntiles[p] = (parent_end[p] - lo + tile - 1) / tile;
+}
+
+// the parent bucket tile t belongs to: the largest p with tile_prefix[p] <= t (empty parents in front of it are skipped by construction)
+__device__ __forceinline__ uint32_t msd_find_parent(const uint32_t* __restrict__ tile_prefix, uint32_t np, uint32_t t) {
+    uint32_t lo = 0, hi = np;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (tile_prefix[mid] <= t) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// hist[p * nchild + d] = keys of parent bucket p whose digit is d.  A workgroup takes a run of consecutive tiles: one search, then it walks.
+template <typename K>
+__global__ __launch_bounds__(MT) void msd_count_kernel(const K* __restrict__ keys, const uint32_t* __restrict__ parent_end, const uint32_t* __restrict__ tile_prefix,
+                                                       uint32_t np, uint32_t shift, uint32_t nchild, uint32_t* __restrict__ hist) {
+    constexpr int ITEMS = MsdGeom<K>::ITEMS, TILE = MsdGeom<K>::TILE;
+    __shared__ uint32_t h[MSD_MAXCHILD];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t ntiles = tile_prefix[np];
+    const uint32_t per = (ntiles + gridDim.x - 1) / gridDim.x;
+    uint32_t t = blockIdx.x * per;
+    const uint32_t tend = t + per < ntiles ? t + per : ntiles;
+    if (per == 0 || t >= tend) return;
+    uint32_t p = msd_find_parent(tile_prefix, np, t);
+    for (uint32_t i = tid; i < nchild; i += MT) h[i] = 0;
+    __syncthreads();
+    uint32_t cur = p;
+    const uint32_t mask = nchild - 1;
+    for (; t < tend; ++t) {
+        while (p + 1 < np && tile_prefix[p + 1] <= t) ++p;
+        if (p != cur) {
+            __syncthreads();
+            for (uint32_t i = tid; i < nchild; i += MT) { const uint32_t c = h[i]; if (c) atomicAdd(&hist[(uint64_t)cur * nchild + i], c); h[i] = 0; }
+            __syncthreads();
+            cur = p;
+        }
+        const uint32_t pend = parent_end[p];
+        const uint32_t lo = (p ? parent_end[p - 1] : 0u) + (t - tile_prefix[p]) * TILE;
+        const uint32_t m = pend - lo < (uint32_t)TILE ? pend - lo : (uint32_t)TILE;
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const uint32_t q = i * MT + tid;
+            if (q < m) atomicAdd(&h[(uint32_t)(keys[lo + q] >> shift) & mask], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < nchild; i += MT) { const uint32_t c = h[i]; if (c) atomicAdd(&hist[(uint64_t)cur * nchild + i], c); }
+}
+
+__global__ __launch_bounds__(MT) void msd_max_kernel(const uint32_t* __restrict__ hist, uint64_t nb, uint32_t* __restrict__ out) {
+    uint32_t m = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * MT + threadIdx.x; i < nb; i += (uint64_t)gridDim.x * MT) m = hist[i] > m ? hist[i] : m;
+    m = wave_max(m);
+    if (lane_id() == 0 && m) atomicMax(out, m);
+}
+
+// One level of the partition.  cursors[p * nchild + d] holds the next free slot of bucket (p, d) (the scanned histogram before the
+// launch, the buckets' ends after it).  FIRST: the keys as msd_extract_kernel left them, row number = position, one parent.
+template <typename K, bool FIRST>
+__global__ __launch_bounds__(MT) void msd_scatter_kernel(const K* __restrict__ keys_in, const uint32_t* __restrict__ idx_in, K* __restrict__ keys_out,
+                                                         uint32_t* __restrict__ idx_out, uint32_t n, const uint32_t* __restrict__ parent_end,
+                                                         const uint32_t* __restrict__ tile_prefix, uint32_t np, uint32_t shift, uint32_t nchild,
+                                                         uint32_t* __restrict__ cursors) {
+    constexpr int ITEMS = MsdGeom<K>::ITEMS, TILE = MsdGeom<K>::TILE;
+    __shared__ K s_keys[TILE];
+    __shared__ uint32_t s_idx[TILE];
+    __shared__ uint32_t s_h[MSD_MAXCHILD];       // the tile's count per digit, then the digit's first slot in the tile
+    __shared__ uint32_t s_g[MSD_MAXCHILD];       // the digit's run in the output: first slot - first slot in the tile
+    __shared__ uint32_t s_scan[MT / 64 + 1];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t ntiles = FIRST ? (n + TILE - 1) / TILE : tile_prefix[np];
+    const uint32_t per = (ntiles + gridDim.x - 1) / gridDim.x;
+    uint32_t t = blockIdx.x * per;
+    const uint32_t tend = t + per < ntiles ? t + per : ntiles;
+    if (per == 0 || t >= tend) return;
+    uint32_t p = FIRST ? 0u : msd_find_parent(tile_prefix, np, t);
+    const uint32_t mask = nchild - 1;
+    const uint32_t R = nchild > (uint32_t)MT ? nchild / MT : 1u;          // digits per lane in the scan of the counts (nchild is a power of two)
+    for (; t < tend; ++t) {
+        uint32_t lo, m;
+        if (FIRST) { lo = t * TILE; m = n - lo < (uint32_t)TILE ? n - lo : (uint32_t)TILE; }
+        else {
+            while (p + 1 < np && tile_prefix[p + 1] <= t) ++p;
+            const uint32_t pend = parent_end[p];
+            lo = (p ? parent_end[p - 1] : 0u) + (t - tile_prefix[p]) * TILE;
+            m = pend - lo < (uint32_t)TILE ? pend - lo : (uint32_t)TILE;
+        }
+        for (uint32_t i = tid; i < nchild; i += MT) s_h[i] = 0;
+        __syncthreads();
+        K key[ITEMS];
+        uint32_t val[ITEMS], rk[ITEMS];
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const uint32_t q = i * MT + tid;
+            key[i] = q < m ? keys_in[lo + q] : (K)0;
+            val[i] = FIRST ? lo + q : (q < m ? idx_in[lo + q] : 0u);
+        }
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const uint32_t q = i * MT + tid;
+            rk[i] = q < m ? atomicAdd(&s_h[(uint32_t)(key[i] >> shift) & mask], 1u) : 0u;
+        }
+        __syncthreads();
+        uint32_t cnt[4], sum = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) { const uint32_t b = tid * R + j; cnt[j] = (j < R && b < nchild) ? s_h[b] : 0u; sum += cnt[j]; }
+        uint32_t total;
+        uint32_t start = block_exclusive_sum<uint32_t, MT / 64>(sum, s_scan, total);
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t b = tid * R + j;
+            if (j < R && b < nchild) {
+                const uint32_t g = cnt[j] ? atomicAdd(&cursors[(uint64_t)p * nchild + b], cnt[j]) : 0u;
+                s_h[b] = start; s_g[b] = g - start;
+                start += cnt[j];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const uint32_t q = i * MT + tid;
+            if (q < m) {
+                const uint32_t pos = s_h[(uint32_t)(key[i] >> shift) & mask] + rk[i];
+                s_keys[pos] = key[i]; s_idx[pos] = val[i];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const uint32_t q = i * MT + tid;
+            if (q < m) {
+                const K k = s_keys[q];
+                const uint32_t out = s_g[(uint32_t)(k >> shift) & mask] + q;
+                keys_out[out] = k; idx_out[out] = s_idx[q];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// bound[c] = the first bucket boundary at or behind slot c G (bound[0] = 0, bound[nchunks] = n): chunk c = pairs [bound[c], bound[c + 1])
+__global__ __launch_bounds__(MT) void msd_chunk_bounds_kernel(const uint32_t* __restrict__ bucket_end, uint64_t nb, uint32_t n, uint32_t nchunks,
+                                                              uint32_t* __restrict__ bound) {
+    const uint32_t c = blockIdx.x * MT + threadIdx.x;
+    if (c > nchunks) return;
+    if (c == 0) { bound[0] = 0; return; }
+    if (c == nchunks) { bound[c] = n; return; }
+    const uint32_t target = c * MSD_G;
+    uint64_t lo = 0, hi = nb;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (bucket_end[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    bound[c] = lo < nb ? bucket_end[lo] : n;
+}
+
+// A chunk in its final order: perm[j] = row number, heads[j] = 1 when the key at j differs from the key at j - 1 (or j = 0), else 0.
+template <typename K>
+__global__ __launch_bounds__(MT) void msd_finish_kernel(const K* __restrict__ keys, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ bound,
+                                                        uint32_t nchunks, uint32_t* __restrict__ perm, uint8_t* __restrict__ heads, uint32_t* __restrict__ overflow) {
+    constexpr int FI = MSD_CAP / MT;
+    constexpr int BI = MSD_NB / MT;
+    __shared__ K s_k[MSD_CAP];
+    __shared__ uint32_t s_i[MSD_CAP];
+    __shared__ uint32_t s_bin[MSD_NB + 1];
+    __shared__ K s_mn[MT / 64], s_mx[MT / 64];
+    __shared__ uint32_t s_scan[MT / 64 + 1];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const uint32_t lo = bound[c], hi = bound[c + 1];
+        const uint32_t m = hi - lo;
+        if (hi <= lo) continue;
+        if (m > MSD_CAP) { if (tid == 0) *overflow = 1u; continue; }
+        K k[FI];
+        uint32_t v[FI], r[FI];
+        K mn = ~(K)0, mx = 0;
+#pragma unroll
+        for (int i = 0; i < FI; ++i) {
+            const uint32_t q = i * MT + tid;
+            k[i] = q < m ? keys[lo + q] : (K)0;
+            v[i] = q < m ? idx[lo + q] : 0u;
+            if (q < m) { mn = msd_min(mn, k[i]); mx = msd_max(mx, k[i]); }
+        }
+        mn = wave_min(mn); mx = wave_max(mx);
+#pragma unroll
+        for (int j = 0; j < BI; ++j) s_bin[j * MT + tid] = 0;
+        if ((tid & 63) == 0) { s_mn[tid >> 6] = mn; s_mx[tid >> 6] = mx; }
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < MT / 64; ++w) { mn = msd_min(mn, s_mn[w]); mx = msd_max(mx, s_mx[w]); }
+        const K range = mx - mn;
+        const uint32_t bits = range ? 64u - (uint32_t)__clzll((unsigned long long)range) : 0u;
+        const uint32_t sh = bits > 11u ? bits - 11u : 0u;                    // (k - mn) >> sh < 2048 = MSD_NB
+#pragma unroll
+        for (int i = 0; i < FI; ++i) {
+            const uint32_t q = i * MT + tid;
+            r[i] = q < m ? atomicAdd(&s_bin[(uint32_t)((k[i] - mn) >> sh)], 1u) : 0u;
+        }
+        __syncthreads();
+        uint32_t cnt[BI], sum = 0;
+#pragma unroll
+        for (int j = 0; j < BI; ++j) { cnt[j] = s_bin[tid * BI + j]; sum += cnt[j]; }
+        uint32_t total;
+        uint32_t start = block_exclusive_sum<uint32_t, MT / 64>(sum, s_scan, total);
+#pragma unroll
+        for (int j = 0; j < BI; ++j) { s_bin[tid * BI + j] = start; start += cnt[j]; }
+        if (tid == 0) s_bin[MSD_NB] = m;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < FI; ++i) {
+            const uint32_t q = i * MT + tid;
+            if (q < m) {
+                const uint32_t pos = s_bin[(uint32_t)((k[i] - mn) >> sh)] + r[i];
+                s_k[pos] = k[i]; s_i[pos] = v[i];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < FI; ++i) {
+            const uint32_t q = i * MT + tid;
+            if (q < m) {
+                const K kk = s_k[q];
+                const uint32_t ii = s_i[q];
+                const uint32_t b = (uint32_t)((kk - mn) >> sh);
+                const uint32_t blo = s_bin[b], bhi = s_bin[b + 1];
+                uint32_t below = 0;
+                bool has = false;
+                K pk = 0;
+                if (bhi - blo > 1) {
+                    for (uint32_t j = blo; j < bhi; ++j) {
+                        const K kj = s_k[j];
+                        const uint32_t ij = s_i[j];
+                        const bool less = kj < kk || (kj == kk && ij < ii);
+                        if (less) { ++below; pk = has ? msd_max(pk, kj) : kj; has = true; }
+                    }
+                }
+                const uint32_t pos = lo + blo + below;
+                perm[pos] = ii;
+                heads[pos] = (!has || pk != kk) ? (uint8_t)1 : (uint8_t)0;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+int ceil_log2_u64(uint64_t v) { int b = 0; while ((uint64_t(1) << b) < v) ++b; return b; }
+
+// the digits of the levels for n rows: T bits in all so that a bucket holds 32 .. 64 rows on average -- a sixteenth of what a chunk may
+// hold: QUAL rows (6-bit symbols of 41 values) fill a fifth of the prefixes, and the buckets need not be full for the passes to run
+// well (a level's runs are tile / 2^bits pairs whatever T is) --, at most eight bits a level (uq_sort_config overrides: tuning and tests)
+int msd_plan(const uq_ctx* ctx, uint64_t n, int keybits, int* bits) {
+    if (ctx->msd_levels > 0) {
+        int tot = 0;
+        for (int l = 0; l < ctx->msd_levels; ++l) { bits[l] = ctx->msd_bits[l]; tot += bits[l]; }
+        return tot <= keybits && tot <= 24 ? ctx->msd_levels : 0;
+    }
+    int T = ceil_log2_u64((n + 63) / 64);
+    if (T < 8) T = 8;
+    if (T > 24) T = 24;
+    if (T > keybits) return 0;
+    const int L = (T + 7) / 8;
+    bits[0] = 8;
+    int rest = T - 8;
+    for (int l = 1; l < L; ++l) { bits[l] = (rest + (L - 1 - l)) / (L - l); rest -= bits[l]; }
+    return L;
+}
+}  // namespace
+
+size_t msd_ws_bytes(uint64_t n) {
+    // the histograms of the levels (the last one the largest: up to 2^24 buckets), the tile tables, the chunk table, a few words
+    const uint64_t nbmax = uint64_t(1) << 24;
+    uint64_t nb = 256;
+    while (nb < nbmax && nb * 32 < n) nb <<= 1;
+    nb <<= 1;                                            // (a plan from the environment may ask for more buckets than the default)
+    if (nb > nbmax) nb = nbmax;
+    return (size_t)(nb * 2 + 4096) * 4 * 2 + (size_t)(n / MSD_G + 16) * 4 + 4096;
+}
+
+template <typename K>
+static int msd_round0_impl(uq_ctx* ctx, const uint8_t* table, uint32_t C, uint64_t n, uint32_t z, void* keysA, void* keysB, uint32_t* idxA, uint32_t* idxB,
+                           uint32_t* perm, uint8_t* heads, void* ws, size_t ws_bytes, int* status, uint64_t* h_andor) {
+    *status = 1;
+    int bits[MSD_MAXLEVELS];
+    const int keybits = 8 * (int)sizeof(K);
+    const int L = msd_plan(ctx, n, keybits, bits);
+    if (L == 0) return 0;
+    hipStream_t s = ctx->stream;
+    // ---- workspace
+    uint64_t nb[MSD_MAXLEVELS];
+    size_t need = 4096;
+    { uint64_t b = 1; for (int l = 0; l < L; ++l) { b <<= bits[l]; nb[l] = b; need += (size_t)(b + 64) * 4 + (size_t)(b + 64 + 1) * 4; } }
+    const uint32_t nchunks = (uint32_t)((n + MSD_G - 1) / MSD_G);
+    need += (size_t)(nchunks + 16) * 4;
+    if (need > ws_bytes) return 0;
+    uint8_t* w = (uint8_t*)ws;
+    unsigned long long* andor = (unsigned long long*)w;            // [0] AND  [1] OR
+    uint32_t* misc = (uint32_t*)(w + 16);                          // [0] largest bucket of the last level  [1] a chunk beyond the LDS (cannot happen)
+    size_t off = 4096;
+    uint32_t* hist[MSD_MAXLEVELS];
+    uint32_t* tilep[MSD_MAXLEVELS];
+    for (int l = 0; l < L; ++l) { hist[l] = (uint32_t*)(w + off); off += (size_t)(nb[l] + 64) * 4; }
+    for (int l = 1; l < L; ++l) { tilep[l] = (uint32_t*)(w + off); off += (size_t)(nb[l - 1] + 64 + 1) * 4; }
+    uint32_t* bound = (uint32_t*)(w + off);
+    UQ_CHECK_HIP(hipMemsetAsync(w, 0, 4096, s));
+    UQ_CHECK_HIP(hipMemsetAsync(andor, 0xFF, 8, s));
+    for (int l = 0; l < L; ++l) UQ_CHECK_HIP(hipMemsetAsync(hist[l], 0, nb[l] * 4, s));
+    constexpr int TILE = MsdGeom<K>::TILE;
+    const uint32_t nt1 = (uint32_t)((n + TILE - 1) / TILE);
+    const uint32_t grid = UQ_NUM_CU * 6;
+    K* kin = (K*)keysA; K* kout = (K*)keysB;
+    uint32_t* vin = idxA; uint32_t* vout = idxB;
+    int shift = keybits - bits[0];
+    msd_extract_kernel<K><<<nt1 < grid ? nt1 : grid, MT, 0, s>>>(table, C, n, z, kin, (uint32_t)shift, (uint32_t)nb[0], hist[0], andor);
+    UQ_LAUNCH_CHECK();
+    for (int l = 0; l < L; ++l) {
+        const uint32_t nchild = 1u << bits[l];
+        if (l > 0) {
+            shift -= bits[l];
+            const uint32_t np = (uint32_t)nb[l - 1];
+            msd_parent_tiles_kernel<<<(np + 1 + MT - 1) / MT, MT, 0, s>>>(hist[l - 1], np, TILE, tilep[l]);
+            UQ_LAUNCH_CHECK();
+            UQ_TRY(uq_scan_exclusive_u32(ctx, tilep[l], tilep[l], (uint64_t)np + 1, nullptr));
+            msd_count_kernel<K><<<grid, MT, 0, s>>>(kin, hist[l - 1], tilep[l], np, (uint32_t)shift, nchild, hist[l]);
+            UQ_LAUNCH_CHECK();
+        }
+        if (l == L - 1) {
+            // the largest bucket decides whether the chunks fit the LDS; the heads' AND / OR whether z held: one wait, before the last scatter
+            msd_max_kernel<<<256, MT, 0, s>>>(hist[l], nb[l], misc);
+            UQ_LAUNCH_CHECK();
+            UQ_TRY(uq_read_back(ctx, ctx->h_pinned, w, 32));
+            UQ_CHECK_HIP(hipStreamSynchronize(s));
+            h_andor[0] = ctx->h_pinned[0]; h_andor[1] = ctx->h_pinned[1];
+            const uint32_t largest = (uint32_t)ctx->h_pinned[2];
+            const uint64_t same = ~(h_andor[0] ^ h_andor[1]);
+            uint32_t zt = 0;
+            while (zt < 64 && ((same >> (63 - zt)) & 1)) ++zt;
+            if (zt < z) { *status = 2; return 0; }                   // the sample agreed on more bits than the table: the caller runs it again
+            if (largest > MSD_G) return 0;                           // heavy buckets: not this table
+        }
+        UQ_TRY(uq_scan_exclusive_u32(ctx, hist[l], hist[l], nb[l], nullptr));
+        if (l == 0) msd_scatter_kernel<K, true><<<nt1 < grid ? nt1 : grid, MT, 0, s>>>(kin, nullptr, kout, vout, (uint32_t)n, nullptr, nullptr, 1, (uint32_t)shift, nchild, hist[0]);
+        else msd_scatter_kernel<K, false><<<grid, MT, 0, s>>>(kin, vin, kout, vout, (uint32_t)n, hist[l - 1], tilep[l], (uint32_t)nb[l - 1], (uint32_t)shift, nchild, hist[l]);
+        UQ_LAUNCH_CHECK();
+        K* tk = kin; kin = kout; kout = tk;
+        uint32_t* tv = vin; vin = vout; vout = tv;
+    }
+    msd_chunk_bounds_kernel<<<(nchunks + 1 + MT - 1) / MT, MT, 0, s>>>(hist[L - 1], nb[L - 1], (uint32_t)n, nchunks, bound);
+    UQ_LAUNCH_CHECK();
+    msd_finish_kernel<K><<<nchunks < UQ_NUM_CU * 8 ? nchunks : UQ_NUM_CU * 8, MT, 0, s>>>(kin, vin, bound, nchunks, perm, heads, misc + 1);
+    UQ_LAUNCH_CHECK();
+    *status = 0;
+    return 0;
+}
+
+int msd_round0(uq_ctx* ctx, const uint8_t* table, uint32_t C, uint64_t n, uint32_t z, int key64, void* keysA, void* keysB, uint32_t* idxA, uint32_t* idxB,
+               uint32_t* perm, uint8_t* heads, void* ws, size_t ws_bytes, int* status, uint64_t* h_andor) {
+    if (key64) return msd_round0_impl<uint64_t>(ctx, table, C, n, z, keysA, keysB, idxA, idxB, perm, heads, ws, ws_bytes, status, h_andor);
+    return msd_round0_impl<uint32_t>(ctx, table, C, n, z, keysA, keysB, idxA, idxB, perm, heads, ws, ws_bytes, status, h_andor);
+}

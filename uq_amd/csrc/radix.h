@@ -23,3 +23,13 @@ int radix_prefix_census32(uq_ctx* ctx, const uint64_t* keys64, uint64_t n, uint3
 // written out), with z from a sample: h_andor[0 .. 1] = AND / OR over every row's chunk, so that the caller can tell whether z holds.
 int radix_rows_prefix_census32(uq_ctx* ctx, const uint8_t* table, uint32_t C, uint64_t n, uint32_t z, uint32_t* keys, uint32_t* vals, void* ws,
                                uint32_t* h_hist, uint64_t* h_andor);
+
+// msd.hip -- round 0 of the row sort as an MSD partition finished in LDS.  Sorts the rows by key = the top 32 (key64 = 0) or all 64 bits of
+// (head << z), head = a row's first eight bytes as a big-endian number (rows of fewer bytes: zero-filled), ties in row order: d_perm = the
+// order, heads[j] = 1 when the key at position j differs from the one in front of it, else 0.  keysA / keysB: n * 8 bytes each, idxA / idxB:
+// n * 4 bytes each, ws: msd_ws_bytes(n).  *status: 0 = done; 1 = not for this table (buckets heavier than a workgroup's LDS: few distinct
+// heads) -- nothing usable was written, the caller takes the LSD passes; 2 = the table's rows share fewer than z leading bits
+// (h_andor = AND / OR over all heads says how many): call again with that z.  One host wait inside.
+size_t msd_ws_bytes(uint64_t n);
+int msd_round0(uq_ctx* ctx, const uint8_t* table, uint32_t C, uint64_t n, uint32_t z, int key64, void* keysA, void* keysB, uint32_t* idxA, uint32_t* idxB,
+               uint32_t* perm, uint8_t* heads, void* ws, size_t ws_bytes, int* status, uint64_t* h_andor);

@@ -16,6 +16,8 @@
 // Ties are broken by input order (stable) -- the canonical order of SURVEY.md Q17.
 // The per-row "first of its group" flags that fall out of the rounds give unique / inverse for free:
 // key = inclusive scan of the flags, and the stable sort order IS argsort(key, stable) (uq.py:796).
+#include <algorithm>
+#include <stdlib.h>
 #include "radix.h"
 
 namespace {
@@ -281,6 +283,7 @@ int sort_rows_core(uq_ctx* ctx, const uint8_t* table, uint64_t n, uint32_t C, ui
     const size_t o_pos = plan.add(n * 4), o_aval = plan.add(n * 4), o_sid = plan.add(n * 4);
     const size_t o_tot = plan.add(64);
     const size_t o_rws = plan.add(radix_ws_bytes(n));
+    const size_t o_msd = plan.add(msd_ws_bytes(n));
     const size_t o_extra = plan.add(extra_bytes + 256);
     void* base;
     UQ_TRY(uq_scratch(ctx, plan.off, &base));
@@ -318,15 +321,37 @@ int sort_rows_core(uq_ctx* ctx, const uint8_t* table, uint64_t n, uint32_t C, ui
         }
         return coll;
     };
-    if (mode32) {
-        const uint64_t samples = 4096;                                           // (n >= 65536 here)
+    // the short groups that tie on round 0's key (chance collisions, duplicated reads): a lane per group sorts its slice of the order by whole
+    // rows and sets the final flags (segment_sort_kernel).  bcnt0 = active_count_kernel's / heads32_count_kernel's counters of `heads`.
+    // Returns through *settled whether every group was short enough (then the order is final).
+    uint8_t* flags = b + o_heads2;
+    const uint64_t ncb0 = (n + CB - 1) / CB;
+    uint32_t* bcnt0 = apos;
+    auto settle_short_groups = [&](bool* settled) -> int {
+        UQ_TRY(uq_scan_exclusive_u64(ctx, (const uint64_t*)bcnt0, (uint64_t*)bcnt0, ncb0, tot));
+        segment_starts_kernel<<<(uint32_t)ncb0, ST, 0, s>>>(heads, (const unsigned long long*)bcnt0, n, pos);
+        UQ_LAUNCH_CHECK();
+        UQ_CHECK_HIP(hipMemsetAsync(tot + 3, 0, 8, s));
+        segment_sort_kernel<<<UQ_NUM_CU * 8, ST, 0, s>>>(table, C, d_perm, heads, flags, n, pos, (const unsigned long long*)tot, (uint32_t*)(tot + 3));
+        UQ_LAUNCH_CHECK();
+        heads = flags; out->heads = flags;
+        UQ_TRY(uq_read_back(ctx, ctx->h_pinned, tot + 3, 8));
+        UQ_CHECK_HIP(hipStreamSynchronize(s));
+        *settled = (uint32_t)ctx->h_pinned[0] == 0;
+        return 0;
+    };
+    const uint64_t msd_min = ctx->msd_min_rows > 0 ? (uint64_t)ctx->msd_min_rows : (uint64_t(1) << 18);
+    bool sampled = false, msd_ok = ctx->msd_min_rows >= 0 && n >= msd_min && n >= 2 && n < (uint64_t(1) << 31);
+    if (mode32 || msd_ok) {
+        const uint64_t samples = 4096;                                           // (spread over the table; fewer rows than that: some twice)
         sample_chunks_kernel<<<(uint32_t)((samples + ST - 1) / ST), ST, 0, s>>>(table, n, C, samples, (uint64_t*)ctx->d_pinned);
         UQ_LAUNCH_CHECK();
         UQ_CHECK_HIP(hipStreamSynchronize(s));
+        sampled = true;
         uint64_t a = ~0ull, o = 0;
         for (uint64_t j = 0; j < samples; ++j) { a &= ctx->h_pinned[j]; o |= ctx->h_pinned[j]; }
         z = leading_same(a, o);
-        mode32 = z <= 32;
+        mode32 = mode32 && z <= 32;
         if (mode32) {
             // crowded tables (a QUAL table of 200 M rows on its first 32 bits) go to the 64-bit round 0 without the pass below: the sample's own digit
             // census overestimates the collisions of spread-out keys by a quarter (a sample of 4096 adds 1 / 4096 to each sum of squares), far from the threshold
@@ -338,9 +363,45 @@ int sort_rows_core(uq_ctx* ctx, const uint8_t* table, uint64_t n, uint32_t C, ui
             }
             if (collisions(s_hist, (double)samples, (double)n) > 0.6) mode32 = false;
         }
+        if (msd_ok) {
+            // the MSD partition wants heads that spread: a value of the top 20 bits behind z that takes eight of the 4096 sampled rows holds
+            // n / 512 rows -- heavier than a finishing chunk whatever the levels (QNAME columns, a read copied a million times)
+            msd_ok = z < 40;
+            if (msd_ok) {
+                static thread_local uint32_t top[4096];
+                for (uint64_t j = 0; j < samples; ++j) top[j] = (uint32_t)((ctx->h_pinned[j] << z) >> 44);
+                std::sort(top, top + samples);
+                uint32_t run = 1, worst = 1;
+                for (uint64_t j = 1; j < samples; ++j) { run = top[j] == top[j - 1] ? run + 1 : 1; worst = run > worst ? run : worst; }
+                if (worst >= 8 && (double)worst * (double)n / (double)samples > 1024.0) msd_ok = false;
+            }
+        }
     }
     int alt = 0;
-    if (mode32) {
+    bool round0_done = false;
+    if (msd_ok) {
+        // MSD partition + LDS finish (msd.hip): keys of 32 bits where the LSD round 0 would take them (mode32), else the whole head
+        int status = 1;
+        for (int attempt = 0; attempt < 3; ++attempt) {
+            uint64_t h_andor[2];
+            UQ_TRY(msd_round0(ctx, table, C, n, z, mode32 ? 0 : 1, keysA, keysB, valsA, valsB, d_perm, heads, b + o_msd, msd_ws_bytes(n), &status, h_andor));
+            if (status != 2) break;
+            z = leading_same(h_andor[0], h_andor[1]);
+        }
+        if (status == 0) {
+            round0_done = true;
+            ++ctx->n_msd_rounds;
+            if (C <= 8) return 0;                                                // the head IS the row: ties are duplicates, flags 1 / 0 as heads_first_kernel leaves them
+            UQ_CHECK_HIP(hipMemcpyAsync(flags, heads, n, hipMemcpyDeviceToDevice, s));
+            active_count_kernel<<<(uint32_t)ncb0, ST, 0, s>>>(heads, n, bcnt0);
+            UQ_LAUNCH_CHECK();
+            bool settled;
+            UQ_TRY(settle_short_groups(&settled));
+            if (settled) return 0;
+        } else if (status == 2) mode32 = false;                                  // (a table that keeps contradicting its sample: the plain 64-bit passes)
+    }
+    if (!round0_done) ++ctx->n_lsd_rounds;
+    if (mode32 && !round0_done) {
         uint32_t* k32a = (uint32_t*)keysB;                                      // keysB's n * 8 bytes hold both u32 key buffers
         uint32_t* k32b = k32a + n;
         static thread_local uint32_t h_hist[4 * 256];
@@ -359,24 +420,14 @@ int sort_rows_core(uq_ctx* ctx, const uint8_t* table, uint64_t n, uint32_t C, ui
             UQ_TRY(radix_sort_pairs32(ctx, k32a, d_perm, k32b, valsB, n, 0, 32, rws, &alt, h_hist, 1));
             if (alt) UQ_CHECK_HIP(hipMemcpyAsync(d_perm, valsB, n * 4, hipMemcpyDeviceToDevice, s));
             // the groups that tie on the prefix are short (colliding pairs, duplicates): a lane sorts each by whole rows
-            uint8_t* flags = b + o_heads2;
-            const uint64_t ncb0 = (n + CB - 1) / CB;
-            uint32_t* bcnt0 = apos;
             heads32_count_kernel<uint32_t><<<(uint32_t)ncb0, ST, 0, s>>>(alt ? k32b : k32a, n, heads, flags, bcnt0);
             UQ_LAUNCH_CHECK();
-            UQ_TRY(uq_scan_exclusive_u64(ctx, (const uint64_t*)bcnt0, (uint64_t*)bcnt0, ncb0, tot));
-            segment_starts_kernel<<<(uint32_t)ncb0, ST, 0, s>>>(heads, (const unsigned long long*)bcnt0, n, pos);
-            UQ_LAUNCH_CHECK();
-            UQ_CHECK_HIP(hipMemsetAsync(tot + 3, 0, 8, s));
-            segment_sort_kernel<<<UQ_NUM_CU * 8, ST, 0, s>>>(table, C, d_perm, heads, flags, n, pos, (const unsigned long long*)tot, (uint32_t*)(tot + 3));
-            UQ_LAUNCH_CHECK();
-            heads = flags; out->heads = flags;
-            UQ_TRY(uq_read_back(ctx, ctx->h_pinned, tot + 3, 8));
-            UQ_CHECK_HIP(hipStreamSynchronize(s));
-            if ((uint32_t)ctx->h_pinned[0] == 0) return 0;        // every group settled: the order is final
+            bool settled;
+            UQ_TRY(settle_short_groups(&settled));
+            if (settled) return 0;        // every group settled: the order is final
         }
     }
-    if (!mode32) {
+    if (!mode32 && !round0_done) {
         extract_all_kernel<<<blocks_for(n), ST, 0, s>>>(table, n, C, keysA, valsA);
         UQ_LAUNCH_CHECK();
         UQ_TRY(radix_sort_pairs(ctx, keysA, valsA, keysB, valsB, n, 0, 64, rws, &alt));
@@ -391,23 +442,14 @@ int sort_rows_core(uq_ctx* ctx, const uint8_t* table, uint64_t n, uint32_t C, ui
             // pair that collides by chance): as after the 32-bit round 0, a lane sorts each group by whole rows on the spot and sets
             // its final flags -- one pair that differs somewhere behind byte 8 used to send every tied row (a tenth of a 200 M row
             // QUAL table) through a radix refinement round of fifteen more passes
-            uint8_t* flags = b + o_heads2;
-            const uint64_t ncb0 = (n + CB - 1) / CB;
-            uint32_t* bcnt0 = apos;
             heads32_count_kernel<uint64_t><<<(uint32_t)ncb0, ST, 0, s>>>(K, n, heads, flags, bcnt0);
             UQ_LAUNCH_CHECK();
-            UQ_TRY(uq_scan_exclusive_u64(ctx, (const uint64_t*)bcnt0, (uint64_t*)bcnt0, ncb0, tot));
-            segment_starts_kernel<<<(uint32_t)ncb0, ST, 0, s>>>(heads, (const unsigned long long*)bcnt0, n, pos);
-            UQ_LAUNCH_CHECK();
-            UQ_CHECK_HIP(hipMemsetAsync(tot + 3, 0, 8, s));
-            segment_sort_kernel<<<UQ_NUM_CU * 8, ST, 0, s>>>(table, C, d_perm, heads, flags, n, pos, (const unsigned long long*)tot, (uint32_t*)(tot + 3));
-            UQ_LAUNCH_CHECK();
-            heads = flags; out->heads = flags;
-            UQ_TRY(uq_read_back(ctx, ctx->h_pinned, tot + 3, 8));
-            UQ_CHECK_HIP(hipStreamSynchronize(s));
-            if ((uint32_t)ctx->h_pinned[0] == 0) return 0;        // every group settled: the order is final
+            bool settled;
+            UQ_TRY(settle_short_groups(&settled));
+            if (settled) return 0;        // every group settled: the order is final
         }
     }
+    (void)sampled;
 
     // ---- refinement rounds (after a 32-bit round 0 the first one looks at the whole of chunk 0 again)
     const uint32_t nchunks = (C + 7) / 8;
@@ -565,6 +607,23 @@ __global__ void unstack_column_kernel(const uint8_t* __restrict__ rows, uint64_t
 
 int uq_gather_rows_internal(uq_ctx* ctx, const uint8_t* d_table, uint64_t table_rows, uint32_t cols, const void* d_index,
                             int index_itemsize, uint64_t n_out, uint8_t* d_out);
+
+extern "C" int uq_sort_config(uq_ctx* ctx, int64_t msd_min_rows, const int* h_level_bits, int nlevels) {
+    UQ_REQUIRE(ctx && nlevels >= 0 && nlevels <= 4 && (nlevels == 0 || h_level_bits), "uq_sort_config: bad argument");
+    int tot = 0;
+    for (int l = 0; l < nlevels; ++l) { UQ_REQUIRE(h_level_bits[l] >= 1 && h_level_bits[l] <= 10, "uq_sort_config: a level takes 1 .. 10 bits"); tot += h_level_bits[l]; }
+    UQ_REQUIRE(tot <= 24, "uq_sort_config: at most 24 bits over the levels");
+    ctx->msd_min_rows = msd_min_rows;
+    ctx->msd_levels = nlevels;
+    for (int l = 0; l < nlevels; ++l) ctx->msd_bits[l] = h_level_bits[l];
+    return 0;
+}
+
+extern "C" int uq_sort_counters(uq_ctx* ctx, uint64_t* h_msd_rounds, uint64_t* h_lsd_rounds) {
+    UQ_REQUIRE(ctx && h_msd_rounds && h_lsd_rounds, "uq_sort_counters: null argument");
+    *h_msd_rounds = ctx->n_msd_rounds; *h_lsd_rounds = ctx->n_lsd_rounds;
+    return 0;
+}
 
 extern "C" int uq_argsort_rows(uq_ctx* ctx, const uint8_t* d_table, uint64_t rows, uint32_t cols, uint32_t* d_perm) {
     UQ_REQUIRE(ctx && (rows == 0 || (d_table && d_perm)), "uq_argsort_rows: null argument");

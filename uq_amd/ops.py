@@ -355,6 +355,19 @@ def unpattern(ctx, payload, rows, cols, pattern_id, out=None):
 
 
 # ------------------------------------------------------------------ sort / gather / unique
+def sort_config(ctx, msd_min_rows=0, level_bits=None):
+    """uq_sort_config: from how many rows a sort's round 0 runs as the MSD partition (0 = default, < 0 = never) and, optionally, its levels' digits."""
+    bits = list(level_bits or [])
+    call('uq_sort_config', ctx.h, int(msd_min_rows), (C.c_int * max(1, len(bits)))(*bits) if bits else None, len(bits))
+
+
+def sort_counters(ctx):
+    """(sorts whose round 0 ran as the MSD partition, sorts that took the LSD passes) since the context was created."""
+    a, b = C.c_uint64(), C.c_uint64()
+    call('uq_sort_counters', ctx.h, C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
 def argsort_rows(ctx, table, rows, cols):
     t = ctx.torch
     perm = t.empty(rows, dtype=t.int32, device=ctx.device)
