@@ -228,7 +228,7 @@ MSD_CASES = [
     (600_000, 113, 'qual', None), (600_000, 113, 'qual', [8, 5]), (524_288, 8, 'random', None), (400_000, 4, 'random', None),
     (400_000, 6, 'dups', None), (300_000, 38, 'lead', None), (700_000, 38, 'collide32', None), (700_000, 16, 'dups', [6, 6]),
     (300_000, 38, 'random', [10, 2]), (300_000, 38, 'random', [3, 3, 3, 3]), (2_100_000, 38, 'dups', None), (300_000, 38, 'heavy', None),
-    (300_000, 12, 'steps', None),
+    (300_000, 12, 'steps', None), (1_300_000, 16, 'dups', None), (1_100_000, 113, 'qual', None), (1_048_576, 9, 'heavy', None),
 ]
 
 

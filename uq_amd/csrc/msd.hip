@@ -249,23 +249,60 @@ __global__ __launch_bounds__(MT) void msd_chunk_bounds_kernel(const uint32_t* __
     bound[c] = lo < nb ? bucket_end[lo] : n;
 }
 
-// A chunk in its final order: perm[j] = row number, heads[j] = 1 when the key at j differs from the key at j - 1 (or j = 0), else 0.
-template <typename K>
+// memcmp order of two rows of C bytes, taken by a sub-wave of eight lanes (t = lane & 7, sub = lane & 56): every lane fetches sixteen bytes of
+// each row -- a row of 113 bytes is one request of eight neighbouring lanes instead of fifteen dependent 8-byte loads of one --, the lowest
+// lane whose piece differs decides.  The piece that would hang over the row's end is the sixteen bytes that END the row (the overlap is
+// compared twice: if it differs, so does the piece in front, which wins).  Returns the same value (< 0, 0, > 0) in all eight lanes; the
+// eight lanes must be in the same control flow.
+__device__ __forceinline__ int msd_row_cmp8(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, uint32_t C, uint32_t t, uint32_t sub) {
+    for (uint32_t base = 0; base < C; base += 128) {
+        const uint32_t off = base + 16 * t;
+        int c = 0;
+        if (C >= 16) {
+            if (off < C) {
+                const uint32_t o = off + 16 <= C ? off : C - 16;
+                uint64_t x0, x1, y0, y1;
+                __builtin_memcpy(&x0, a + o, 8); __builtin_memcpy(&x1, a + o + 8, 8);
+                __builtin_memcpy(&y0, b + o, 8); __builtin_memcpy(&y1, b + o + 8, 8);
+                if (x0 != y0) c = __builtin_bswap64(x0) < __builtin_bswap64(y0) ? -1 : 1;
+                else if (x1 != y1) c = __builtin_bswap64(x1) < __builtin_bswap64(y1) ? -1 : 1;
+            }
+        } else if (t == 0) {
+            for (uint32_t i = 0; i < C && c == 0; ++i) c = a[i] == b[i] ? 0 : (a[i] < b[i] ? -1 : 1);
+        }
+        const uint32_t mine = (uint32_t)(__ballot(c != 0) >> sub) & 0xFFu;
+        if (mine) return __shfl(c, (int)(sub + (uint32_t)__ffs((int)mine) - 1u), 64);
+    }
+    return 0;
+}
+
+constexpr uint32_t MSD_IDX = 0x3FFFFFFFu;        // a row number (n < 2^30) under the two flag bits of an entry of the sorted chunk
+constexpr uint32_t MSD_SEG_MAX = 32;             // tie groups of more rows are left open (flag 0) for the caller's refinement rounds
+
+// A chunk in its final order by (key, row number): perm[j] = row number, heads[j] = 1 when the key at j differs from the key at j - 1 (or
+// j = 0); else 2 (not ROWS: the key is the whole row, an equal key is a duplicate, final) or 0 (ROWS: the rows go on behind the key -- the
+// positions where such a tie group starts are appended to tie_list for msd_ties_kernel).
+template <typename K, bool ROWS>
 __global__ __launch_bounds__(MT) void msd_finish_kernel(const K* __restrict__ keys, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ bound,
-                                                        uint32_t nchunks, uint32_t* __restrict__ perm, uint8_t* __restrict__ heads, uint32_t* __restrict__ overflow) {
+                                                        uint32_t nchunks, uint32_t* __restrict__ perm, uint8_t* __restrict__ heads,
+                                                        uint32_t* __restrict__ flags_out /* [0] overflow */, uint32_t* __restrict__ tie_list,
+                                                        uint32_t* __restrict__ tie_count) {
     constexpr int FI = MSD_CAP / MT;
     constexpr int BI = MSD_NB / MT;
     __shared__ K s_k[MSD_CAP];
-    __shared__ uint32_t s_i[MSD_CAP];
-    __shared__ uint32_t s_bin[MSD_NB + 1];
+    __shared__ uint32_t s_i[MSD_CAP];             // row numbers by bin, then the sorted chunk: row number | flag << 30
+    __shared__ uint32_t s_bin[MSD_NB + 1];        // bins, then the list of the chunk's tie groups (their first positions)
     __shared__ K s_mn[MT / 64], s_mx[MT / 64];
     __shared__ uint32_t s_scan[MT / 64 + 1];
+    __shared__ uint32_t s_nlead;
     const uint32_t tid = threadIdx.x;
     for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
         const uint32_t lo = bound[c], hi = bound[c + 1];
         const uint32_t m = hi - lo;
-        if (hi <= lo) continue;
-        if (m > MSD_CAP) { if (tid == 0) *overflow = 1u; continue; }
+        if (hi <= lo || m > MSD_CAP) {
+            if (tid == 0) { if (m > MSD_CAP && hi > lo) flags_out[0] = 1u; if (ROWS) tie_count[c] = 0; }
+            continue;
+        }
         K k[FI];
         uint32_t v[FI], r[FI];
         K mn = ~(K)0, mx = 0;
@@ -280,6 +317,7 @@ __global__ __launch_bounds__(MT) void msd_finish_kernel(const K* __restrict__ ke
 #pragma unroll
         for (int j = 0; j < BI; ++j) s_bin[j * MT + tid] = 0;
         if ((tid & 63) == 0) { s_mn[tid >> 6] = mn; s_mx[tid >> 6] = mx; }
+        if (tid == 0) s_nlead = 0;
         __syncthreads();
 #pragma unroll
         for (int w = 0; w < MT / 64; ++w) { mn = msd_min(mn, s_mn[w]); mx = msd_max(mx, s_mx[w]); }
@@ -310,9 +348,12 @@ __global__ __launch_bounds__(MT) void msd_finish_kernel(const K* __restrict__ ke
             }
         }
         __syncthreads();
+        // the place of the pair at slot q among the pairs of its bin, by (key, row number); its flag from the largest key below it
+        uint32_t place[FI], entry[FI];
 #pragma unroll
         for (int i = 0; i < FI; ++i) {
             const uint32_t q = i * MT + tid;
+            place[i] = 0xFFFFFFFFu; entry[i] = 0;
             if (q < m) {
                 const K kk = s_k[q];
                 const uint32_t ii = s_i[q];
@@ -321,7 +362,11 @@ __global__ __launch_bounds__(MT) void msd_finish_kernel(const K* __restrict__ ke
                 uint32_t below = 0;
                 bool has = false;
                 K pk = 0;
+#if defined(MSD_ABL) && MSD_ABL >= 2
+                if (false) {
+#else
                 if (bhi - blo > 1) {
+#endif
                     for (uint32_t j = blo; j < bhi; ++j) {
                         const K kj = s_k[j];
                         const uint32_t ij = s_i[j];
@@ -329,12 +374,148 @@ __global__ __launch_bounds__(MT) void msd_finish_kernel(const K* __restrict__ ke
                         if (less) { ++below; pk = has ? msd_max(pk, kj) : kj; has = true; }
                     }
                 }
-                const uint32_t pos = lo + blo + below;
-                perm[pos] = ii;
-                heads[pos] = (!has || pk != kk) ? (uint8_t)1 : (uint8_t)0;
+                place[i] = blo + below;
+#if defined(MSD_ABL) && MSD_ABL >= 2
+                place[i] = q;
+#endif
+                const uint32_t flag = (!has || pk != kk) ? 1u : (ROWS ? 0u : 2u);
+                entry[i] = ii | (flag << 30);
             }
         }
         __syncthreads();
+#pragma unroll
+        for (int i = 0; i < FI; ++i)
+            if (place[i] != 0xFFFFFFFFu) s_i[place[i]] = entry[i];
+        __syncthreads();
+        if (ROWS) {
+            // the chunk's tie groups (an entry that is a head in front of one that is open) go on the table's list: msd_ties_kernel sorts them
+            // by whole rows with every lane of the device on row fetches (inside this kernel, between its barriers, they cost twice the rest)
+            uint32_t* s_lead = s_bin;
+#pragma unroll
+            for (int i = 0; i < FI; ++i) {
+                const uint32_t q = i * MT + tid;
+                if (q + 1 < m && (s_i[q] >> 30) == 1u && (s_i[q + 1] >> 30) == 0u) s_lead[atomicAdd(&s_nlead, 1u)] = lo + q;
+            }
+            __syncthreads();
+            const uint32_t nlead = s_nlead;                       // (at most m / 2 <= 1024: the chunk's own slots of the list)
+            for (uint32_t g = tid; g < nlead; g += MT) tie_list[(uint64_t)c * (MSD_CAP / 2) + g] = s_lead[g];
+            if (tid == 0) tie_count[c] = nlead;
+        }
+#pragma unroll
+        for (int i = 0; i < FI; ++i) {
+            const uint32_t q = i * MT + tid;
+            if (q < m) { const uint32_t e = s_i[q]; perm[lo + q] = e & MSD_IDX; heads[lo + q] = (uint8_t)(e >> 30); }
+        }
+        __syncthreads();
+    }
+}
+
+// The groups that tie on the key, by whole rows: nearly all are SHORT (duplicated reads, chance collisions of a 32-bit prefix).  A sub-wave of
+// eight lanes per group (msd_row_cmp8), two groups at a time: stable insertion sort of the group's slice of perm -- a row moves only past
+// strictly greater ones and the slice starts in row order --, then heads[j] = 1 (a new row value) or 2 (equal to the row in front, final).
+// Groups of more than 32 rows keep their 0 flags for the caller's refinement rounds (*leftover is raised).  A group's first position keeps
+// its flag 1 throughout: the sub-wave of the group in front may be looking for its end.
+__global__ __launch_bounds__(MT) void msd_ties_kernel(const uint8_t* __restrict__ table, uint32_t C, uint32_t n, uint32_t* __restrict__ perm,
+                                                      uint8_t* __restrict__ heads, const uint32_t* __restrict__ tie_list,
+                                                      const uint32_t* __restrict__ tie_count, uint32_t nchunks, uint32_t* __restrict__ leftover) {
+    const uint32_t lane = threadIdx.x & 63u, t = lane & 7u, sub = lane & 56u;
+    constexpr int U = 2;
+    // a workgroup per chunk's list (finish left them per chunk: no counter that every workgroup of the device would queue on)
+    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    const uint32_t ngroups = tie_count[c];
+    const uint32_t* __restrict__ list = tie_list + (uint64_t)c * (MSD_CAP / 2);
+    for (uint32_t g0 = (threadIdx.x >> 3) * U; g0 < ngroups; g0 += (MT / 8) * U) {
+        uint32_t jj[U], kk[U], xa[U], xb[U];
+        uint64_t a0[U], a1[U], b0[U], b1[U];
+        const uint32_t off = 16 * t;
+        const bool piece = C >= 16 && off < C;
+        const uint32_t o = piece ? (off + 16 <= C ? off : C - 16) : 0u;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t g = g0 + u;
+            jj[u] = 0; kk[u] = 0; xa[u] = xb[u] = 0; a0[u] = a1[u] = b0[u] = b1[u] = 0;
+            if (g < ngroups) {
+                const uint32_t j = list[g];
+                jj[u] = j;
+                // the group's length: lane t looks at position j + 1 + t; the first position that is not open ends the group
+                uint32_t len = 1;
+                for (uint32_t basep = j + 1; ; basep += 8) {
+                    const uint32_t pos = basep + t;
+                    const bool open = pos < n && heads[pos] == 0;
+                    const uint32_t closed = (uint32_t)(__ballot(!open) >> sub) & 0xFFu;
+                    if (closed) { len += (uint32_t)__ffs((int)closed) - 1u; break; }
+                    len += 8;
+                    if (len > MSD_SEG_MAX) break;
+                }
+                kk[u] = len;
+                if (len == 2) {
+                    xa[u] = perm[j]; xb[u] = perm[j + 1];
+                    if (piece) {
+                        const uint8_t* ra = table + (uint64_t)xa[u] * C + o;
+                        const uint8_t* rb = table + (uint64_t)xb[u] * C + o;
+                        __builtin_memcpy(&a0[u], ra, 8); __builtin_memcpy(&a1[u], ra + 8, 8);
+                        __builtin_memcpy(&b0[u], rb, 8); __builtin_memcpy(&b1[u], rb + 8, 8);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t j = jj[u], len = kk[u];
+            if (len < 2) continue;
+            if (len > MSD_SEG_MAX) { if (t == 0) *leftover = 1u; continue; }
+            if (len == 2) {                                   // nearly every group: one comparison settles the order and the flag
+                int cm;                                       // memcmp(row xb, row xa)
+                if (C >= 16 && C <= 128) {
+                    int c = 0;
+                    if (b0[u] != a0[u]) c = __builtin_bswap64(b0[u]) < __builtin_bswap64(a0[u]) ? -1 : 1;
+                    else if (b1[u] != a1[u]) c = __builtin_bswap64(b1[u]) < __builtin_bswap64(a1[u]) ? -1 : 1;
+                    const uint32_t mine = (uint32_t)(__ballot(c != 0) >> sub) & 0xFFu;
+                    cm = mine ? __shfl(c, (int)(sub + (uint32_t)__ffs((int)mine) - 1u), 64) : 0;
+                } else cm = msd_row_cmp8(table + (uint64_t)xb[u] * C, table + (uint64_t)xa[u] * C, C, t, sub);
+                if (t == 0) {
+                    if (cm < 0) { perm[j] = xb[u]; perm[j + 1] = xa[u]; }
+                    heads[j + 1] = cm == 0 ? (uint8_t)2 : (uint8_t)1;
+                }
+                continue;
+            }
+            // a longer group: its row numbers in the sub-wave's registers (lane t holds entries t, t + 8, t + 16, t + 24)
+            uint32_t e[4];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) e[w] = (t + 8 * w) < len ? perm[j + t + 8 * w] : 0u;
+            auto entry = [&](uint32_t i) -> uint32_t {      // entry i of the group, the same value in all eight lanes
+                const uint32_t w = i >> 3;
+                const uint32_t v = w == 0 ? e[0] : w == 1 ? e[1] : w == 2 ? e[2] : e[3];
+                return __shfl(v, (int)(sub + (i & 7u)), 64);
+            };
+            auto put = [&](uint32_t i, uint32_t x) {
+                if (t == (i & 7u)) { const uint32_t w = i >> 3; if (w == 0) e[0] = x; else if (w == 1) e[1] = x; else if (w == 2) e[2] = x; else e[3] = x; }
+            };
+            for (uint32_t i = 1; i < len; ++i) {
+                const uint32_t x = entry(i);
+                uint32_t tt = i;
+                while (tt > 0) {
+                    const uint32_t y = entry(tt - 1);
+                    if (msd_row_cmp8(table + (uint64_t)x * C, table + (uint64_t)y * C, C, t, sub) >= 0) break;
+                    put(tt, y);
+                    --tt;
+                }
+                put(tt, x);
+            }
+            uint32_t prev = entry(0);
+            uint32_t dupmask = 0;                             // bit i: entry i equals entry i - 1
+            for (uint32_t i = 1; i < len; ++i) {
+                const uint32_t x = entry(i);
+                if (msd_row_cmp8(table + (uint64_t)x * C, table + (uint64_t)prev * C, C, t, sub) == 0) dupmask |= 1u << i;
+                prev = x;
+            }
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const uint32_t i = t + 8 * w;
+                if (i < len) { perm[j + i] = e[w]; if (i > 0) heads[j + i] = ((dupmask >> i) & 1u) ? (uint8_t)2 : (uint8_t)1; }
+            }
+        }
+    }
     }
 }
 
@@ -368,13 +549,14 @@ size_t msd_ws_bytes(uint64_t n) {
     while (nb < nbmax && nb * 32 < n) nb <<= 1;
     nb <<= 1;                                            // (a plan from the environment may ask for more buckets than the default)
     if (nb > nbmax) nb = nbmax;
-    return (size_t)(nb * 2 + 4096) * 4 * 2 + (size_t)(n / MSD_G + 16) * 4 + 4096;
+    return (size_t)(nb * 2 + 4096) * 4 * 2 + (size_t)(n / MSD_G + 16) * 4 * 2 + 4096;
 }
 
 template <typename K>
 static int msd_round0_impl(uq_ctx* ctx, const uint8_t* table, uint32_t C, uint64_t n, uint32_t z, void* keysA, void* keysB, uint32_t* idxA, uint32_t* idxB,
-                           uint32_t* perm, uint8_t* heads, void* ws, size_t ws_bytes, int* status, uint64_t* h_andor) {
+                           uint32_t* perm, uint8_t* heads, void* ws, size_t ws_bytes, int* status, uint64_t* h_andor, bool* settled) {
     *status = 1;
+    *settled = false;
     int bits[MSD_MAXLEVELS];
     const int keybits = 8 * (int)sizeof(K);
     const int L = msd_plan(ctx, n, keybits, bits);
@@ -385,17 +567,18 @@ static int msd_round0_impl(uq_ctx* ctx, const uint8_t* table, uint32_t C, uint64
     size_t need = 4096;
     { uint64_t b = 1; for (int l = 0; l < L; ++l) { b <<= bits[l]; nb[l] = b; need += (size_t)(b + 64) * 4 + (size_t)(b + 64 + 1) * 4; } }
     const uint32_t nchunks = (uint32_t)((n + MSD_G - 1) / MSD_G);
-    need += (size_t)(nchunks + 16) * 4;
+    need += (size_t)(nchunks + 16) * 4 * 2;
     if (need > ws_bytes) return 0;
     uint8_t* w = (uint8_t*)ws;
     unsigned long long* andor = (unsigned long long*)w;            // [0] AND  [1] OR
-    uint32_t* misc = (uint32_t*)(w + 16);                          // [0] largest bucket of the last level  [1] a chunk beyond the LDS (cannot happen)
+    uint32_t* misc = (uint32_t*)(w + 16);                          // [0] largest bucket of the last level  [1] a chunk beyond the LDS (cannot happen)  [2] a tie group left open  [3] tie groups listed
     size_t off = 4096;
     uint32_t* hist[MSD_MAXLEVELS];
     uint32_t* tilep[MSD_MAXLEVELS];
     for (int l = 0; l < L; ++l) { hist[l] = (uint32_t*)(w + off); off += (size_t)(nb[l] + 64) * 4; }
     for (int l = 1; l < L; ++l) { tilep[l] = (uint32_t*)(w + off); off += (size_t)(nb[l - 1] + 64 + 1) * 4; }
     uint32_t* bound = (uint32_t*)(w + off);
+    uint32_t* tie_cnt = bound + nchunks + 8;
     UQ_CHECK_HIP(hipMemsetAsync(w, 0, 4096, s));
     UQ_CHECK_HIP(hipMemsetAsync(andor, 0xFF, 8, s));
     for (int l = 0; l < L; ++l) UQ_CHECK_HIP(hipMemsetAsync(hist[l], 0, nb[l] * 4, s));
@@ -441,14 +624,26 @@ static int msd_round0_impl(uq_ctx* ctx, const uint8_t* table, uint32_t C, uint64
     }
     msd_chunk_bounds_kernel<<<(nchunks + 1 + MT - 1) / MT, MT, 0, s>>>(hist[L - 1], nb[L - 1], (uint32_t)n, nchunks, bound);
     UQ_LAUNCH_CHECK();
-    msd_finish_kernel<K><<<nchunks < UQ_NUM_CU * 8 ? nchunks : UQ_NUM_CU * 8, MT, 0, s>>>(kin, vin, bound, nchunks, perm, heads, misc + 1);
+    const bool rows = C > 8;                                                 // the rows go on behind the head (32-bit keys are for such tables only)
+    const uint32_t fgrid = nchunks < UQ_NUM_CU * 16 ? nchunks : UQ_NUM_CU * 16;
+    uint32_t* tie_list = vout;                                               // (the ping-pong buffer the last scatter read from: n / 2 groups at most)
+    if (rows) {
+        msd_finish_kernel<K, true><<<fgrid, MT, 0, s>>>(kin, vin, bound, nchunks, perm, heads, misc + 1, tie_list, tie_cnt);
+        UQ_LAUNCH_CHECK();
+        msd_ties_kernel<<<nchunks < UQ_NUM_CU * 8 ? nchunks : UQ_NUM_CU * 8, MT, 0, s>>>(table, C, (uint32_t)n, perm, heads, tie_list, tie_cnt, nchunks, misc + 2);
+    } else msd_finish_kernel<K, false><<<fgrid, MT, 0, s>>>(kin, vin, bound, nchunks, perm, heads, misc + 1, nullptr, nullptr);
     UQ_LAUNCH_CHECK();
+    UQ_TRY(uq_read_back(ctx, ctx->h_pinned, misc, 16));
+    UQ_CHECK_HIP(hipStreamSynchronize(s));
+    const uint32_t* hm = (const uint32_t*)ctx->h_pinned;
+    UQ_REQUIRE(hm[1] == 0, "row sort: a chunk beyond the finishing workgroup's LDS (the bucket bound was checked: a defect)");
+    *settled = hm[2] == 0;
     *status = 0;
     return 0;
 }
 
 int msd_round0(uq_ctx* ctx, const uint8_t* table, uint32_t C, uint64_t n, uint32_t z, int key64, void* keysA, void* keysB, uint32_t* idxA, uint32_t* idxB,
-               uint32_t* perm, uint8_t* heads, void* ws, size_t ws_bytes, int* status, uint64_t* h_andor) {
-    if (key64) return msd_round0_impl<uint64_t>(ctx, table, C, n, z, keysA, keysB, idxA, idxB, perm, heads, ws, ws_bytes, status, h_andor);
-    return msd_round0_impl<uint32_t>(ctx, table, C, n, z, keysA, keysB, idxA, idxB, perm, heads, ws, ws_bytes, status, h_andor);
+               uint32_t* perm, uint8_t* heads, void* ws, size_t ws_bytes, int* status, uint64_t* h_andor, bool* settled) {
+    if (key64) return msd_round0_impl<uint64_t>(ctx, table, C, n, z, keysA, keysB, idxA, idxB, perm, heads, ws, ws_bytes, status, h_andor, settled);
+    return msd_round0_impl<uint32_t>(ctx, table, C, n, z, keysA, keysB, idxA, idxB, perm, heads, ws, ws_bytes, status, h_andor, settled);
 }

@@ -29,7 +29,10 @@ int radix_rows_prefix_census32(uq_ctx* ctx, const uint8_t* table, uint32_t C, ui
 // order, heads[j] = 1 when the key at position j differs from the one in front of it, else 0.  keysA / keysB: n * 8 bytes each, idxA / idxB:
 // n * 4 bytes each, ws: msd_ws_bytes(n).  *status: 0 = done; 1 = not for this table (buckets heavier than a workgroup's LDS: few distinct
 // heads) -- nothing usable was written, the caller takes the LSD passes; 2 = the table's rows share fewer than z leading bits
-// (h_andor = AND / OR over all heads says how many): call again with that z.  One host wait inside.
+// (h_andor = AND / OR over all heads says how many): call again with that z.
+// Rows wider than the key: the groups that tie on the key are sorted by whole rows inside the finishing kernel (up to 32 rows a group) and
+// heads[j] is 1 = a new row value / 2 = equal to the row in front, final / 0 = ties with it on the key, left open (*settled = false: the
+// caller's refinement rounds take over).  Two host waits inside (the bucket bound; the open-group flag).
 size_t msd_ws_bytes(uint64_t n);
 int msd_round0(uq_ctx* ctx, const uint8_t* table, uint32_t C, uint64_t n, uint32_t z, int key64, void* keysA, void* keysB, uint32_t* idxA, uint32_t* idxB,
-               uint32_t* perm, uint8_t* heads, void* ws, size_t ws_bytes, int* status, uint64_t* h_andor);
+               uint32_t* perm, uint8_t* heads, void* ws, size_t ws_bytes, int* status, uint64_t* h_andor, bool* settled);

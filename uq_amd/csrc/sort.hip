@@ -341,7 +341,7 @@ int sort_rows_core(uq_ctx* ctx, const uint8_t* table, uint64_t n, uint32_t C, ui
         return 0;
     };
     const uint64_t msd_min = ctx->msd_min_rows > 0 ? (uint64_t)ctx->msd_min_rows : (uint64_t(1) << 18);
-    bool sampled = false, msd_ok = ctx->msd_min_rows >= 0 && n >= msd_min && n >= 2 && n < (uint64_t(1) << 31);
+    bool sampled = false, msd_ok = ctx->msd_min_rows >= 0 && n >= msd_min && n >= 2 && n < (uint64_t(1) << 30);
     if (mode32 || msd_ok) {
         const uint64_t samples = 4096;                                           // (spread over the table; fewer rows than that: some twice)
         sample_chunks_kernel<<<(uint32_t)((samples + ST - 1) / ST), ST, 0, s>>>(table, n, C, samples, (uint64_t*)ctx->d_pinned);
@@ -382,22 +382,17 @@ int sort_rows_core(uq_ctx* ctx, const uint8_t* table, uint64_t n, uint32_t C, ui
     if (msd_ok) {
         // MSD partition + LDS finish (msd.hip): keys of 32 bits where the LSD round 0 would take them (mode32), else the whole head
         int status = 1;
+        bool settled = false;
         for (int attempt = 0; attempt < 3; ++attempt) {
             uint64_t h_andor[2];
-            UQ_TRY(msd_round0(ctx, table, C, n, z, mode32 ? 0 : 1, keysA, keysB, valsA, valsB, d_perm, heads, b + o_msd, msd_ws_bytes(n), &status, h_andor));
+            UQ_TRY(msd_round0(ctx, table, C, n, z, mode32 ? 0 : 1, keysA, keysB, valsA, valsB, d_perm, heads, b + o_msd, msd_ws_bytes(n), &status, h_andor, &settled));
             if (status != 2) break;
             z = leading_same(h_andor[0], h_andor[1]);
         }
         if (status == 0) {
             round0_done = true;
             ++ctx->n_msd_rounds;
-            if (C <= 8) return 0;                                                // the head IS the row: ties are duplicates, flags 1 / 0 as heads_first_kernel leaves them
-            UQ_CHECK_HIP(hipMemcpyAsync(flags, heads, n, hipMemcpyDeviceToDevice, s));
-            active_count_kernel<<<(uint32_t)ncb0, ST, 0, s>>>(heads, n, bcnt0);
-            UQ_LAUNCH_CHECK();
-            bool settled;
-            UQ_TRY(settle_short_groups(&settled));
-            if (settled) return 0;
+            if (settled) return 0;                                               // every tie group was short: the order and the flags are final
         } else if (status == 2) mode32 = false;                                  // (a table that keeps contradicting its sample: the plain 64-bit passes)
     }
     if (!round0_done) ++ctx->n_lsd_rounds;
