@@ -456,22 +456,23 @@ def sort_legs(ctx, args, rank, world, use_dist, fence, fetch, red_dev):
     Cd3, Cq3 = d3['dna_bytes_per_row'], d3['quality_bytes_per_row']
     starts = [uqdist.shard_range(total, r, world)[0] for r in range(world)] + [total]
     t = torch
+    per_rank = [starts[r + 1] - starts[r] for r in range(world)]
 
     def sort_qual_raw():
-        gs = uqdist.global_sort_rows(be, qual3, ns, Cq3, lo, total_rows=total)
+        gs = uqdist.global_sort_rows(be, qual3, ns, Cq3, lo, total_rows=total, rows_of_ranks=per_rank)
         dg = uqdist.dist_gather_rows(be, dna3, ns, Cd3, starts, gs['gidx'])
         return gs['rows'], (gs, dg)
 
     def group_ids(gs, cols):
         m = gs['rows']
         if not m: return t.empty(0, dtype=t.int32, device=ctx.device)
-        skey, uniq, nu = ops.unique_sorted_rows(ctx, gs['table'], m, cols)
-        return skey                                          # (the per-rank id offsets are a handful of integers: dist_encode._unique)
+        uniq = be.unique_rows_of_groups(gs['table'], m, cols, gs['group'], gs['ngroups'])      # the unique table is a member of the container
+        return gs['group']                                   # (the per-rank id offsets are a handful of integers: dist_encode._unique)
 
     def sort_dna_keyed():
-        gd = uqdist.global_sort_rows(be, dna3, ns, Cd3, lo, total_rows=total)
+        gd = uqdist.global_sort_rows(be, dna3, ns, Cd3, lo, total_rows=total, rows_of_ranks=per_rank)
         kd = group_ids(gd, Cd3)
-        gq = uqdist.global_sort_rows(be, qual3, ns, Cq3, lo, total_rows=total)
+        gq = uqdist.global_sort_rows(be, qual3, ns, Cq3, lo, total_rows=total, rows_of_ranks=per_rank)
         kq = group_ids(gq, Cq3)
         in_file_order = uqdist.dist_scatter_rows(be, kq.view(t.uint8), 4, starts, gq['gidx'])
         kq_sorted = uqdist.dist_gather_rows(be, in_file_order, ns, 4, starts, gd['gidx'])

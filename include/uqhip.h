@@ -312,6 +312,14 @@ int uq_encode_int(uq_ctx* ctx, const int64_t* d_val, uint64_t n, int64_t sub, in
  * of neighbouring rows.  d_group[j] = dense rank of row j's value (from 0), d_unique (may be NULL) = the distinct rows in order. */
 int uq_unique_sorted_rows(uq_ctx* ctx, const uint8_t* d_sorted_table, uint64_t rows, uint32_t cols, uint32_t* d_group, uint8_t* d_unique,
                           uint64_t* h_nunique);
+/* The distinct rows of a table in memcmp order from the group ids its sort left (uq_unique_rows' d_sorted_key): d_unique[g] = the first
+ * row of group g, g < nunique.  Replaces the table half of numpy.unique (uq.py:786) where the rows have been moved into sorted order. */
+int uq_unique_rows_of_groups(uq_ctx* ctx, const uint8_t* d_sorted_table, uint64_t rows, uint32_t cols, const uint32_t* d_group,
+                             uint64_t nunique, uint8_t* d_unique);
+/* d_order = the positions 0 .. n - 1 grouped by d_dest[position] (ndest <= 16 destinations, ascending), each group in ascending order
+ * (a stable partition); d_counts[k] (DEVICE, uint64) = size of group k.  What goes in front of an all-to-all: rows by destination rank,
+ * requests by owner rank.  *h_bad (may be NULL: then nothing waits for the device) = UQ_NONE or a position whose destination is >= ndest. */
+int uq_partition_order(uq_ctx* ctx, const uint8_t* d_dest, uint64_t n, uint32_t ndest, uint32_t* d_order, uint64_t* d_counts, uint64_t* h_bad);
 int uq_partition_rows(uq_ctx* ctx, const uint8_t* d_splitters, uint32_t nsplit, uint32_t cols, const uint8_t* d_table, uint64_t rows,
                       uint64_t row_index_base, uint64_t total_rows, uint8_t* d_dest);
 int uq_owner_of_rows(uq_ctx* ctx, const int64_t* d_row_index, uint64_t n, const int64_t* h_shard_starts, uint32_t world, uint8_t* d_owner);

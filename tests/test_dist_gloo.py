@@ -24,6 +24,24 @@ class NumpyRows:
         t = table.numpy().reshape(rows, cols)
         return torch.from_numpy(np.lexsort([t[:, c] for c in range(cols - 1, -1, -1)]).astype(np.int32))
 
+    def argsort_groups(self, table, rows, cols):
+        perm = self.argsort_rows(table, rows, cols)
+        t = table.numpy().reshape(rows, cols)[perm.numpy().astype(np.int64)]
+        head = np.ones(rows, dtype=bool); head[1:] = (t[1:] != t[:-1]).any(axis=1)
+        return perm, torch.from_numpy((np.cumsum(head) - 1).astype(np.int32)), int(head.sum())
+
+    def unique_rows_of_groups(self, sorted_table, rows, cols, group, nunique):
+        t = sorted_table.numpy().reshape(rows, cols)
+        g = group.numpy().astype(np.int64)
+        first = np.ones(rows, dtype=bool); first[1:] = g[1:] != g[:-1]
+        assert int(first.sum()) == nunique
+        return torch.from_numpy(np.ascontiguousarray(t[first]).reshape(-1))
+
+    def partition_order(self, dest, n, ndest):
+        d = dest.numpy()[:n]
+        assert d.max(initial=0) < ndest
+        return torch.from_numpy(np.argsort(d, kind='stable').astype(np.int32)), torch.from_numpy(np.bincount(d, minlength=ndest).astype(np.int64))
+
     def gather_rows(self, table, rows, cols, index):
         t = table.numpy().reshape(rows, cols)
         idx = index.numpy().astype(np.int64) & 0xFFFFFFFF if index.dtype == torch.int32 else index.numpy().astype(np.int64)

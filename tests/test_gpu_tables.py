@@ -392,6 +392,37 @@ def test_lower_bound_rows_and_single_rank_global_sort(ctx):
     assert np.array_equal(ctx.to_numpy(back).reshape(n, C), T)
 
 
+@pytest.mark.parametrize('n,ndest', [(1, 1), (5, 3), (4096, 8), (4097, 8), (100_003, 2), (70_000, 16), (300_000, 5), (12_289, 1)])
+def test_partition_order(ctx, n, ndest):
+    """uq_partition_order (what goes in front of every all-to-all of uq_amd.dist): the stable partition of positions by a one-byte
+    destination == numpy's stable argsort of the bytes, counts == bincount; skewed and missing destinations."""
+    rng = np.random.RandomState(n + ndest)
+    for kind in ('uniform', 'skewed', 'one'):
+        if kind == 'uniform': d = rng.randint(0, ndest, size=n)
+        elif kind == 'skewed': d = np.minimum(rng.geometric(0.6, size=n) - 1, ndest - 1)
+        else: d = np.full(n, ndest - 1)
+        d = d.astype(np.uint8)
+        order, counts = ops.partition_order(ctx, _dev(ctx, d), n, ndest)
+        assert np.array_equal(ctx.to_numpy(order, np.uint32).astype(np.int64), np.argsort(d, kind='stable'))
+        assert np.array_equal(ctx.to_numpy(counts.view(ctx.torch.uint8), np.int64), np.bincount(d, minlength=ndest))
+    from uq_amd._lib import UqHipError
+    with pytest.raises(UqHipError):
+        ops.partition_order(ctx, _dev(ctx, np.zeros(4, dtype=np.uint8)), 4, 17)
+
+
+@pytest.mark.parametrize('n,C,nd,prefix', SORT_CASES, ids=lambda v: str(v))
+def test_unique_rows_of_groups(ctx, n, C, nd, prefix):
+    """The distinct rows of a sorted table from the group ids its sort left (uq_unique_rows_of_groups) == numpy.unique's table."""
+    rng = np.random.RandomState(n * 11 + C)
+    T = _rows_with_dups(rng, n, C, nd, prefix)
+    d_T = _dev(ctx, T.ravel())
+    perm, _, skey, _, nu = ops.unique_rows(ctx, d_T, n, C, want_key=False, want_unique=False)
+    S = ops.gather_rows(ctx, d_T, n, C, perm)
+    uniq = ops.unique_rows_of_groups(ctx, S, n, C, skey, nu)
+    ru, _ = O.unique_rows(T)
+    assert nu == len(ru) and np.array_equal(ctx.to_numpy(uniq).reshape(nu, C), ru)
+
+
 @pytest.mark.parametrize('C', [1, 3, 4, 7, 8, 13, 16, 38, 64, 113, 200])
 @pytest.mark.parametrize('itemsize', [4, 8])
 def test_scatter_rows(ctx, C, itemsize):

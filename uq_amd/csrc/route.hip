@@ -8,6 +8,7 @@
 //   uq_index_affine        out[j] = in[j] + add, between 32- and 64-bit index arrays (local order <-> file-wide row numbers)
 //   uq_invert_permutation  inv[perm[j] - base] = j
 //   uq_scatter_rows        out[index[j] - base] = values[j]: rows to their places in ONE random pass (instead of inverse + gather)
+//   uq_partition_order     the stable partition of a shard's positions by destination rank (what goes in front of an all-to-all)
 #include "common.h"
 
 namespace {
@@ -106,8 +107,98 @@ __global__ __launch_bounds__(RT) void scatter_rows_kernel(const uint8_t* __restr
     }
 }
 
+// ---- stable partition of positions 0 .. n - 1 by a one-byte destination (at most 16 destinations: the ranks of a node): order = the
+// positions grouped by destination, each group in ascending order; counts[d] = size of group d.  What the exchanges need in front of
+// an all-to-all (rows by destination rank, requests by owner rank) without a sort: one histogram pass over the bytes, the scan of the
+// per-tile counts, one ranking pass -- a position's rank among its tile's positions of the same destination comes from one ballot per
+// destination and popcounts (wave64), the waves' counts through LDS.
+constexpr int PT = 4096, PI = PT / RT;              // positions per tile, per lane (position of item i of lane l of wave w: i * 256 + w * 64 + l)
+constexpr uint32_t PMAXD = 16;
+__global__ __launch_bounds__(RT) void partition_count_kernel(const uint8_t* __restrict__ dest, uint64_t n, uint32_t ndest, uint32_t ntiles,
+                                                             uint32_t* __restrict__ tile_counts, unsigned long long* __restrict__ bad) {
+    __shared__ uint32_t h[PMAXD];
+    if (threadIdx.x < PMAXD) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * PT;
+#pragma unroll
+    for (int i = 0; i < PI; ++i) {
+        const uint64_t p = base + (uint64_t)i * RT + threadIdx.x;
+        if (p < n) { const uint32_t d = dest[p]; if (d < ndest) atomicAdd(&h[d], 1u); else atomicMin(bad, (unsigned long long)p); }
+    }
+    __syncthreads();
+    if (threadIdx.x < ndest) tile_counts[(uint64_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
+}
+__global__ __launch_bounds__(RT) void partition_rank_kernel(const uint8_t* __restrict__ dest, uint64_t n, uint32_t ndest, uint32_t ntiles,
+                                                            const uint32_t* __restrict__ tile_offsets, uint32_t* __restrict__ order) {
+    __shared__ uint32_t s_cnt[PI * (RT / 64) * PMAXD];          // [item][wave][destination]: count, then the exclusive prefix in position order
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    const uint64_t base = (uint64_t)blockIdx.x * PT;
+    const uint64_t lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+    uint32_t d[PI], below[PI];
+#pragma unroll
+    for (int i = 0; i < PI; ++i) {
+        const uint64_t p = base + (uint64_t)i * RT + tid;
+        d[i] = p < n ? dest[p] : 0xFFFFFFFFu;
+        below[i] = 0;
+        for (uint32_t k = 0; k < ndest; ++k) {
+            const uint64_t b = __ballot(d[i] == k);
+            if (d[i] == k) below[i] = (uint32_t)__popcll(b & lt);
+            if (lane == 0) s_cnt[(i * (RT / 64) + w) * PMAXD + k] = (uint32_t)__popcll(b);
+        }
+    }
+    __syncthreads();
+    if (tid < ndest) {                                          // one lane per destination: prefix over the 64 (item, wave) cells, from the tile's first slot
+        uint32_t run = tile_offsets[(uint64_t)tid * ntiles + blockIdx.x];
+        for (uint32_t c = 0; c < PI * (RT / 64); ++c) { const uint32_t v = s_cnt[c * PMAXD + tid]; s_cnt[c * PMAXD + tid] = run; run += v; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PI; ++i) {
+        const uint64_t p = base + (uint64_t)i * RT + tid;
+        if (p < n && d[i] < ndest) order[s_cnt[(i * (RT / 64) + w) * PMAXD + d[i]] + below[i]] = (uint32_t)p;
+    }
+}
+__global__ void partition_totals_kernel(const uint32_t* __restrict__ tile_offsets, const uint32_t* __restrict__ tile_counts_last, uint32_t ndest, uint32_t ntiles,
+                                        uint64_t n, unsigned long long* __restrict__ counts) {
+    const uint32_t k = threadIdx.x;                             // counts[k] = first slot of destination k + 1 (or n) - first slot of k
+    if (k >= ndest) return;
+    const unsigned long long lo = tile_offsets[(uint64_t)k * ntiles];
+    const unsigned long long hi = k + 1 < ndest ? tile_offsets[(uint64_t)(k + 1) * ntiles] : n;
+    counts[k] = hi - lo;
+}
+
 uint32_t blocks_of(uint64_t n) { return (uint32_t)((n + RT - 1) / RT); }
 }  // namespace
+
+// d_order[0 .. n) = the positions 0 .. n - 1 grouped by d_dest[position] (ascending), every group in ascending order; d_counts[k] (device,
+// uint64) = size of group k.  ndest <= 16.  *h_bad = UQ_NONE or a position whose destination is >= ndest.  Nothing here waits for the
+// device unless h_bad is given.
+extern "C" int uq_partition_order(uq_ctx* ctx, const uint8_t* d_dest, uint64_t n, uint32_t ndest, uint32_t* d_order, uint64_t* d_counts, uint64_t* h_bad) {
+    UQ_REQUIRE(ctx && ndest >= 1 && ndest <= PMAXD && d_counts, "uq_partition_order: 1 .. 16 destinations");
+    UQ_REQUIRE(n < (uint64_t(1) << 32), "uq_partition_order: more than 2^32-1 positions");
+    if (h_bad) *h_bad = UQ_NONE;
+    if (n == 0) { UQ_CHECK_HIP(hipMemsetAsync(d_counts, 0, ndest * 8, ctx->stream)); return 0; }
+    UQ_REQUIRE(d_dest && d_order, "uq_partition_order: null buffer");
+    const uint32_t ntiles = (uint32_t)((n + PT - 1) / PT);
+    void* scr;
+    UQ_TRY(uq_scratch(ctx, (size_t)ndest * ntiles * 4 + 512, &scr));
+    unsigned long long* bad = (unsigned long long*)scr;
+    uint32_t* tc = (uint32_t*)((uint8_t*)scr + 256);
+    UQ_CHECK_HIP(hipMemsetAsync(bad, 0xFF, 8, ctx->stream));
+    partition_count_kernel<<<ntiles, RT, 0, ctx->stream>>>(d_dest, n, ndest, ntiles, tc, bad);
+    UQ_LAUNCH_CHECK();
+    UQ_TRY(uq_scan_exclusive_u32(ctx, tc, tc, (uint64_t)ndest * ntiles, nullptr));
+    partition_totals_kernel<<<1, PMAXD, 0, ctx->stream>>>(tc, nullptr, ndest, ntiles, n, (unsigned long long*)d_counts);
+    UQ_LAUNCH_CHECK();
+    partition_rank_kernel<<<ntiles, RT, 0, ctx->stream>>>(d_dest, n, ndest, ntiles, tc, d_order);
+    UQ_LAUNCH_CHECK();
+    if (h_bad) {
+        UQ_TRY(uq_read_back(ctx, ctx->h_pinned, bad, 8));
+        UQ_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        *h_bad = ctx->h_pinned[0];
+    }
+    return 0;
+}
 
 // d_out[(d_index[j] - base) * cols ...] = d_values[j * cols ...] for j < n; every target row must lie in [0, out_rows).  *h_bad = UQ_NONE or
 // the lowest j that points outside.  Synchronises.

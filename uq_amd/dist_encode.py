@@ -184,7 +184,8 @@ class ShardedSession(Session):
 
     # ------------------------------------------------------------------ table builds over shards
     def _sorted(self, t, n, cols):
-        gs = uqdist.global_sort_rows(self.be, t, n, cols, self.read_offset, self.group, total_rows=self.total_reads)
+        gs = uqdist.global_sort_rows(self.be, t, n, cols, self.read_offset, self.group, total_rows=self.total_reads,
+                                      rows_of_ranks=[self.shard_starts[r + 1] - self.shard_starts[r] for r in range(self.world)])
         return gs, {'gidx': gs['gidx'], 'offset': gs['offset'], 'rows': gs['rows']}
 
     def _unique(self, gs, cols):
@@ -195,7 +196,8 @@ class ShardedSession(Session):
         ops, ctx, t = self.ops, self.ctx, self.ctx.torch
         m = gs['rows']
         if m:
-            skey, uniq, nu = ops.unique_sorted_rows(ctx, gs['table'], m, cols)       # the shard came out of the sort in order: neighbours only
+            skey, nu = gs['group'], gs['ngroups']                                    # the sort's own head flags: nobody compares neighbouring rows again
+            uniq = self.be.unique_rows_of_groups(gs['table'], m, cols, skey, nu)
             edge = bytes(ctx.to_numpy(gs['table'][:cols]).tobytes()) + bytes(ctx.to_numpy(gs['table'][(m - 1) * cols:m * cols]).tobytes())
         else:
             skey, uniq, nu, edge = t.empty(0, dtype=t.int32, device=ctx.device), ctx.empty(0), 0, b''

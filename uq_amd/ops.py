@@ -423,6 +423,22 @@ def unique_sorted_rows(ctx, sorted_table, rows, cols, want_unique=True):
     return group, uniq, nu.value
 
 
+def unique_rows_of_groups(ctx, sorted_table, rows, cols, group, nunique):
+    """The distinct rows of a table in memcmp order whose group ids are known (uq_unique_rows_of_groups): uint8[nunique * cols]."""
+    uniq = ctx.torch.empty(nunique * cols, dtype=ctx.torch.uint8, device=ctx.device)
+    call('uq_unique_rows_of_groups', ctx.h, _p(sorted_table), rows, cols, _p(group), nunique, _p(uniq))
+    return uniq
+
+
+def partition_order(ctx, dest, n, ndest):
+    """Stable partition of positions 0 .. n - 1 by dest[position] (uq_partition_order): (order i32[n], counts int64[ndest] ON THE DEVICE)."""
+    t = ctx.torch
+    order = t.empty(n, dtype=t.int32, device=ctx.device)
+    counts = t.empty(ndest, dtype=t.int64, device=ctx.device)
+    call('uq_partition_order', ctx.h, _p(dest), n, ndest, _p(order), _p(counts), None)
+    return order, counts
+
+
 def key_itemsize(max_key):
     return load().uq_key_itemsize(int(max_key))
 

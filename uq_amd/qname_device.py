@@ -132,9 +132,9 @@ def _distinct_counts(ctx, keys, n, thresholds, shard):
     m = gs['rows']
     counts, nu, uniq, edge, first0 = [0] * len(thresholds), 0, ctx.empty(0), b'', 0
     if m:
-        perm, _, skey, uniq, nu = ops.unique_rows(ctx, gs['table'], m, 8, want_key=False)
-        first = ops.gather_rows(ctx, gs['gidx'].view(ctx.torch.uint8), m, 8, perm).view(ctx.torch.int64)   # file-wide read numbers
-        counts = ops.prefix_distinct(ctx, first, skey, m, thresholds)
+        skey, nu = gs['group'], gs['ngroups']                # the shard came out of the sort in order, with its groups
+        uniq = shard.be.unique_rows_of_groups(gs['table'], m, 8, skey, nu)
+        counts = ops.prefix_distinct(ctx, gs['gidx'], skey, m, thresholds)           # gidx = file-wide read numbers, ascending inside a group
         edge = bytes(ctx.to_numpy(gs['table'][:8]).tobytes()) + bytes(ctx.to_numpy(gs['table'][(m - 1) * 8:m * 8]).tobytes())
         first0 = int(ctx.to_numpy(gs['gidx'][:1], np.int64)[0])          # the shard's first row is the first of its group in file order (stable sort)
     # Equal keys share a rank -- except a value heavier than a rank's share, which global_sort_rows deals over several ranks by file
