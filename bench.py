@@ -463,17 +463,14 @@ def sort_legs(ctx, args, rank, world, use_dist, fence, fetch, red_dev):
         dg = uqdist.dist_gather_rows(be, dna3, ns, Cd3, starts, gs['gidx'])
         return gs['rows'], (gs, dg)
 
-    def group_ids(gs, cols):
-        m = gs['rows']
-        if not m: return t.empty(0, dtype=t.int32, device=ctx.device)
-        uniq = be.unique_rows_of_groups(gs['table'], m, cols, gs['group'], gs['ngroups'])      # the unique table is a member of the container
-        return gs['group']                                   # (the per-rank id offsets are a handful of integers: dist_encode._unique)
+    def keyed(table, cols):
+        # a keyed table (uq.py:784-789): the global order, the groups the sort's own head flags give, and the distinct rows -- the table member
+        return uqdist.global_sort_rows(be, table, ns, cols, lo, total_rows=total, rows_of_ranks=per_rank, want='unique')
 
     def sort_dna_keyed():
-        gd = uqdist.global_sort_rows(be, dna3, ns, Cd3, lo, total_rows=total, rows_of_ranks=per_rank)
-        kd = group_ids(gd, Cd3)
-        gq = uqdist.global_sort_rows(be, qual3, ns, Cq3, lo, total_rows=total, rows_of_ranks=per_rank)
-        kq = group_ids(gq, Cq3)
+        gd = keyed(dna3, Cd3)
+        gq = keyed(qual3, Cq3)
+        kd, kq = gd['group'], gq['group']                    # (the per-rank id offsets are a handful of integers: dist_encode._unique)
         in_file_order = uqdist.dist_scatter_rows(be, kq.view(t.uint8), 4, starts, gq['gidx'])
         kq_sorted = uqdist.dist_gather_rows(be, in_file_order, ns, 4, starts, gd['gidx'])
         return gd['rows'], (gd, kd, gq, kq_sorted)

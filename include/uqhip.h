@@ -312,9 +312,10 @@ int uq_encode_int(uq_ctx* ctx, const int64_t* d_val, uint64_t n, int64_t sub, in
  * of neighbouring rows.  d_group[j] = dense rank of row j's value (from 0), d_unique (may be NULL) = the distinct rows in order. */
 int uq_unique_sorted_rows(uq_ctx* ctx, const uint8_t* d_sorted_table, uint64_t rows, uint32_t cols, uint32_t* d_group, uint8_t* d_unique,
                           uint64_t* h_nunique);
-/* The distinct rows of a table in memcmp order from the group ids its sort left (uq_unique_rows' d_sorted_key): d_unique[g] = the first
- * row of group g, g < nunique.  Replaces the table half of numpy.unique (uq.py:786) where the rows have been moved into sorted order. */
-int uq_unique_rows_of_groups(uq_ctx* ctx, const uint8_t* d_sorted_table, uint64_t rows, uint32_t cols, const uint32_t* d_group,
+/* The distinct rows of a table from what its sort left: the order (d_perm, uq_argsort_rows / uq_unique_rows) and the group ids of the
+ * sorted positions (d_group = uq_unique_rows' d_sorted_key): d_unique[g] = the first row of group g, g < nunique.  d_perm = NULL: the
+ * table has been moved into sorted order already.  Replaces the table half of numpy.unique (uq.py:786); only the distinct rows move. */
+int uq_unique_rows_of_groups(uq_ctx* ctx, const uint8_t* d_table, uint64_t rows, uint32_t cols, const uint32_t* d_perm, const uint32_t* d_group,
                              uint64_t nunique, uint8_t* d_unique);
 /* d_order = the positions 0 .. n - 1 grouped by d_dest[position] (ndest <= 16 destinations, ascending), each group in ascending order
  * (a stable partition); d_counts[k] (DEVICE, uint64) = size of group k.  What goes in front of an all-to-all: rows by destination rank,

@@ -30,8 +30,9 @@ class NumpyRows:
         head = np.ones(rows, dtype=bool); head[1:] = (t[1:] != t[:-1]).any(axis=1)
         return perm, torch.from_numpy((np.cumsum(head) - 1).astype(np.int32)), int(head.sum())
 
-    def unique_rows_of_groups(self, sorted_table, rows, cols, group, nunique):
-        t = sorted_table.numpy().reshape(rows, cols)
+    def unique_rows_of_groups(self, table, rows, cols, group, nunique, perm=None):
+        t = table.numpy().reshape(rows, cols)
+        if perm is not None: t = t[perm.numpy().astype(np.int64) & 0xFFFFFFFF]
         g = group.numpy().astype(np.int64)
         first = np.ones(rows, dtype=bool); first[1:] = g[1:] != g[:-1]
         assert int(first.sum()) == nunique

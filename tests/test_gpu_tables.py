@@ -421,6 +421,7 @@ def test_unique_rows_of_groups(ctx, n, C, nd, prefix):
     uniq = ops.unique_rows_of_groups(ctx, S, n, C, skey, nu)
     ru, _ = O.unique_rows(T)
     assert nu == len(ru) and np.array_equal(ctx.to_numpy(uniq).reshape(nu, C), ru)
+    assert ctx.torch.equal(ops.unique_rows_of_groups(ctx, d_T, n, C, skey, nu, perm=perm), uniq)      # ... without moving the table first
 
 
 @pytest.mark.parametrize('C', [1, 3, 4, 7, 8, 13, 16, 38, 64, 113, 200])

@@ -122,7 +122,7 @@ SIGNATURES = {
     'uq_int_prefix_distinct': [_vp, _vp, _u64, C.c_int64, _u64, _u64, _P(_u64), _int, _P(_u64)],
     'uq_encode_int': [_vp, _vp, _u64, C.c_int64, _int, _vp],
     'uq_unique_sorted_rows': [_vp, _vp, _u64, _u32, _vp, _vp, _P(_u64)],
-    'uq_unique_rows_of_groups': [_vp, _vp, _u64, _u32, _vp, _u64, _vp],
+    'uq_unique_rows_of_groups': [_vp, _vp, _u64, _u32, _vp, _vp, _u64, _vp],
     'uq_partition_order': [_vp, _vp, _u64, _u32, _vp, _vp, _P(_u64)],
     'uq_partition_rows': [_vp, _vp, _u32, _u32, _vp, _u64, _u64, _u64, _vp],
     'uq_owner_of_rows': [_vp, _vp, _u64, _P(C.c_int64), _u32, _vp],

@@ -555,12 +555,13 @@ __global__ __launch_bounds__(ST) void adjacent_heads_kernel(const uint8_t* __res
     heads[j] = same ? 2 : 1;
 }
 
-// positions where a new group starts in a sorted table whose group ids are known: first[group[j]] = j
-__global__ __launch_bounds__(ST) void group_firsts_kernel(const uint32_t* __restrict__ group, uint64_t n, uint32_t* __restrict__ first) {
+// where a new group starts in sorted order: first[group[j]] = j, or the row at j (perm[j]) when the table itself has not been moved
+__global__ __launch_bounds__(ST) void group_firsts_kernel(const uint32_t* __restrict__ group, const uint32_t* __restrict__ perm, uint64_t n,
+                                                          uint32_t* __restrict__ first) {
     const uint64_t j = (uint64_t)blockIdx.x * ST + threadIdx.x;
     if (j >= n) return;
     const uint32_t g = group[j];
-    if (j == 0 || group[j - 1] != g) first[g] = (uint32_t)j;
+    if (j == 0 || group[j - 1] != g) first[g] = perm ? perm[j] : (uint32_t)j;
 }
 
 __global__ void lower_bound_rows_kernel(const uint8_t* __restrict__ table, uint64_t rows, uint32_t C, const uint8_t* __restrict__ probes,
@@ -695,20 +696,21 @@ extern "C" int uq_unique_sorted_rows(uq_ctx* ctx, const uint8_t* d_sorted_table,
     return 0;
 }
 
-// The distinct rows of a table in memcmp order whose group ids (dense ranks of the row values, as uq_unique_rows' d_sorted_key or
-// uq_unique_sorted_rows' d_group give them) are known: d_unique[g] = the first row of group g.  No row is compared: the sort that put
-// the table in order has already said where the values change.
-extern "C" int uq_unique_rows_of_groups(uq_ctx* ctx, const uint8_t* d_sorted_table, uint64_t rows, uint32_t cols, const uint32_t* d_group,
+// The distinct rows of a table whose sort has left the order (d_perm) and the group ids of the sorted positions (d_group: dense ranks of
+// the row values, uq_unique_rows' d_sorted_key): d_unique[g] = the first row of group g in sorted order.  d_perm = NULL: the table has
+// been moved into sorted order already.  No row is compared -- the sort has said where the values change -- and only the distinct
+// rows are moved: a keyed table never needs its duplicates in sorted order.
+extern "C" int uq_unique_rows_of_groups(uq_ctx* ctx, const uint8_t* d_table, uint64_t rows, uint32_t cols, const uint32_t* d_perm, const uint32_t* d_group,
                                         uint64_t nunique, uint8_t* d_unique) {
     UQ_REQUIRE(ctx && cols >= 1 && nunique <= rows, "uq_unique_rows_of_groups: bad argument");
     if (rows == 0 || nunique == 0) return 0;
-    UQ_REQUIRE(d_sorted_table && d_group && d_unique && rows < (uint64_t(1) << 32), "uq_unique_rows_of_groups: null buffer or more than 2^32-1 rows");
+    UQ_REQUIRE(d_table && d_group && d_unique && rows < (uint64_t(1) << 32), "uq_unique_rows_of_groups: null buffer or more than 2^32-1 rows");
     void* scr;
     UQ_TRY(uq_scratch(ctx, nunique * 4 + 256, &scr));
     uint32_t* first = (uint32_t*)scr;
-    group_firsts_kernel<<<blocks_for(rows), ST, 0, ctx->stream>>>(d_group, rows, first);
+    group_firsts_kernel<<<blocks_for(rows), ST, 0, ctx->stream>>>(d_group, d_perm, rows, first);
     UQ_LAUNCH_CHECK();
-    return uq_gather_rows_internal(ctx, d_sorted_table, rows, cols, first, 4, nunique, d_unique);
+    return uq_gather_rows_internal(ctx, d_table, rows, cols, first, 4, nunique, d_unique);
 }
 
 extern "C" int uq_lower_bound_rows(uq_ctx* ctx, const uint8_t* d_sorted_table, uint64_t rows, uint32_t cols,

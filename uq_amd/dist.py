@@ -168,9 +168,9 @@ class HipRows:
         perm, _, group, _, nu = ops.unique_rows(self.ctx, table, rows, cols, want_key=False, want_unique=False)
         return perm, group, nu
 
-    def unique_rows_of_groups(self, sorted_table, rows, cols, group, nunique):
+    def unique_rows_of_groups(self, table, rows, cols, group, nunique, perm=None):
         from . import ops
-        return ops.unique_rows_of_groups(self.ctx, sorted_table, rows, cols, group, nunique)
+        return ops.unique_rows_of_groups(self.ctx, table, rows, cols, group, nunique, perm)
 
     def partition_order(self, dest, n, ndest):
         """Stable partition of positions by a one-byte destination: (order int32[n], counts int64[ndest] on the device) -- uq_partition_order."""
@@ -305,11 +305,13 @@ def _sample_positions(rows, k, seed):
     return (edges[:-1] + (rng.random(k) * (edges[1:] - edges[:-1])).astype(np.int64)).astype(np.int32)
 
 
-def global_sort_rows(be, table, rows, cols, read_offset, group=None, samples_per_rank=None, total_rows=None, rows_of_ranks=None):
+def global_sort_rows(be, table, rows, cols, read_offset, group=None, samples_per_rank=None, total_rows=None, rows_of_ranks=None, want='sorted'):
     """Sample sort of row shards over the process group -- ONE sort per row.  Every rank passes its UNSORTED shard (`rows` x `cols`
     bytes, records [read_offset, read_offset + rows) of the file) and gets back a contiguous range of the globally sorted order:
     dict(table=sorted rows, rows=m, gidx=int64 file-wide index of each row, offset=global position of the first row,
-    group=int32 group id of every row (dense ranks of the row values inside this rank's range), ngroups).
+    group=int32 group id of every row (dense ranks of the row values inside this rank's range), ngroups, edge=its first and last row).
+    want='unique' (a keyed table: uq.py:784-789): instead of `table` the dict holds unique=the range's distinct rows in order -- the
+    duplicates are never moved into sorted order.
       1. a stratified sample of every shard is all-gathered and sorted on the device; W - 1 splitters are its quantiles;
       2. every row's destination = the number of splitters below it (uq_partition_rows) -- no local sort is needed for that;
       3. stable partition of the shard's positions by destination (uq_partition_order: a histogram, a scan, a ranking pass -- no sort),
@@ -326,9 +328,9 @@ def global_sort_rows(be, table, rows, cols, read_offset, group=None, samples_per
     if world == 1:
         if rows:
             perm, grp, ng = be.argsort_groups(table, rows, cols)
-            return dict(table=be.gather_rows(table, rows, cols, perm), rows=rows, gidx=be.index_affine(perm, int(read_offset), 8), offset=0, group=grp, ngroups=ng)
-        return dict(table=table, rows=0, gidx=torch.empty(0, dtype=torch.int64, device=be.device), offset=0,
-                    group=torch.empty(0, dtype=torch.int32, device=be.device), ngroups=0)
+            return _sorted_range(be, table, rows, cols, perm, grp, ng, be.index_affine(perm, int(read_offset), 8), 0, want)
+        return dict(table=table, unique=table, rows=0, gidx=torch.empty(0, dtype=torch.int64, device=be.device), offset=0,
+                    group=torch.empty(0, dtype=torch.int32, device=be.device), ngroups=0, edge=table)
     if rows_of_ranks is None:
         rows_of_ranks = [r[0] for r in gather_matrix([rows], dist, torch, be.device, group)]
     if total_rows is None:
@@ -363,14 +365,22 @@ def global_sort_rows(be, table, rows, cols, read_offset, group=None, samples_per
     midx, _ = exchange_split(send_idx, nsend, dist, torch, be.device, torch.int64, group, rcounts=nrecv)
     m = sum(nrecv)
     # 4. the one sort
+    offset = sum(sum(matrix[s][d] for s in range(world)) for d in range(rank))
     if m:
         perm2, grp, ng = be.argsort_groups(merged, m, cols)
-        out = be.gather_rows(merged, m, cols, perm2)
         oidx = be.gather_rows(midx.view(torch.uint8), m, 8, perm2).view(torch.int64)
-    else:
-        out, oidx, grp, ng = merged, midx, torch.empty(0, dtype=torch.int32, device=be.device), 0
-    offset = sum(sum(matrix[s][d] for s in range(world)) for d in range(rank))
-    return dict(table=out, rows=m, gidx=oidx, offset=offset, group=grp, ngroups=ng)
+        return _sorted_range(be, merged, m, cols, perm2, grp, ng, oidx, offset, want)
+    return dict(table=merged, unique=merged, rows=0, gidx=midx, offset=offset, group=torch.empty(0, dtype=torch.int32, device=be.device), ngroups=0, edge=merged)
+
+
+def _sorted_range(be, table, m, cols, perm, grp, ng, gidx, offset, want):
+    """What global_sort_rows hands back for a rank's range: the rows in sorted order, or (want='unique') only its distinct rows."""
+    torch = be.torch
+    ends = torch.stack([perm[0], perm[m - 1]])
+    out = dict(rows=m, gidx=gidx, offset=offset, group=grp, ngroups=ng, edge=be.gather_rows(table, m, cols, ends))
+    if want == 'unique': out['unique'] = be.unique_rows_of_groups(table, m, cols, grp, ng, perm)
+    else: out['table'] = be.gather_rows(table, m, cols, perm)
+    return out
 
 
 def _route_by_owner(be, shard_starts, gidx, world, dist=None, group=None):

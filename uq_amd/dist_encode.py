@@ -183,22 +183,21 @@ class ShardedSession(Session):
                   [(first * isz, tensor.contiguous().view(self.ctx.torch.uint8).reshape(-1))])
 
     # ------------------------------------------------------------------ table builds over shards
-    def _sorted(self, t, n, cols):
+    def _sorted(self, t, n, cols, want='sorted'):
         gs = uqdist.global_sort_rows(self.be, t, n, cols, self.read_offset, self.group, total_rows=self.total_reads,
-                                      rows_of_ranks=[self.shard_starts[r + 1] - self.shard_starts[r] for r in range(self.world)])
+                                      rows_of_ranks=[self.shard_starts[r + 1] - self.shard_starts[r] for r in range(self.world)], want=want)
         return gs, {'gidx': gs['gidx'], 'offset': gs['offset'], 'rows': gs['rows']}
 
     def _unique(self, gs, cols):
-        """Head flags of a sorted shard -> (unique rows, count, first global group id, total groups, group id per sorted row).
+        """A rank's range of the global sort (want='unique') -> (unique rows, count, first global group id, total groups, group id per sorted row).
         A group may run on from the rank in front (dist.global_sort_rows deals a tie group heavier than a rank's share over several
         ranks): the ranks exchange their first and last rows, and a rank whose first row equals the last row in front of it drops
         that row from its unique table and starts its ids one lower."""
         ops, ctx, t = self.ops, self.ctx, self.ctx.torch
         m = gs['rows']
         if m:
-            skey, nu = gs['group'], gs['ngroups']                                    # the sort's own head flags: nobody compares neighbouring rows again
-            uniq = self.be.unique_rows_of_groups(gs['table'], m, cols, skey, nu)
-            edge = bytes(ctx.to_numpy(gs['table'][:cols]).tobytes()) + bytes(ctx.to_numpy(gs['table'][(m - 1) * cols:m * cols]).tobytes())
+            skey, nu, uniq = gs['group'], gs['ngroups'], gs['unique']                # the sort's own head flags; only the distinct rows were moved
+            edge = bytes(ctx.to_numpy(gs['edge']).tobytes())
         else:
             skey, uniq, nu, edge = t.empty(0, dtype=t.int32, device=ctx.device), ctx.empty(0), 0, b''
         edges = self.shard.gather_bytes(edge)                       # first + last row of every rank (empty: no rows)
@@ -245,7 +244,7 @@ class ShardedSession(Session):
                 table, first = (g, sort_order['rows'], cols), sort_order['offset']
             self.write_pattern_shard(table, first, N, table_name + '.raw')
         else:
-            gs, order = self._sorted(t, n, cols)                                                 # uq.py:784-789
+            gs, order = self._sorted(t, n, cols, want='unique')                                  # uq.py:784-789
             uniq, nu, g0, nu_total, gids = self._unique(gs, cols)
             isz = ops.key_itemsize(nu_total - 1)                                                 # uq.py:790
             self._key_member(gs, order, gids, sort_order, isz, table_name + '.key')
@@ -280,7 +279,7 @@ class ShardedSession(Session):
                 self.write_out_shard(c, first, N, column['name'] + '.raw', np.dtype(column['dtype']))
         else:
             rows = ops.stack_columns(ctx, cols_d, common)                                        # uq.py:828-830
-            gs, order = self._sorted(rows, n, width)
+            gs, order = self._sorted(rows, n, width, want='unique')
             uniq, nu, g0, nu_total, gids = self._unique(gs, width)
             isz = ops.key_itemsize(nu_total - 1)                                                 # uq.py:832
             self._key_member(gs, order, gids, sort_order, isz, 'QNAME.key')

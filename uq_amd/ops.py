@@ -423,10 +423,11 @@ def unique_sorted_rows(ctx, sorted_table, rows, cols, want_unique=True):
     return group, uniq, nu.value
 
 
-def unique_rows_of_groups(ctx, sorted_table, rows, cols, group, nunique):
-    """The distinct rows of a table in memcmp order whose group ids are known (uq_unique_rows_of_groups): uint8[nunique * cols]."""
+def unique_rows_of_groups(ctx, table, rows, cols, group, nunique, perm=None):
+    """The distinct rows of a table from what its sort left (uq_unique_rows_of_groups): uint8[nunique * cols].  perm = the sort's order when
+    the table has not been moved into it (only the distinct rows are gathered), None for a table in sorted order."""
     uniq = ctx.torch.empty(nunique * cols, dtype=ctx.torch.uint8, device=ctx.device)
-    call('uq_unique_rows_of_groups', ctx.h, _p(sorted_table), rows, cols, _p(group), nunique, _p(uniq))
+    call('uq_unique_rows_of_groups', ctx.h, _p(table), rows, cols, _p(perm), _p(group), nunique, _p(uniq))
     return uniq
 
 

@@ -128,14 +128,14 @@ def _distinct_counts(ctx, keys, n, thresholds, shard):
         perm, key, skey, uniq, nu = ops.unique_rows(ctx, keys, n, 8)
         return ops.prefix_distinct(ctx, perm, skey, n, thresholds), nu, key, uniq
     from .dist import global_sort_rows
-    gs = global_sort_rows(shard.be, keys.view(ctx.torch.uint8), n, 8, shard.read_offset, shard.group, total_rows=shard.total)
+    gs = global_sort_rows(shard.be, keys.view(ctx.torch.uint8), n, 8, shard.read_offset, shard.group, total_rows=shard.total, want='unique')
     m = gs['rows']
     counts, nu, uniq, edge, first0 = [0] * len(thresholds), 0, ctx.empty(0), b'', 0
     if m:
         skey, nu = gs['group'], gs['ngroups']                # the shard came out of the sort in order, with its groups
-        uniq = shard.be.unique_rows_of_groups(gs['table'], m, 8, skey, nu)
+        uniq = gs['unique']
         counts = ops.prefix_distinct(ctx, gs['gidx'], skey, m, thresholds)           # gidx = file-wide read numbers, ascending inside a group
-        edge = bytes(ctx.to_numpy(gs['table'][:8]).tobytes()) + bytes(ctx.to_numpy(gs['table'][(m - 1) * 8:m * 8]).tobytes())
+        edge = bytes(ctx.to_numpy(gs['edge']).tobytes())
         first0 = int(ctx.to_numpy(gs['gidx'][:1], np.int64)[0])          # the shard's first row is the first of its group in file order (stable sort)
     # Equal keys share a rank -- except a value heavier than a rank's share, which global_sort_rows deals over several ranks by file
     # position.  Such a group is counted by every rank that holds a piece of it; its true first occurrence sits on the EARLIEST of them.
