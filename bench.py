@@ -144,10 +144,11 @@ def main():
     side = SideContext(ctx)
     red_dev = ctx.device if not (use_dist and dist.get_backend() == 'gloo') else 'cpu'     # where the closing all-reduces live
     notricks = args.workload == 'cfg5-notricks'
-    # N = 1: the step is the WHOLE encode of the shard, QNAME columns included.  N > 1: the QNAME layout is a property of the whole
-    # file (line 1, common prefix): the sharded encoder (uq_amd.dist_encode) combines it over the ranks; this bench's shards are
-    # timed without it and the JSON says so.
-    qname_in_step = not use_dist and not args.no_qname
+    # The step is the WHOLE encode of the shard, QNAME columns included, at every N.  N > 1: the QNAME layout is a property of the whole
+    # file (line 1, the common prefix / suffix): rank 0 guesses it from its reads, ONE broadcast of the structure makes it every rank's,
+    # every rank's pack kernel verifies it on all its reads, and flags / value ranges / first occurrences are combined over the ranks
+    # (one all-gather of a few integers, one all-reduce of the small first-occurrence tables: qname_device.analyse_fused_sharded).
+    qname_in_step = not args.no_qname
 
     def fence():
         if use_dist: dist.barrier()
@@ -161,6 +162,10 @@ def main():
 
     def run_encode(n, steps, warmup, compare_exact, qname_in_step=qname_in_step):
         """`steps` timed steps of the hot path over n reads per GPU (W untimed first) -> everything the JSON needs."""
+        shard = None
+        if use_dist:
+            from uq_amd import dist as uqdist
+            shard = uqdist.Shard(uqdist.HipRows(ctx), rank * n, world * n)       # rank r's shard = reads [r n, (r + 1) n) of the synthetic file
         if args.workload == 'cfg2':
             spec = synth.Spec(SEED, args.length)
         else:
@@ -208,7 +213,10 @@ def main():
                         # the QNAME passes ride in the pack kernel: layout guessed on the device from a sample of the reads (queued here,
                         # behind the index), verified on every read while the fields are parsed; distinct counts queued behind it
                         fq = ops.FusedQname(ctx, cap_reads)
-                        ops.qname_guess_async(ctx, d_buf, ls_cap, fq)
+                        if rank == 0: ops.qname_guess_async(ctx, d_buf, ls_cap, fq)
+                        if use_dist:
+                            from uq_amd import qname_device
+                            qname_device.broadcast_guess(ctx, fq, shard)             # rank 0's guess, on every rank before its pack kernel
                     e0.record()
                     sp = ops.pack_stats_async(ctx, d_buf, ls_cap, cap_reads, guess, st=st_q, fq=fq)
                     e1.record()
@@ -260,12 +268,12 @@ def main():
             qpath, qres = None, None
             if qname_in_step:
                 from uq_amd import qname_device
-                qres = qname_device.analyse_fused(ctx, fq, nreads) if (fq is not None and spec is not None) else None
-                qpath = 'fused into the pack kernel'
+                qres = qname_device.analyse_fused_sharded(ctx, fq, nreads, shard) if (fq is not None and spec is not None) else None
+                qpath = 'fused into the pack kernel' + (' (rank 0\'s layout guess broadcast, every rank verifies; flags / ranges / first occurrences combined over the ranks)' if use_dist else '')
                 if qres is None:
                     ls = index()
-                    qres = qname_device.analyse_device(ctx, d_buf, ls, nreads)
-                    qpath = 'exact kernels (layout, tokeniser)'
+                    qres = qname_device.analyse_device(ctx, d_buf, ls, nreads, shard)
+                    qpath = 'exact kernels (layout, tokeniser)' + (' over shards' if use_dist else '')
                 if qres is None: raise RuntimeError('the synthetic QNAMEs are outside the device subset')
             d, p = decide_and_params(hs, nreads)
             if spec is not None and ops.same_pack_params(p, guess):
@@ -317,6 +325,12 @@ def main():
                 a, b = state['qname'], qex
                 if a[:4] != b[:4] or not all(torch.equal(x, y) for x, y in zip(a[4], b[4])):
                     raise RuntimeError('parity failure: the fused QNAME pass differs from the exact kernels')
+        if compare_exact and use_dist and qname_in_step:
+            from uq_amd import qname_device
+            qex = qname_device.analyse_device(ctx, d_buf, state['ls'], state['nreads'], shard)      # the exact kernels over the same shards (collective)
+            a = state['qname']
+            if qex is None or a[:4] != qex[:4] or not all(torch.equal(x, y) for x, y in zip(a[4], qex[4])):
+                raise RuntimeError('parity failure: the sharded fused QNAME pass differs from the exact sharded kernels')
         if state['bad'] is not None and ops.bad_index(state['bad']) is not None:
             raise RuntimeError('pack reported an uncoded symbol at read %d' % ops.bad_index(state['bad']))
         d, nreads = state['d'], state['nreads']
@@ -395,8 +409,8 @@ def main():
         if not cb['gpu_rows_match_oracle_on_sample']:
             raise RuntimeError('parity failure: GPU rows differ from the oracle on the CPU sample')
         result['cpu_baseline'] = cb
-    # what the N > 1 lines measure (their step leaves the QNAME passes out), at N = 1: the like-for-like baseline of a scaling curve
-    if qname_in_step and world == 1:
+    # the step without the QNAME passes (what the N > 1 lines of rounds 1 - 3 timed), at N = 1: for comparisons with those records
+    if qname_in_step and world == 1 and not use_dist:
         plain = run_encode(args.reads, max(5, args.steps // 2), 2, False, qname_in_step=False)
         result['qname']['step_without_qname_ms'] = round(plain['dt_step'] * 1e3, 3)
         result['qname']['value_without_qname'] = round(plain['total_bytes'] / 1e6 / plain['dt_step'], 1)

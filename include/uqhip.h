@@ -390,6 +390,13 @@ int uq_pack_stats_qname_async(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t*
                               uq_qname_fused* d_q, uint32_t* d_vals, uint64_t vals_pitch, int* h_fused);
 int uq_qname_fused_finish(uq_ctx* ctx, uq_qname_fused* d_q, const uint32_t* d_vals, uint64_t vals_pitch);
 int uq_qname_fused_fetch(uq_ctx* ctx, const uq_qname_fused* d_q, uq_qname_fused* h_out);
+/* The fused pass over SHARDS (one rank per GPU, uq_amd.qname_device.analyse_fused_sharded): rank 0's guess is broadcast, every rank's
+ * pack kernel verifies and parses its own reads, flags / vmin / vmax are combined over the ranks, and the distinct counts of the
+ * small-range columns (h_range[c] <= 4096 values from h_vmin[c]; 0: skip the column) come from first-occurrence tables with FILE-WIDE
+ * read numbers: d_first[c * 4096 + v - h_vmin[c]] = read_offset + the shard's lowest read holding v, INT64_MAX where v does not occur;
+ * int64 so that a collective's MIN over the ranks is the file's table.  Nothing waits for the device. */
+int uq_qname_fused_first_seen(uq_ctx* ctx, const uint32_t* d_vals, uint64_t vals_pitch, uint64_t nreads, uint64_t read_offset,
+                              const uint32_t* h_vmin, const uint32_t* h_range, int ncols, int64_t* d_first);
 int uq_encode_u32(uq_ctx* ctx, const uint32_t* d_val, uint64_t n, uint32_t sub, int itemsize, void* d_out);
 int uq_encode_u32_columns(uq_ctx* ctx, const uint32_t* d_vals, uint64_t vals_pitch, uint64_t n, int ncols, const uint32_t* h_sub,
                           const int* h_itemsize, void* const* h_d_outs);       /* uq_encode_u32 of the first ncols columns of a fused pass, one launch */

@@ -171,6 +171,45 @@ def test_sharded_decode_with_idle_ranks(tmp_path):
     assert out.read_bytes() == fq
 
 
+def _fused_qname_over_ranks(tmp_path, world, names, tag):
+    recs = _records_of(len(names))
+    fq = b''.join(nm + b'\n' + b'\n'.join(r.split(b'\n')[1:]) + b'\n' for nm, r in zip(names, recs))
+    p = tmp_path / ('%s.fastq' % tag)
+    p.write_bytes(fq)
+    env = dict(os.environ, PYTHONPATH=REPO)
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
+                          '--master-port', str(_free_port()), os.path.join(REPO, 'tests', 'sharded_fused_qname_job.py'), str(p)],
+                         env=env, cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    text = out.stdout.decode(errors='replace')
+    assert out.returncode == 0, text[-3000:]
+    return [l for l in text.splitlines() if l.startswith('OK') or l.startswith('DECLINED')][-1]
+
+
+_RECS = {}
+def _records_of(n):
+    from test_gpu_e2e import _records
+    if n not in _RECS: _RECS[n] = _records(synth.fastq(20261003 + 49, n, 24, n_rate=1))
+    return _RECS[n]
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_fused_qname_pass_over_shards(tmp_path, world):
+    """The QNAME passes of the N > 1 step (bench.py; qname_device.analyse_fused_sharded): rank 0's layout guess broadcast, every rank's pack
+    kernel verifies and parses, flags / value ranges / first occurrences combined over the ranks.  Illumina-like names over 150 000 reads
+    (checkpoints at 10 000 ... 80 000 and the last read fall into different shards; a small-range column whose distinct values keep growing
+    across the shards -- a mapping turned integers only by the FILE's counts --, flow-cell coordinates that fire at rank 0's first
+    checkpoint, a column whose value range only the last rank completes): the concatenated columns are the oracle's.  (A field that is
+    constant on rank 0 and varies later would make rank 0's guess take it into the suffix: the other ranks' flags then stand the pass down.)  A name that breaks the layout on the last
+    rank only, and a column that stays a mapping of numbers: every rank stands down together."""
+    n = 150_000
+    names = [b'@M01:7:FC:%d:%d:%d:%d:%d' % (1 + i % 4, 1101 + (i // 40) % 3000, 1000 + (i * 7919) % 28000, 1000 + (i * 104729) % 28000, 1 + (i // 25000)) for i in range(n)]
+    assert _fused_qname_over_ranks(tmp_path, world, names, 'ok').startswith('OK 5')
+    broken = list(names); broken[n - 7] = b'@M01:7:FC:2:1101:x1:2:1'
+    assert _fused_qname_over_ranks(tmp_path, world, broken, 'broken') == 'DECLINED'
+    few = [b'@q:%d:%d' % ([5, 70000, 12345678, 31][i % 4], i % 3) for i in range(50_000)]          # four far-apart numbers: a mapping of strings
+    assert _fused_qname_over_ranks(tmp_path, world, few, 'mapping') == 'DECLINED'
+
+
 def test_bench_two_ranks_rehearsal():
     """bench.py's N > 1 path (sharded synthetic input, all-reduced statistics, MAX-over-ranks timing, one JSON line from
     rank 0) with two ranks sharing the card over gloo; the driver runs the same code over RCCL, one rank per GPU."""
@@ -184,7 +223,7 @@ def test_bench_two_ranks_rehearsal():
     r = json.loads(lines[0])
     assert r['n_gpus'] == 2 and r['scaling'] == 'weak' and r['value'] > 0 and r['config']['reads_per_gpu'] == 200000
     assert r['roofline']['bound'] == 'hbm' and 'cpu_baseline' not in r          # the CPU baseline is timed at N = 1 only
-    assert r['qname']['in_step'] is False                                        # (the QNAME layout belongs to the whole file: N = 1 only)
+    assert r['qname']['in_step'] is True and r['qname']['path'].startswith('fused into the pack kernel')   # rank 0's guess broadcast, all ranks verify: the whole encode at N > 1 too (checked in the run against the exact sharded kernels)
     # the global --sort legs, strong-scaled (150 000 reads over the two ranks): sample sort + all-to-all(v) of the QUAL rows with the
     # DNA rows moved along; and the keyed --sort DNA mix (two sorts, group ids scattered back and fetched in the DNA order)
     sl = r['sort_leg']

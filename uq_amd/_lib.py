@@ -135,6 +135,7 @@ SIGNATURES = {
     'uq_pack_stats_qname_async': [_vp, _vp, _vp, _u64, _P(PackParams), _vp, _vp, _vp, _vp, _vp, _vp, _u64, _P(_int)],
     'uq_qname_fused_finish': [_vp, _vp, _vp, _u64],
     'uq_qname_fused_fetch': [_vp, _vp, _P(QnameFused)],
+    'uq_qname_fused_first_seen': [_vp, _vp, _u64, _u64, _u64, _P(_u32), _P(_u32), _int, _vp],
     'uq_encode_u32': [_vp, _vp, _u64, _u32, _int, _vp],
     'uq_encode_u32_columns': [_vp, _vp, _u64, _u64, _int, _P(_u32), _P(_int), _P(_vp)],
     'uq_emit_fastq': [_vp, _P(EmitParams), _P(_vp), _P(_vp), _P(_vp), _vp, _vp, _vp, _u64, _vp, _vp, _u64, _P(_u64)],

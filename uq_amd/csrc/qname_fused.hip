@@ -472,6 +472,55 @@ extern "C" int uq_qname_fused_finish(uq_ctx* ctx, uq_qname_fused* d_q, const uin
     return 0;
 }
 
+// ---- the same first occurrences over SHARDS (one rank per GPU): the read numbers are file-wide (read_offset + local number) and the value
+// ranges are the whole file's (the caller has combined vmin / vmax over the ranks), so that a MIN over the ranks' tables is the file's
+// table and `distinct among reads [0, T]` follows for every checkpoint T of the file.  int64 entries (a collective's MIN takes them as they
+// are), INT64_MAX = the value does not occur in this shard.
+struct QfRanges { uint32_t vmin[UQ_QF_MAXC]; uint32_t range[UQ_QF_MAXC]; };          // range 0: not a small-range column, skipped
+namespace {
+__global__ void qf_fill_i64_kernel(long long* __restrict__ p, uint64_t n, long long v) {
+    const uint64_t i = (uint64_t)blockIdx.x * QF_THREADS + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+__global__ __launch_bounds__(QF_THREADS) void qf_first_seen_global_kernel(const uint32_t* __restrict__ vals, uint64_t pitch, uint64_t n, uint64_t read_offset,
+                                                                           QfRanges rg, long long* __restrict__ first) {
+    __shared__ uint32_t s_first[QF_SMALL];
+    const uint32_t col = blockIdx.y;
+    const uint32_t vmin = rg.vmin[col], range = rg.range[col];
+    if (range == 0 || range > QF_SMALL || n == 0) return;
+    const uint32_t* v = vals + col * pitch;
+    long long* f = first + (size_t)col * QF_SMALL;
+    for (uint32_t i = threadIdx.x; i < range; i += QF_THREADS) s_first[i] = 0xFFFFFFFFu;
+    __syncthreads();
+    const uint64_t per = (n + gridDim.x - 1) / gridDim.x;          // a workgroup takes a contiguous slice of the shard's reads
+    const uint64_t lo = (uint64_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += QF_THREADS) {
+        const uint32_t slot = v[i] - vmin;
+        if (slot < range && (uint32_t)i < s_first[slot]) atomicMin(&s_first[slot], (uint32_t)i);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < range; i += QF_THREADS)
+        if (s_first[i] != 0xFFFFFFFFu) atomicMin(&f[i], (long long)(read_offset + s_first[i]));
+}
+}  // namespace
+
+extern "C" int uq_qname_fused_first_seen(uq_ctx* ctx, const uint32_t* d_vals, uint64_t vals_pitch, uint64_t nreads, uint64_t read_offset,
+                                         const uint32_t* h_vmin, const uint32_t* h_range, int ncols, int64_t* d_first) {
+    UQ_REQUIRE(ctx && h_vmin && h_range && d_first && ncols >= 1 && ncols <= UQ_QF_MAXC, "uq_qname_fused_first_seen: bad argument");
+    UQ_REQUIRE(nreads < (uint64_t(1) << 32) && (nreads == 0 || d_vals), "uq_qname_fused_first_seen: null buffer or more than 2^32-1 reads in a shard");
+    QfRanges rg;
+    memset(&rg, 0, sizeof(rg));
+    for (int c = 0; c < ncols; ++c) { UQ_REQUIRE(h_range[c] <= QF_SMALL, "uq_qname_fused_first_seen: a range beyond %u", QF_SMALL); rg.vmin[c] = h_vmin[c]; rg.range[c] = h_range[c]; }
+    const uint64_t cells = (uint64_t)UQ_QF_MAXC * QF_SMALL;
+    qf_fill_i64_kernel<<<(uint32_t)((cells + QF_THREADS - 1) / QF_THREADS), QF_THREADS, 0, ctx->stream>>>((long long*)d_first, cells, 0x7FFFFFFFFFFFFFFFll);
+    UQ_LAUNCH_CHECK();
+    if (nreads) {
+        qf_first_seen_global_kernel<<<dim3(UQ_NUM_CU * 4, (uint32_t)ncols), QF_THREADS, 0, ctx->stream>>>(d_vals, vals_pitch, nreads, read_offset, rg, (long long*)d_first);
+        UQ_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
 extern "C" int uq_qname_fused_fetch(uq_ctx* ctx, const uq_qname_fused* d_q, uq_qname_fused* h_out) {
     UQ_REQUIRE(ctx && d_q && h_out, "uq_qname_fused_fetch: null argument");
     if (ctx->qf_sent != d_q) UQ_TRY(uq_read_back(ctx, ctx->h_pinned + QF_PINNED_AT, d_q, sizeof(uq_qname_fused)));    // (no finish in front)

@@ -249,6 +249,17 @@ def qname_fused_fetch(ctx, fq):
     return out
 
 
+def qname_fused_first_seen(ctx, fq, n, read_offset, vmins, ranges):
+    """First occurrences of the small-range columns of a shard as file-wide read numbers (uq_qname_fused_first_seen): int64[QF_MAXC * 4096]
+    on the device, INT64_MAX = absent; ranges[c] = 0 skips column c."""
+    t = ctx.torch
+    k = len(vmins)
+    first = t.empty(QF_MAXC * 4096, dtype=t.int64, device=ctx.device)
+    call('uq_qname_fused_first_seen', ctx.h, _p(fq.vals), fq.pitch, int(n), int(read_offset), (C.c_uint32 * k)(*[int(x) for x in vmins]),
+         (C.c_uint32 * k)(*[int(x) for x in ranges]), k, _p(first))
+    return first
+
+
 def encode_u32_columns(ctx, fq, n, subs, itemsizes):
     """The first len(subs) columns of a fused pass narrowed to their dtypes in one launch (uq_encode_u32_columns)."""
     t = ctx.torch

@@ -293,6 +293,108 @@ def analyse_fused(ctx, fq, nreads):
     return prefix, suffix, separators, columns, arrays
 
 
+def broadcast_guess(ctx, fq, shard):
+    """The fused pass over shards, step 1: rank 0's layout guess (ops.qname_guess[_async] has been queued on rank 0) becomes every rank's --
+    the structure's bytes travel in ONE broadcast, queued on the stream like any kernel (nccl); the pack kernels behind it verify the
+    layout on every read of every shard."""
+    if shard is None or shard.world == 1:
+        return
+    dist = shard.dist
+    if dist.get_backend(shard.group) == 'gloo' and fq.q.is_cuda:
+        host = fq.q.cpu(); dist.broadcast(host, src=0, group=shard.group); fq.q.copy_(host)      # rehearsal with ranks sharing a card
+    else:
+        dist.broadcast(fq.q, src=0, group=shard.group)
+
+
+def analyse_fused_sharded(ctx, fq, nreads, shard):
+    """analyse_fused for one rank of a sharded file (`nreads` = this rank's reads, shard = uq_amd.dist.Shard): the layout was rank 0's guess
+    (broadcast_guess), every rank's pack kernel verified it on its own reads and ran its local qname_fused_finish.  Combined here:
+      * ok / flags / read counts / vmin / vmax of all ranks, and rank 0's early-checkpoint counts of the wide-range columns (reads
+        [0, 40 000] are rank 0's), in ONE all-gather of a few integers per rank;
+      * the small-range columns' first-occurrence tables (file-wide read numbers) in ONE all-reduce (MIN): the distinct counts at every
+        checkpoint of the FILE follow (uq.py:586-602, 634-638).
+    Every rank takes the same decisions from the same numbers.  None: some rank raised a flag, a column stays undecided (it would need
+    the distributed sort of its values) or a mapping of strings -- the caller runs analyse_device(shard=...), the exact sharded kernels."""
+    if shard is None or shard.world == 1:
+        return analyse_fused(ctx, fq, nreads)
+    t = ctx.torch
+    r = ops.qname_fused_fetch(ctx, fq)
+    n = int(nreads)
+    MAXC = 8
+    mine = [int(bool(r.ok)), int(r.flags != 0 or int(r.nreads) != n), n, int(r.nsep)]
+    mine += [int(r.vmin[c]) for c in range(MAXC)] + [int(r.vmax[c]) for c in range(MAXC)] + [int(r.undetermined[c]) for c in range(MAXC)]
+    mine += [int(r.counts[c][k]) for c in range(MAXC) for k in range(3)]
+    flat = [0] * (len(mine) * shard.world)
+    flat[shard.rank * len(mine):(shard.rank + 1) * len(mine)] = mine
+    allv = shard.reduce(flat, 'sum')
+    allv = [allv[q * len(mine):(q + 1) * len(mine)] for q in range(shard.world)]
+    have = [v for v in allv if v[2] > 0]                                   # ranks with reads
+    if not allv[0][0] or allv[0][2] == 0 or any(v[1] for v in have) or sum(v[2] for v in allv) != shard.total:
+        return None
+    ncols = allv[0][3] + 1
+    N = shard.total
+    thresholds = _thresholds(N)
+    gvmin = [min(v[4 + c] for v in have) for c in range(ncols)]
+    gvmax = [max(v[12 + c] for v in have) for c in range(ncols)]
+    n0 = allv[0][2]
+    small = [c for c in range(ncols) if gvmax[c] - gvmin[c] + 1 <= INT_RANGE_SMALL]
+    counts_small = {}
+    if small:
+        ranges = [gvmax[c] - gvmin[c] + 1 if c in small else 0 for c in range(ncols)]
+        first = ops.qname_fused_first_seen(ctx, fq, n, shard.read_offset, gvmin, ranges)
+        if shard.dist.get_backend(shard.group) == 'gloo' and first.is_cuda:
+            host = first.cpu(); shard.dist.all_reduce(host, op=shard.dist.ReduceOp.MIN, group=shard.group)
+        else:
+            shard.dist.all_reduce(first, op=shard.dist.ReduceOp.MIN, group=shard.group); host = first.cpu()
+        tab = host.numpy().reshape(MAXC, 4096)
+        for c in small:
+            row = tab[c][:ranges[c]]
+            counts_small[c] = [int((row <= T).sum()) for T in thresholds]
+    head = [T for T in thresholds if T < INT_PREFIX][:3]                   # the checkpoints the wide-range kernel looks at (qf_wide_kernel)
+    columns = []
+    for c in range(ncols):
+        vmin, vmax = gvmin[c], gvmax[c]
+        col = {'name': 'QNAME_%d' % (c + 1), 'format': 'mapping'}
+        if c in counts_small:
+            ths, counts = thresholds, counts_small[c]
+            nu = counts[-1]
+        else:
+            # rank 0 judged the column on reads [0, T], T = 10 000, 20 000, 40 000: the file's own first checkpoints when rank 0 holds them
+            # all and ran its wide-range kernel on this column; it fires there (flow-cell coordinates do) or the column stays undecided
+            r0 = allv[0]
+            if not head or n0 <= head[-1] or r0[12 + c] - r0[4 + c] + 1 <= INT_RANGE_SMALL or _thresholds(n0)[:len(head)] != head:
+                return None
+            ths, counts = head, [r0[28 + 3 * c + k] for k in range(len(head))]
+            fired = [k for k, (T, cnt) in enumerate(zip(ths, counts)) if cnt > T // 10]
+            if not fired:
+                return None
+            ths, counts, nu = ths[:fired[0] + 1], counts[:fired[0] + 1], None
+        for T, cnt in zip(ths, counts):
+            if cnt > T // 10:
+                col['format'] = 'integers'
+                break
+        if col['format'] == 'mapping':
+            lim, dt = _ladder(nu)
+            col['dtype'] = dt
+            if vmax - vmin > lim:
+                return None                                 # stays a mapping of strings: the exact path's sorted map
+            col['format'] = 'integers'; col['max'] = vmax; col['min'] = vmin
+            col['offset'] = bool(vmax > lim)
+        else:
+            col['min'] = vmin; col['max'] = vmax
+            lim, dt = _ladder(vmax - vmin)
+            col['dtype'] = dt
+            col['offset'] = bool(vmax > lim)
+        columns.append(col)
+    l1 = bytes(r.line1[:r.l1len]).decode('latin-1')
+    prefix = l1[:r.plen]
+    suffix = l1[r.l1len - r.slen:] if r.slen else ''
+    separators = bytes(r.seps[:r.nsep]).decode('latin-1')
+    arrays = ops.encode_u32_columns(ctx, fq, n, [c['min'] if c['offset'] else 0 for c in columns], [np.dtype(c['dtype']).itemsize for c in columns]) if n else \
+        [ctx.torch.empty(0, dtype=getattr(t, {1: 'uint8', 2: 'int16', 4: 'int32', 8: 'int64'}[np.dtype(c['dtype']).itemsize]), device=ctx.device) for c in columns]
+    return prefix, suffix, separators, columns, arrays
+
+
 def analyse_device(ctx, d_buf, d_ls, nreads, shard=None):
     """(prefix, suffix, separators, columns, device column tensors), or None -> use the host path."""
     lay = infer_layout_device(ctx, d_buf, d_ls, nreads, shard)
