@@ -101,6 +101,7 @@ def main():
     ap.add_argument('--sort-reads', type=int, default=200_000_000,
                     help='reads of the global --sort legs over ALL GPUs (strong scaling: 200 M / N per GPU; BASELINE configs[3] is 200 M over '
                          '8 GPUs); 0 = skip')
+    ap.add_argument('--no-e2e', action='store_true', help='skip the end-to-end record (N = 1: the CLI on a tmpfs file of the same workload, both ways)')
     ap.add_argument('--force-dist', action='store_true', help='initialise the process group and run the collectives even with one rank')
     ap.add_argument('--multi-pass', action='store_true',
                     help='round 1\'s step: census -> index -> statistics -> decisions -> pack, three reads of the stream (the default '
@@ -431,6 +432,15 @@ def main():
         del big
         torch.cuda.empty_cache()
 
+    # ---- end to end ("given twice -- kernel and end to end"): the drop-in CLI on a FILE of the same workload, both ways.  File system,
+    # PCIe and tar writing are all inside; this is never `value` (which has its input resident in HBM).
+    if world == 1 and not use_dist and args.workload == 'cfg2' and not args.no_e2e:
+        try:
+            result['end_to_end'] = end_to_end(ctx, args)
+        except OSError as e:                                   # (no room on the tmpfs of this box: say so instead of failing the line)
+            result['end_to_end'] = {'skipped': '%s: %s' % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
+
     # ---- the global --sort legs (the north_star's scaling claim: ">= 6x further at 8 GPUs for --sort DNA"; BASELINE configs[3] is
     # `--sort QUAL --raw DNA QUAL QNAME` over 8 GPUs).  STRONG scaling: args.sort_reads reads over all N GPUs (200 M / N each), so
     # that the N = 1 and N = 8 lines divide directly.  Table movements of the two mixes, through uq_amd.dist (N = 1: the same calls
@@ -444,6 +454,57 @@ def main():
         print(json.dumps(result), file=json_out, flush=True)
     if use_dist:
         dist.destroy_process_group()
+
+
+def end_to_end(ctx, args):
+    """BASELINE configs[1] through the CLI (uq_amd.uq.Session, what `python -m uq_amd.uq -i reads.fastq -o reads.uQ --sort None --raw DNA QUAL
+    QNAME --pattern 0.1 0.1` runs) from a file on tmpfs to a .uQ on tmpfs, and back to text; the decoded file must be the input."""
+    import tempfile
+    from uq_amd import ops, synth, uq
+    n = args.reads
+    d = ops.synth_fastq(ctx, synth.Spec(SEED, args.length), 0, n)
+    tmpdir = tempfile.mkdtemp(prefix='uq_e2e_', dir='/dev/shm' if os.path.isdir('/dev/shm') else None)
+    path, out, back = os.path.join(tmpdir, 'reads.fastq'), os.path.join(tmpdir, 'reads.uQ'), os.path.join(tmpdir, 'back.fastq')
+    try:
+        host = ctx.to_numpy(d)
+        host.tofile(path)
+        nbytes = int(host.size)
+        del d
+        flags = ['--sort', 'None', '--raw', 'DNA', 'QUAL', 'QNAME', '--pattern', '0.1', '0.1']
+        a = uq.validate_args(uq.build_parser().parse_args(['-i', path, '-o', out, '--quiet'] + flags))
+        s = uq.Session(a, ctx=ctx)
+        stages = {}
+
+        def lap(name, fn):
+            t = time.perf_counter(); fn(); ctx.sync(); stages[name] = round(time.perf_counter() - t, 4)
+
+        def run():
+            lap('file -> pinned -> HBM, census queued per chunk, guess, pack + statistics + QNAME fields', lambda: s.load(path))
+            lap('decisions from the whole file, QNAME columns', s.analyse)
+            lap('pack (kept: the guess held)', s.pack)
+            if a.sort is None: a.sort = (None,)
+            if a.raw is None: a.raw = (None,)
+            lap('members (--raw: the tables as they are)', lambda: s.run_mix(a.sort, a.raw, False))
+            lap('tar: HBM -> pinned -> pwrite', lambda: s.write_container(out))
+        t0 = time.perf_counter()
+        run()
+        enc = time.perf_counter() - t0
+        load_path, qpath = s.load_path, s.qname_path
+        del s
+        a2 = uq.validate_args(uq.build_parser().parse_args(['-i', out, '--decode', '--quiet']))
+        t0 = time.perf_counter()
+        with open(back, 'wb') as f:
+            uq.Session(a2, ctx=ctx).decode(out=f)
+        dec = time.perf_counter() - t0
+        same = bool(np.array_equal(np.fromfile(back, dtype=np.uint8), host))
+        if not same: raise RuntimeError('parity failure: decode(encode(file)) differs from the file')
+        return {'workload': 'BASELINE configs[1] through the CLI: %d x %dbp, a %.3f GB file on tmpfs -> .uQ on tmpfs (%.3f GB) -> text again' % (n, args.length, nbytes / 1e9, os.path.getsize(out) / 1e9),
+                'encode_s': round(enc, 3), 'decode_s': round(dec, 3), 'MBps': round(nbytes / 1e6 / enc, 1), 'decode_MBps': round(nbytes / 1e6 / dec, 1),
+                'stages_s': stages, 'encode_path': load_path, 'qname_path': qpath, 'decoded_file_is_the_input': same,
+                'note': 'file system, PCIe and tar writing included; never `value`'}
+    finally:
+        import shutil
+        shutil.rmtree(tmpdir, ignore_errors=True)
 
 
 def sort_legs(ctx, args, rank, world, use_dist, fence, fetch, red_dev):

@@ -54,7 +54,7 @@ def main():
         def lap(name, fn):
             t = time.perf_counter(); fn(); ctx.sync(); stages[name] = round(time.perf_counter() - t, 3)
 
-        lap('read_file+h2d+index', lambda: s.load(path))
+        lap('read_file+h2d+census+pack_stats_qname(queued)', lambda: s.load(path))
         lap('stats+decisions+qname', s.analyse)
         lap('pack', s.pack)
         if a.sort is None: a.sort = (None,)

@@ -145,33 +145,64 @@ class Session:
             census['c'].chunk(lo, n)
         chunked = self.io.chunk % (16 << 10) == 0
         d_buf = self.io.file_to_device(path, on_chunk=on_chunk if chunked else None)
-        self.load_device(d_buf, nlines=census['c'].end() if 'c' in census else None)
+        self.load_device(d_buf, census=census.get('c'))
 
-    def load_device(self, d_buf, nlines=None):
-        """The same for FASTQ bytes that are already in HBM (a uint8 device tensor): newline census, record index, pass-1
-        statistics -- the statistics counted by the pack kernel while it packs speculatively (see below), so the stream is read
-        twice.  --multi-pass: census -> index -> statistics -> pack as separate passes (three reads).  Same results whichever path."""
+    def load_device(self, d_buf, census=None):
+        """The same for FASTQ bytes that are already in HBM (a uint8 device tensor; `census`: an ops.ChunkedCensus of it whose chunks have
+        all been queued -- load() queues them behind the PCIe copies).  The default is the step bench.py times, queued back
+        to back: the census's closing scan (the line count stays on the device) -> the QNAME layout guess from a sample of the reads ->
+        pack + pass-1 statistics + QNAME fields in ONE kernel, with decisions guessed from the head of the file (a second context's
+        stream works them out beside the census) and verified afterwards against the whole file's counts.  NO record index is written:
+        the kernels walk the census's newline lists; `d_ls` is expanded on first use by whatever still wants it (the exact QNAME kernels,
+        the plain packers, the N-trick's first occurrences).  The stream is read twice.  --multi-pass: census -> index -> statistics ->
+        pack as separate passes (three reads).  Same results whichever path."""
         ops, ctx, args = self.ops, self.ctx, self.args
         self.d_buf = d_buf
         if not hasattr(self, '_host'): self.path, self._host = None, None
-        self._spec, self.load_path = None, 'multi-pass'
-        if nlines is None:                                                       # else: the census ran chunk by chunk during the load
+        self._spec, self._fq, self._d_ls, self.load_path = None, None, None, 'multi-pass'
+        nbytes = int(d_buf.numel())
+        nlines, queued, guess, cap = None, None, None, 0
+        if not getattr(args, 'multi_pass', False) and nbytes:
+            if census is None:
+                ctx.sync()                               # (whoever made the buffer may still be writing it: the guess's stream does not wait for this one)
+                census = ops.ChunkedCensus(ctx, d_buf)
+                census.chunk(0, nbytes)
+            census.end_async()
+            if getattr(self, 'side', None) is None:
+                from .device import SideContext
+                self.side = SideContext(ctx)            # the guess's small census / index / statistics must not touch the queued census's state
+            g = ops.head_guess(self.side, d_buf, notricks=args.notricks, pad=args.pad, head_bytes=ops.HEAD_BYTES_SMALL, head_reads=ops.HEAD_READS_INDEXED)
+            if g is not None:
+                guess, rpb = g
+                cap = int(nbytes * rpb * 1.02) + 1024
+                guess.avg_record_bytes = int(1.0 / rpb)
+                fq = None
+                if not getattr(args, 'host_qname', False) and not getattr(args, 'exact_qname', False):
+                    fq = ops.FusedQname(ctx, cap)
+                    ops.qname_guess_async(ctx, d_buf, None, fq)
+                queued = ops.pack_stats_async(ctx, d_buf, None, cap, guess, fq=fq)
+                if queued is not None and fq is not None: ops.qname_fused_finish(ctx, fq)
+            nlines, ok = census.wait()
+            if not ok:                                   # a tile with more newlines than a list holds (lines of a few bytes): the bitmap form
+                nlines, queued = ops.count_lines(ctx, d_buf), None
+        elif census is not None:
+            nlines = census.end()
+        if nlines is None:
             nlines = ops.count_lines(ctx, self.d_buf)
         if nlines % 4 != 0:
             error('ERROR: The FASTQ file provided contains' + str(nlines) + 'rows, which is not divisible by 4!')
         if nlines == 0: error('ERROR: empty input')
         self.total = nlines // 4
-        self.d_ls = ops.index_lines(ctx, self.d_buf, nlines)                 # record index
-        # pass-1 statistics.  Unless --multi-pass says otherwise they are counted by the PACK kernel (uq_pack_stats): it packs
-        # with decisions guessed from the first 8192 reads while it counts the (base, quality) codes it produces anyway, so
-        # the stream is read twice (census, pack) instead of three times; analyse() / _encode() keep the tables only if the
-        # decisions derived from the whole file's counts equal the guess (else uq_pack runs with the real ones), and counts
-        # the kernel could not complete (a symbol or a length outside the guess) are redone by the plain statistics pass.
-        # The same kernel takes the QNAME passes along (uq.py:394-444, 555-565, 717-736): the lines are in its LDS tiles anyway.  A
-        # layout guessed on the device from a sample of the reads is verified on every read while the fields are parsed
-        # (uq_qname_guess, uq_pack_stats_qname); analyse_qname() uses the result when no read raised a flag, else the exact passes.
-        self._fq = None
-        if not getattr(args, 'multi_pass', False):
+        if queued is not None and self.total <= cap:
+            n = self.total
+            self._spec = (guess, queued[0][:n * guess.dna_bytes_per_row], queued[1][:n * guess.quality_bytes_per_row], queued[2])
+            self.d_stats = queued[3]
+            self.load_path = 'two reads (census; pack + statistics), queued, no record index'
+            self._fq = fq
+        elif not getattr(args, 'multi_pass', False):
+            # the queued form does not hold for this file (more reads than the head promised, a head without a whole record, an alphabet
+            # without a fused kernel): the same two reads through the plain calls, with the index
+            del queued
             guess = ops.head_guess_indexed(ctx, self.d_buf, self.d_ls, self.total, args.notricks, args.pad)
             fq = None
             if guess is not None and not getattr(args, 'host_qname', False) and not getattr(args, 'exact_qname', False):
@@ -188,6 +219,17 @@ class Session:
         if self._spec is None:
             self.d_stats = ops.stats_new(ctx)
             ops.stats_accumulate(ctx, self.d_stats, self.d_buf, self.d_ls, 0, self.total)
+
+    @property
+    def d_ls(self):
+        """The record index (uint64 offset of every line start), expanded when somebody asks for it: the default encode never does."""
+        if getattr(self, '_d_ls', None) is None:
+            self._d_ls = self.ops.index_lines(self.ctx, self.d_buf, 4 * self.total)
+        return self._d_ls
+
+    @d_ls.setter
+    def d_ls(self, value):
+        self._d_ls = value
 
     @property
     def host(self):
