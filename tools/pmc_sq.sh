@@ -6,7 +6,7 @@ set -e
 tag=$1; pat=$2; shift; shift
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out
-mkdir -p $OUT
+mkdir -p $OUT $(dirname $OUT/$tag)
 cd /tmp && export TMPDIR=/tmp
 : > $OUT/${tag}_sq.txt
 i=0

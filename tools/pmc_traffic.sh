@@ -7,7 +7,7 @@ set -e
 tag=$1; pat=$2; shift; shift
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out
-mkdir -p $OUT
+mkdir -p $OUT $(dirname $OUT/$tag)
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c

@@ -70,31 +70,34 @@ __device__ __forceinline__ uint32_t pack4(uint32_t x) {
 }
 
 // LDS tile (16-byte aligned) -> global span, with the widest stores the destination alignment allows.
-__device__ __noinline__ void store_tile_any(uint8_t* gdst, const uint8_t* lsrc, uint32_t nb, uint32_t tid) {
+// CLEAR: every byte is zeroed right after the lane has read it (the variable-length dealing leaves the empty upper parts of the rows to that).
+template <bool CLEAR = false>
+__device__ __noinline__ void store_tile_any(uint8_t* gdst, uint8_t* lsrc, uint32_t nb, uint32_t tid) {
     const uint32_t mis = (uint32_t)(uintptr_t)gdst;
     if ((mis & 15) == 0) {
         const uint32_t nv = nb >> 4;
-        for (uint32_t i = tid; i < nv; i += 256) ((uint4*)gdst)[i] = ((const uint4*)lsrc)[i];
-        for (uint32_t i = (nv << 4) + tid; i < nb; i += 256) gdst[i] = lsrc[i];
+        for (uint32_t i = tid; i < nv; i += 256) { ((uint4*)gdst)[i] = ((const uint4*)lsrc)[i]; if (CLEAR) ((uint4*)lsrc)[i] = make_uint4(0, 0, 0, 0); }
+        for (uint32_t i = (nv << 4) + tid; i < nb; i += 256) { gdst[i] = lsrc[i]; if (CLEAR) lsrc[i] = 0; }
     } else if ((mis & 7) == 0) {
         const uint32_t nv = nb >> 3;
-        for (uint32_t i = tid; i < nv; i += 256) ((uint2*)gdst)[i] = ((const uint2*)lsrc)[i];
-        for (uint32_t i = (nv << 3) + tid; i < nb; i += 256) gdst[i] = lsrc[i];
+        for (uint32_t i = tid; i < nv; i += 256) { ((uint2*)gdst)[i] = ((const uint2*)lsrc)[i]; if (CLEAR) ((uint2*)lsrc)[i] = make_uint2(0, 0); }
+        for (uint32_t i = (nv << 3) + tid; i < nb; i += 256) { gdst[i] = lsrc[i]; if (CLEAR) lsrc[i] = 0; }
     } else if ((mis & 3) == 0) {
         const uint32_t nv = nb >> 2;
-        for (uint32_t i = tid; i < nv; i += 256) ((uint32_t*)gdst)[i] = ((const uint32_t*)lsrc)[i];
-        for (uint32_t i = (nv << 2) + tid; i < nb; i += 256) gdst[i] = lsrc[i];
+        for (uint32_t i = tid; i < nv; i += 256) { ((uint32_t*)gdst)[i] = ((const uint32_t*)lsrc)[i]; if (CLEAR) ((uint32_t*)lsrc)[i] = 0; }
+        for (uint32_t i = (nv << 2) + tid; i < nb; i += 256) { gdst[i] = lsrc[i]; if (CLEAR) lsrc[i] = 0; }
     } else {
-        for (uint32_t i = tid; i < nb; i += 256) gdst[i] = lsrc[i];
+        for (uint32_t i = tid; i < nb; i += 256) { gdst[i] = lsrc[i]; if (CLEAR) lsrc[i] = 0; }
     }
 }
 // The usual case inline -- R is a multiple of 16 wherever that wastes little, so a tile's rows start 16-byte aligned: a call costs two full
 // waits (the callee waits for everything in flight on entry -- the next tile's bytes -- and for its own stores before it returns).
-__device__ __forceinline__ void store_tile(uint8_t* gdst, const uint8_t* lsrc, uint32_t nb, uint32_t tid) {
+template <bool CLEAR = false>
+__device__ __forceinline__ void store_tile(uint8_t* gdst, uint8_t* lsrc, uint32_t nb, uint32_t tid) {
     if ((((uint32_t)(uintptr_t)gdst) & 15u) == 0 && (nb & 15u) == 0) {
 #pragma unroll 1
-        for (uint32_t i = tid; i < (nb >> 4); i += 256) ((uint4*)gdst)[i] = ((const uint4*)lsrc)[i];
-    } else store_tile_any(gdst, lsrc, nb, tid);
+        for (uint32_t i = tid; i < (nb >> 4); i += 256) { ((uint4*)gdst)[i] = ((const uint4*)lsrc)[i]; if (CLEAR) ((uint4*)lsrc)[i] = make_uint4(0, 0, 0, 0); }
+    } else store_tile_any<CLEAR>(gdst, lsrc, nb, tid);
 }
 
 // ---- the QNAME phase of the fused pack + statistics kernel (uq_pack_stats_qname; SURVEY.md 8 row f1 inside rows a3 / a4).
@@ -293,7 +296,9 @@ __global__ __launch_bounds__(256) void tile_origin_kernel(CensusView cv, const u
 // was the long pole of every tile: 2.10 ms against 1.38 ms without the QNAME phase; a fifth wave for the QNAME lines leaves the CU
 // with workgroups of five waves, of which it places three at a time where four of four waves fit: 2.0 - 2.5 ms.)  Built for four
 // workgroups per CU: the parser's registers come on top of a tile in flight.
-template <int BD, int BQ, bool NTRICK, bool FAST, bool STATS, bool QN, bool LISTS = false>
+// VAR (variable-length tables, the queued fused forms): the lanes of a read visit only the groups that hold a symbol or the sentinel; the
+// rows' empty upper parts (rows are sized for the longest read) are never stored -- the copy-out of the tile before has cleared the LDS image.
+template <int BD, int BQ, bool NTRICK, bool FAST, bool STATS, bool QN, bool LISTS = false, bool VAR = false>
 __global__ __launch_bounds__(PK_THREADS, (STATS && (NTRICK || QN)) ? 4 : 5) void pack_tile_kernel(const uint8_t* __restrict__ buf,
                                                                const uint64_t* __restrict__ ls, uint64_t first,
                                                                uint64_t n, PackLut lut, PackGeom g,
@@ -321,6 +326,7 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && (NTRICK || QN)) ? 4 : 5) void
     uint32_t fill_pairs = 0, n_pairs = 0;                        // pairs counted in bin 0 / bin n_code that were fills / N-trick positions
     constexpr uint32_t PKS_BINS = pks_bins(BD), PKS_WORDS = pks_words(BD);
     if (STATS) for (uint32_t i = tid; i < PKS_WORDS; i += PK_THREADS) cnt_tab[i] = 0;       // the first tile's barrier orders it
+    if (VAR) for (uint32_t i = tid; i < (g.out_bytes >> 4); i += PK_THREADS) ((uint4*)out_d)[i] = make_uint4(0, 0, 0, 0);       // (likewise; every copy-out clears what it reads)
     QnLds* qn = (QnLds*)(cnt_tab + pks_words(BD));                   // the QNAME phase's state (uq_pack_stats_qname only)
     bool qn_on = false;
     if (STATS && QN) qn_on = qf->ok != 0;                        // the guess kernels in front may have declined: the lines are left alone
@@ -435,6 +441,133 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && (NTRICK || QN)) ? 4 : 5) void
         if (ok) {
             // ---- B: P lanes per read; a lane owns groups of 8 consecutive symbols, both streams:
             //         characters -> codes -> bits (8 symbols of b bits = b whole bytes)
+            // one group of eight symbols of read r (length L, SEQ / QUAL lines at so / qo of the stage, the rows' last bytes at orow_d / orow_q):
+            // characters -> codes -> bits, counted (STATS), stored into the LDS image of the two tables
+            auto pack_group = [&](const uint32_t r, const uint32_t L, const uint32_t so, const uint32_t qo, uint8_t* orow_d, uint8_t* orow_q, const uint32_t gg) {
+                // symbols t = 8gg .. 8gg+7 (t counts from the END of the read) = characters j = L-1-t, i.e. the
+                // 8 bytes ending at position L - 8gg; byte k of the window is character j = j0 + k
+                const int32_t j0 = (int32_t)L - 8 * (int32_t)gg - 8;
+                uint64_t vd = 0, vq = 0;
+                if (j0 > -8) {      // else: the whole group lies above the read (rows are sized for the longest one): zeros
+                uint32_t b_lo, b_hi, q_lo, q_hi;
+                lds_window8(stage, (int32_t)so + j0, b_lo, b_hi);
+                lds_window8(stage, (int32_t)qo + j0, q_lo, q_hi);
+                if (j0 < 0) {   // window reaches above the first base: those symbols are zero (fill with code-0 characters)
+                    uint32_t mlo, mhi;
+                    window_masks((uint32_t)(-j0), mlo, mhi);
+                    b_lo = bfi(mlo, b_lo, g.fill_d); b_hi = bfi(mhi, b_hi, g.fill_d);
+                    q_lo = bfi(mlo, q_lo, g.fill_q); q_hi = bfi(mhi, q_hi, g.fill_q);
+                }
+                uint32_t ad0, ad1, aq0, aq1;      // 4 symbols each; *0 = the more significant half
+                bool generic = !FAST;
+                if (FAST) {
+                    uint32_t c0, c1, e0, e1;                     // codes, and (non-zero byte) = not a base of the alphabet
+                    if constexpr (BD == 2) {
+                        c0 = acgt_codes(b_lo); c1 = acgt_codes(b_hi);
+                        e0 = acgt_chars(c0) ^ b_lo; e1 = acgt_chars(c1) ^ b_hi;
+                    } else {                                     // up to eight bases told apart by three bits of their characters
+                        c0 = __builtin_amdgcn_perm(g.i2c_hi, g.i2c_lo, (b_lo >> g.h_shift) & 0x07070707u);
+                        c1 = __builtin_amdgcn_perm(g.i2c_hi, g.i2c_lo, (b_hi >> g.h_shift) & 0x07070707u);
+                        e0 = __builtin_amdgcn_perm(g.c2c_hi, g.c2c_lo, c0) ^ b_lo; e1 = __builtin_amdgcn_perm(g.c2c_hi, g.c2c_lo, c1) ^ b_hi;
+                    }
+                    uint32_t u0 = q_lo + g.q_addlo, u1 = q_hi + g.q_addlo;
+                    uint32_t bq0 = (q_lo | (q_lo + g.q_addhi) | ~u0) & 0x80808080u;
+                    uint32_t bq1 = (q_hi | (q_hi + g.q_addhi) | ~u1) & 0x80808080u;
+                    uint32_t x0 = u0 & 0x7F7F7F7Fu, x1 = u1 & 0x7F7F7F7Fu;
+                    if (e0 | e1) {
+                        if (NTRICK && !((q_lo | q_hi) & 0x80808080u)) {
+                            const uint32_t m0 = nonzero_bytes(e0), m1 = nonzero_bytes(e1);
+                            if (((b_lo ^ g.n_char) & m0) | ((b_hi ^ g.n_char) & m1)) generic = true;   // not the N-trick base
+                            c0 &= ~m0; c1 &= ~m1;
+                            x0 = bfi(m0, g.n_code, x0); x1 = bfi(m1, g.n_code, x1);
+                            bq0 &= ~m0; bq1 &= ~m1;
+                        } else generic = true;
+                    }
+                    if (bq0 | bq1) generic = true;
+                    ad0 = pack4<BD>(c0); ad1 = pack4<BD>(c1);
+                    aq0 = pack4<BQ>(x0); aq1 = pack4<BQ>(x1);
+                    if (STATS) {
+                        if (generic) incomplete = true;          // a symbol outside the guess: not counted here
+                        else {
+                            uint8_t* hb = (uint8_t*)cnt_tab + ((lane_id() & (PKS_COPIES - 1)) << 2);
+                            if constexpr (BD == 2) {
+                                const uint32_t bin0 = (c0 << 6) | x0, bin1 = (c1 << 6) | x1;    // BQ <= 6 and two bits of base: a bin per byte
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) {
+                                    atomicAdd((uint32_t*)(hb + (((bin0 >> (8 * k)) & 0xFFu) * (4 * PKS_COPIES))), 1u);
+                                    atomicAdd((uint32_t*)(hb + (((bin1 >> (8 * k)) & 0xFFu) * (4 * PKS_COPIES))), 1u);
+                                }
+                            } else {                                                            // three bits of base: nine bits of bin, pair by pair
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) {
+                                    const uint32_t b0 = (((c0 >> (8 * k)) & 7u) << 6) | ((x0 >> (8 * k)) & 63u), b1 = (((c1 >> (8 * k)) & 7u) << 6) | ((x1 >> (8 * k)) & 63u);
+                                    atomicAdd((uint32_t*)(hb + b0 * (4 * PKS_COPIES)), 1u);
+                                    atomicAdd((uint32_t*)(hb + b1 * (4 * PKS_COPIES)), 1u);
+                                }
+                            }
+                            if (j0 < 0) fill_pairs += (uint32_t)(-j0);
+                            if (NTRICK && (e0 | e1)) {
+                                // the N-trick base's own pairs: the guess says it occurs with ONE quality character (that is what
+                                // makes it an N-trick base); positions that bear it are counted in a register, byte-parallel, and a
+                                // position with any other quality makes the guess wrong: incomplete, the exact pass decides
+                                const uint32_t m0 = nonzero_bytes(e0), m1 = nonzero_bytes(e1);
+                                const uint32_t ne0 = nonzero_bytes(q_lo ^ g.n_qchar), ne1 = nonzero_bytes(q_hi ^ g.n_qchar);
+                                n_pairs += (uint32_t)__popc(m0 & 0x01010101u) + (uint32_t)__popc(m1 & 0x01010101u);
+                                if ((m0 & ne0) | (m1 & ne1)) incomplete = true;
+                            }
+                        }
+                    }
+                }
+                if (generic) {
+                    const uint32_t cbw[2] = {b_lo, b_hi};
+                    const uint32_t cqw[2] = {q_lo, q_hi};
+                    uint32_t ad[2] = {0, 0}, aq[2] = {0, 0};
+                    int32_t orall = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const uint32_t cb = (cbw[k >> 2] >> (8 * (k & 3))) & 255u;
+                        const uint32_t cc = (cqw[k >> 2] >> (8 * (k & 3))) & 255u;
+                        int32_t dc = l_dna[cb];
+                        int32_t qc = l_qual[cc];
+                        if (NTRICK) {
+                            if (dc < 0) { dc = 0; qc = l_nq[cb]; }
+                        }
+                        orall |= dc | qc;
+                        ad[k >> 2] = (ad[k >> 2] << BD) | (uint32_t)dc;
+                        aq[k >> 2] = (aq[k >> 2] << BQ) | (uint32_t)qc;
+                    }
+                    if (orall < 0) {            // a character without a code: report, keep the row deterministic
+                        badr = badr < (uint32_t)(r0 + r) ? badr : (uint32_t)(r0 + r);
+                        ad[0] = ad[1] = aq[0] = aq[1] = 0;
+                    }
+                    ad0 = ad[0]; ad1 = ad[1]; aq0 = aq[0]; aq1 = aq[1];
+                }
+                vd = ((uint64_t)ad0 << (4 * BD)) | ad1;
+                vq = ((uint64_t)aq0 << (4 * BQ)) | aq1;
+                }
+                if (g.variable) {                                  // sentinel = code 1 at symbol index t = L
+                    const int32_t i = (int32_t)L - 8 * (int32_t)gg;
+                    if (i >= 0 && i < 8) { vd |= 1ull << (BD * i); vq |= 1ull << (BQ * i); }
+                }
+                // byte index counts from the row's LAST byte; only the top group can stick out of the row
+                uint8_t* od = orow_d - BD * gg;
+                uint8_t* oq = orow_q - BQ * gg;
+                if (gg + 1 < g.G) {
+                    // byte stores: unaligned ds_write_b32 / b16 pieces are accepted by gfx950 but slower (1.11 -> 1.27 ms)
+#pragma unroll
+                    for (int i = 0; i < BD; ++i) od[-i] = (uint8_t)(vd >> (8 * i));
+#pragma unroll
+                    for (int i = 0; i < BQ; ++i) oq[-i] = (uint8_t)(vq >> (8 * i));
+                } else {
+                    const uint32_t nd = g.Cd - BD * gg, nq = g.Cq - BQ * gg;     // bytes left in the row from here up
+#pragma unroll
+                    for (int i = 0; i < BD; ++i)
+                        if ((uint32_t)i < nd) od[-i] = (uint8_t)(vd >> (8 * i));
+#pragma unroll
+                    for (int i = 0; i < BQ; ++i)
+                        if ((uint32_t)i < nq) oq[-i] = (uint8_t)(vq >> (8 * i));
+                }
+            };
             if (rr < Rt) {
                 const uint32_t r = rr;
                 const uint32_t so = meta[4 * r + 1];
@@ -448,142 +581,21 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && (NTRICK || QN)) ? 4 : 5) void
                 if (L > g.dna_max || meta[4 * r + 4] - qo - 1 != L) { badr = badr < (uint32_t)(r0 + r) ? badr : (uint32_t)(r0 + r); L = 0; }
                 uint8_t* orow_d = out_d + r * g.Cd + (g.Cd - 1);
                 uint8_t* orow_q = out_q + r * g.Cq + (g.Cq - 1);
-                for (uint32_t gg = pp; gg < g.G; gg += g.P) {
-                    // symbols t = 8gg .. 8gg+7 (t counts from the END of the read) = characters j = L-1-t, i.e. the
-                    // 8 bytes ending at position L - 8gg; byte k of the window is character j = j0 + k
-                    const int32_t j0 = (int32_t)L - 8 * (int32_t)gg - 8;
-                    uint64_t vd = 0, vq = 0;
-                    if (j0 > -8) {      // else: the whole group lies above the read (rows are sized for the longest one): zeros
-                    uint32_t b_lo, b_hi, q_lo, q_hi;
-                    lds_window8(stage, (int32_t)so + j0, b_lo, b_hi);
-                    lds_window8(stage, (int32_t)qo + j0, q_lo, q_hi);
-                    if (j0 < 0) {   // window reaches above the first base: those symbols are zero (fill with code-0 characters)
-                        uint32_t mlo, mhi;
-                        window_masks((uint32_t)(-j0), mlo, mhi);
-                        b_lo = bfi(mlo, b_lo, g.fill_d); b_hi = bfi(mhi, b_hi, g.fill_d);
-                        q_lo = bfi(mlo, q_lo, g.fill_q); q_hi = bfi(mhi, q_hi, g.fill_q);
-                    }
-                    uint32_t ad0, ad1, aq0, aq1;      // 4 symbols each; *0 = the more significant half
-                    bool generic = !FAST;
-                    if (FAST) {
-                        uint32_t c0, c1, e0, e1;                     // codes, and (non-zero byte) = not a base of the alphabet
-                        if constexpr (BD == 2) {
-                            c0 = acgt_codes(b_lo); c1 = acgt_codes(b_hi);
-                            e0 = acgt_chars(c0) ^ b_lo; e1 = acgt_chars(c1) ^ b_hi;
-                        } else {                                     // up to eight bases told apart by three bits of their characters
-                            c0 = __builtin_amdgcn_perm(g.i2c_hi, g.i2c_lo, (b_lo >> g.h_shift) & 0x07070707u);
-                            c1 = __builtin_amdgcn_perm(g.i2c_hi, g.i2c_lo, (b_hi >> g.h_shift) & 0x07070707u);
-                            e0 = __builtin_amdgcn_perm(g.c2c_hi, g.c2c_lo, c0) ^ b_lo; e1 = __builtin_amdgcn_perm(g.c2c_hi, g.c2c_lo, c1) ^ b_hi;
-                        }
-                        uint32_t u0 = q_lo + g.q_addlo, u1 = q_hi + g.q_addlo;
-                        uint32_t bq0 = (q_lo | (q_lo + g.q_addhi) | ~u0) & 0x80808080u;
-                        uint32_t bq1 = (q_hi | (q_hi + g.q_addhi) | ~u1) & 0x80808080u;
-                        uint32_t x0 = u0 & 0x7F7F7F7Fu, x1 = u1 & 0x7F7F7F7Fu;
-                        if (e0 | e1) {
-                            if (NTRICK && !((q_lo | q_hi) & 0x80808080u)) {
-                                const uint32_t m0 = nonzero_bytes(e0), m1 = nonzero_bytes(e1);
-                                if (((b_lo ^ g.n_char) & m0) | ((b_hi ^ g.n_char) & m1)) generic = true;   // not the N-trick base
-                                c0 &= ~m0; c1 &= ~m1;
-                                x0 = bfi(m0, g.n_code, x0); x1 = bfi(m1, g.n_code, x1);
-                                bq0 &= ~m0; bq1 &= ~m1;
-                            } else generic = true;
-                        }
-                        if (bq0 | bq1) generic = true;
-                        ad0 = pack4<BD>(c0); ad1 = pack4<BD>(c1);
-                        aq0 = pack4<BQ>(x0); aq1 = pack4<BQ>(x1);
-                        if (STATS) {
-                            if (generic) incomplete = true;          // a symbol outside the guess: not counted here
-                            else {
-                                uint8_t* hb = (uint8_t*)cnt_tab + ((lane_id() & (PKS_COPIES - 1)) << 2);
-                                if constexpr (BD == 2) {
-                                    const uint32_t bin0 = (c0 << 6) | x0, bin1 = (c1 << 6) | x1;    // BQ <= 6 and two bits of base: a bin per byte
-#pragma unroll
-                                    for (int k = 0; k < 4; ++k) {
-                                        atomicAdd((uint32_t*)(hb + (((bin0 >> (8 * k)) & 0xFFu) * (4 * PKS_COPIES))), 1u);
-                                        atomicAdd((uint32_t*)(hb + (((bin1 >> (8 * k)) & 0xFFu) * (4 * PKS_COPIES))), 1u);
-                                    }
-                                } else {                                                            // three bits of base: nine bits of bin, pair by pair
-#pragma unroll
-                                    for (int k = 0; k < 4; ++k) {
-                                        const uint32_t b0 = (((c0 >> (8 * k)) & 7u) << 6) | ((x0 >> (8 * k)) & 63u), b1 = (((c1 >> (8 * k)) & 7u) << 6) | ((x1 >> (8 * k)) & 63u);
-                                        atomicAdd((uint32_t*)(hb + b0 * (4 * PKS_COPIES)), 1u);
-                                        atomicAdd((uint32_t*)(hb + b1 * (4 * PKS_COPIES)), 1u);
-                                    }
-                                }
-                                if (j0 < 0) fill_pairs += (uint32_t)(-j0);
-                                if (NTRICK && (e0 | e1)) {
-                                    // the N-trick base's own pairs: the guess says it occurs with ONE quality character (that is what
-                                    // makes it an N-trick base); positions that bear it are counted in a register, byte-parallel, and a
-                                    // position with any other quality makes the guess wrong: incomplete, the exact pass decides
-                                    const uint32_t m0 = nonzero_bytes(e0), m1 = nonzero_bytes(e1);
-                                    const uint32_t ne0 = nonzero_bytes(q_lo ^ g.n_qchar), ne1 = nonzero_bytes(q_hi ^ g.n_qchar);
-                                    n_pairs += (uint32_t)__popc(m0 & 0x01010101u) + (uint32_t)__popc(m1 & 0x01010101u);
-                                    if ((m0 & ne0) | (m1 & ne1)) incomplete = true;
-                                }
-                            }
-                        }
-                    }
-                    if (generic) {
-                        const uint32_t cbw[2] = {b_lo, b_hi};
-                        const uint32_t cqw[2] = {q_lo, q_hi};
-                        uint32_t ad[2] = {0, 0}, aq[2] = {0, 0};
-                        int32_t orall = 0;
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) {
-                            const uint32_t cb = (cbw[k >> 2] >> (8 * (k & 3))) & 255u;
-                            const uint32_t cc = (cqw[k >> 2] >> (8 * (k & 3))) & 255u;
-                            int32_t dc = l_dna[cb];
-                            int32_t qc = l_qual[cc];
-                            if (NTRICK) {
-                                if (dc < 0) { dc = 0; qc = l_nq[cb]; }
-                            }
-                            orall |= dc | qc;
-                            ad[k >> 2] = (ad[k >> 2] << BD) | (uint32_t)dc;
-                            aq[k >> 2] = (aq[k >> 2] << BQ) | (uint32_t)qc;
-                        }
-                        if (orall < 0) {            // a character without a code: report, keep the row deterministic
-                            badr = badr < (uint32_t)(r0 + r) ? badr : (uint32_t)(r0 + r);
-                            ad[0] = ad[1] = aq[0] = aq[1] = 0;
-                        }
-                        ad0 = ad[0]; ad1 = ad[1]; aq0 = aq[0]; aq1 = aq[1];
-                    }
-                    vd = ((uint64_t)ad0 << (4 * BD)) | ad1;
-                    vq = ((uint64_t)aq0 << (4 * BQ)) | aq1;
-                    }
-                    if (g.variable) {                                  // sentinel = code 1 at symbol index t = L
-                        const int32_t i = (int32_t)L - 8 * (int32_t)gg;
-                        if (i >= 0 && i < 8) { vd |= 1ull << (BD * i); vq |= 1ull << (BQ * i); }
-                    }
-                    // byte index counts from the row's LAST byte; only the top group can stick out of the row
-                    uint8_t* od = orow_d - BD * gg;
-                    uint8_t* oq = orow_q - BQ * gg;
-                    if (gg + 1 < g.G) {
-                        // byte stores: unaligned ds_write_b32 / b16 pieces are accepted by gfx950 but slower (1.11 -> 1.27 ms)
-#pragma unroll
-                        for (int i = 0; i < BD; ++i) od[-i] = (uint8_t)(vd >> (8 * i));
-#pragma unroll
-                        for (int i = 0; i < BQ; ++i) oq[-i] = (uint8_t)(vq >> (8 * i));
-                    } else {
-                        const uint32_t nd = g.Cd - BD * gg, nq = g.Cq - BQ * gg;     // bytes left in the row from here up
-#pragma unroll
-                        for (int i = 0; i < BD; ++i)
-                            if ((uint32_t)i < nd) od[-i] = (uint8_t)(vd >> (8 * i));
-#pragma unroll
-                        for (int i = 0; i < BQ; ++i)
-                            if ((uint32_t)i < nq) oq[-i] = (uint8_t)(vq >> (8 * i));
-                    }
-                }
+                // VAR: only the groups that hold a symbol or the sentinel -- the rows' empty upper parts are zero already: every copy-out clears what
+                // it reads (rows are sized for the LONGEST read: 38 group slots for 21.5 groups on average at 36 - 301 bp)
+                const uint32_t gend = VAR ? (((L + 8) >> 3) < g.G ? ((L + 8) >> 3) : g.G) : g.G;
+                for (uint32_t gg = pp; gg < gend; gg += g.P) pack_group(r, L, so, qo, orow_d, orow_q, gg);
             }
         }
         __syncthreads();
         if (ok) {
             // ---- C: coalesced stores of the two packed tiles (widest vector the tile's byte offset allows)
             if constexpr (STATS && (NTRICK || QN)) {            // (the forms built for four workgroups per CU have the registers for the inline loop)
-                store_tile(dna + r0 * g.Cd, out_d, Rt * g.Cd, tid);
-                store_tile(qual + r0 * g.Cq, out_q, Rt * g.Cq, tid);
+                store_tile<VAR>(dna + r0 * g.Cd, out_d, Rt * g.Cd, tid);
+                store_tile<VAR>(qual + r0 * g.Cq, out_q, Rt * g.Cq, tid);
             } else {
-                store_tile_any(dna + r0 * g.Cd, out_d, Rt * g.Cd, tid);
-                store_tile_any(qual + r0 * g.Cq, out_q, Rt * g.Cq, tid);
+                store_tile_any<VAR>(dna + r0 * g.Cd, out_d, Rt * g.Cd, tid);
+                store_tile_any<VAR>(qual + r0 * g.Cq, out_q, Rt * g.Cq, tid);
             }
         }
     };
@@ -705,13 +717,17 @@ PackKernel pick_nt(bool ntrick, bool fast) {
 }
 
 // the fused pack + statistics kernels exist for the lookup-free path only (2-bit A/C/G/T, contiguous qualities)
-template <int BD, bool QN, bool LISTS = false>
+template <int BD, bool QN, bool LISTS = false, bool VAR = false>
 PackKernel pick_stats_kernel_q(int bq, bool ntrick) {
-#define UQ_PS(B) case B: return ntrick ? pack_tile_kernel<BD, B, true, true, true, QN, LISTS> : pack_tile_kernel<BD, B, false, true, true, QN, LISTS>;
-    switch (bq) { UQ_PS(1) UQ_PS(2) UQ_PS(3) UQ_PS(4) UQ_PS(5) default: return ntrick ? pack_tile_kernel<BD, 6, true, true, true, QN, LISTS> : pack_tile_kernel<BD, 6, false, true, true, QN, LISTS>; }
+#define UQ_PS(B) case B: return ntrick ? pack_tile_kernel<BD, B, true, true, true, QN, LISTS, VAR> : pack_tile_kernel<BD, B, false, true, true, QN, LISTS, VAR>;
+    switch (bq) { UQ_PS(1) UQ_PS(2) UQ_PS(3) UQ_PS(4) UQ_PS(5) default: return ntrick ? pack_tile_kernel<BD, 6, true, true, true, QN, LISTS, VAR> : pack_tile_kernel<BD, 6, false, true, true, QN, LISTS, VAR>; }
 #undef UQ_PS
 }
-PackKernel pick_stats_kernel(int bd, int bq, bool ntrick, bool qn, bool lists) {
+PackKernel pick_stats_kernel(int bd, int bq, bool ntrick, bool qn, bool lists, bool var) {
+    if (var && lists) {                           // variable lengths in the queued forms: the dealing of phase B (VAR)
+        if (qn) return bd == 3 ? pick_stats_kernel_q<3, true, true, true>(bq, ntrick) : pick_stats_kernel_q<2, true, true, true>(bq, ntrick);
+        return bd == 3 ? pick_stats_kernel_q<3, false, true, true>(bq, ntrick) : pick_stats_kernel_q<2, false, true, true>(bq, ntrick);
+    }
     if (qn && lists) return bd == 3 ? pick_stats_kernel_q<3, true, true>(bq, ntrick) : pick_stats_kernel_q<2, true, true>(bq, ntrick);
     if (lists) return bd == 3 ? pick_stats_kernel_q<3, false, true>(bq, ntrick) : pick_stats_kernel_q<2, false, true>(bq, ntrick);
     if (bd == 3) return qn ? pick_stats_kernel_q<3, true>(bq, ntrick) : pick_stats_kernel_q<3, false>(bq, ntrick);
@@ -878,10 +894,11 @@ static int pack_impl(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_s
     }
     if (d_stats && ntrick_bases == 1 && hp->n_qual[nchar] >= nq) return 0;    // the N-trick code is no quality of the alphabet (Q9): exact kernels only
     if (d_stats && (!fast || (bd != 2 && bd != 3) || bq > 6)) return 0;  // the fused kernels exist for the lookup-free paths (2- / 3-bit bases, <= 64 contiguous qualities) only
+    const bool var_deal = d_stats && use_lists && hp->variable;
     const size_t lds = 16 + (size_t)g.stage_bytes + g.out_bytes + (4 * R + 4) * 4 + 3 * 512 + (d_stats ? pks_words((int)bd) * 4 + sizeof(QnLds) : 0);
     UQ_REQUIRE(lds <= 160 * 1024, "uq_pack: tile needs %zu bytes of LDS", lds);
     const uint64_t tiles = (nreads + R - 1) / R;
-    PackKernel k = d_stats ? pick_stats_kernel((int)bd, (int)bq, ntrick, d_q != nullptr, use_lists) : pick_kernel((int)bd, (int)bq, ntrick, fast);
+    PackKernel k = d_stats ? pick_stats_kernel((int)bd, (int)bq, ntrick, d_q != nullptr, use_lists, var_deal) : pick_kernel((int)bd, (int)bq, ntrick, fast);
     if (lds > 48 * 1024) UQ_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // persistent workgroups: exactly as many as are resident at once (LDS and registers both limit that: a grid sized from the LDS
     // alone would leave the kernels built for four waves per SIMD with a second, quarter-full round of workgroups)
