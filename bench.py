@@ -355,20 +355,23 @@ def main():
     state, d, nreads, fastq_bytes, kernel = m['state'], m['d'], m['nreads'], m['fastq_bytes'], m['kernel']
     two_reads = kernel.startswith('pack_tile_kernel<STATS')
 
-    traffic = None
-    tpath = os.path.join(HERE, 'profiles', 'pack_stats_traffic.json' if two_reads else 'pack_traffic.json')
-    if os.path.exists(tpath):
+    def measured_traffic(workload, reads, form):
+        """HBM bytes per launch of the step's pack kernel from the PMC passes on record (profiles/pack_stats_traffic.json: rocprofv3 --pmc FETCH_SIZE /
+        WRITE_SIZE in separate passes, tools/pmc_traffic.sh + tools/update_traffic.py), not from this run: an entry is only quoted while the kernel's
+        source is byte for byte the one it was measured on."""
+        tpath = os.path.join(HERE, 'profiles', 'pack_stats_traffic.json')
         try:
-            tj = json.load(open(tpath))
-            # counters are taken in separate rocprofv3 --pmc passes (tools/pmc_traffic.sh), not in this run: the figure is only
-            # quoted while the kernel's source is byte for byte the one it was measured on
             import hashlib
-            same_kernel = hashlib.sha256(open(os.path.join(HERE, tj['kernel_source']), 'rb').read()).hexdigest() == tj['kernel_source_sha256']
-            if args.workload == 'cfg2' and tj.get('reads') == nreads and tj.get('length') == args.length and same_kernel and \
-               tj.get('kernel_form', '') == ('qname' if qname_in_step else 'plain'):
-                traffic = tj.get('hbm_bytes_per_launch')
+            tj = json.load(open(tpath))
+            sha = hashlib.sha256(open(os.path.join(HERE, tj['kernel_source']), 'rb').read()).hexdigest()
+            for e in tj.get('entries', []):
+                if e['kernel_source_sha256'] == sha and e['workload'] == workload and e['reads'] == reads and e['kernel_form'] == form:
+                    return e['hbm_bytes_per_launch']
         except Exception:
-            traffic = None
+            pass
+        return None
+
+    traffic = measured_traffic(args.workload, nreads, 'qname' if qname_in_step else 'plain') if two_reads and args.length == 150 else None
 
     mode = ((' [TWO reads of the stream, queued back to back (the line count stays on the device): census' + (' + index' if m['indexed'] else ' (no record index: the kernels walk its newline lists)') +
              ', then pack + statistics in one kernel with decisions guessed from the shard\'s first '
@@ -426,7 +429,8 @@ def main():
             'workload': 'the same step over %d x %dbp (%.1f GB of FASTQ resident in HBM), 3 timed steps after 2 warm-up steps' % (big['nreads'], args.length, big['fastq_bytes'] / 1e9),
             'ms_per_step': round(big['dt_step'] * 1e3, 3), 'value': round(big['total_bytes'] / 1e6 / big['dt_step'], 1), 'unit': 'MB/s',
             'reads_per_s': round(big['total_reads'] / big['dt_step'], 1), 'qname_path': big['state'].get('qname_path'),
-            'step_frac_of_8TBps': round(big['step_bytes'] / 1e9 / big['dt_step'] / HBM_PEAK_GBS, 4), 'roofline': roofline_of(big)}
+            'step_frac_of_8TBps': round(big['step_bytes'] / 1e9 / big['dt_step'] / HBM_PEAK_GBS, 4),
+            'roofline': roofline_of(big, measured_traffic('cfg2', big['nreads'], 'qname' if qname_in_step else 'plain') if args.length == 150 else None)}
         if 'cpu_baseline' in result:
             result['north_star_200M']['times_cpu_baseline'] = round(result['north_star_200M']['value'] / result['cpu_baseline']['value'], 1)
         del big

@@ -39,6 +39,9 @@ class Context:
         h = C.c_void_p()
         call('uq_ctx_create', int(device), C.c_void_p(self.stream.cuda_stream), C.byref(h))
         self.h = h
+        import os
+        if os.environ.get('UQ_MSD_MIN_ROWS'):              # hunts: every row sort's round 0 as the MSD partition (1) or never (-1); default 2^18 rows
+            call('uq_sort_config', self.h, int(os.environ['UQ_MSD_MIN_ROWS']), None, 0)
 
     def close(self):
         if self.h:
