@@ -251,11 +251,12 @@ __global__ __launch_bounds__(MT) void msd_chunk_bounds_kernel(const uint32_t* __
 
 // memcmp order of two rows of C bytes, taken by a sub-wave of eight lanes (t = lane & 7, sub = lane & 56): every lane fetches sixteen bytes of
 // each row -- a row of 113 bytes is one request of eight neighbouring lanes instead of fifteen dependent 8-byte loads of one --, the lowest
-// lane whose piece differs decides.  The piece that would hang over the row's end is the sixteen bytes that END the row (the overlap is
+// lane whose piece differs decides (LPG = 4 lanes a sub-wave for rows of up to 64 bytes: twice the groups in flight).  The piece that would hang over the row's end is the sixteen bytes that END the row (the overlap is
 // compared twice: if it differs, so does the piece in front, which wins).  Returns the same value (< 0, 0, > 0) in all eight lanes; the
 // eight lanes must be in the same control flow.
+template <int LPG = 8>
 __device__ __forceinline__ int msd_row_cmp8(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, uint32_t C, uint32_t t, uint32_t sub) {
-    for (uint32_t base = 0; base < C; base += 128) {
+    for (uint32_t base = 0; base < C; base += 16 * LPG) {
         const uint32_t off = base + 16 * t;
         int c = 0;
         if (C >= 16) {
@@ -270,7 +271,7 @@ __device__ __forceinline__ int msd_row_cmp8(const uint8_t* __restrict__ a, const
         } else if (t == 0) {
             for (uint32_t i = 0; i < C && c == 0; ++i) c = a[i] == b[i] ? 0 : (a[i] < b[i] ? -1 : 1);
         }
-        const uint32_t mine = (uint32_t)(__ballot(c != 0) >> sub) & 0xFFu;
+        const uint32_t mine = (uint32_t)(__ballot(c != 0) >> sub) & ((1u << LPG) - 1u);
         if (mine) return __shfl(c, (int)(sub + (uint32_t)__ffs((int)mine) - 1u), 64);
     }
     return 0;
@@ -415,16 +416,22 @@ __global__ __launch_bounds__(MT) void msd_finish_kernel(const K* __restrict__ ke
 // strictly greater ones and the slice starts in row order --, then heads[j] = 1 (a new row value) or 2 (equal to the row in front, final).
 // Groups of more than 32 rows keep their 0 flags for the caller's refinement rounds (*leftover is raised).  A group's first position keeps
 // its flag 1 throughout: the sub-wave of the group in front may be looking for its end.
+template <int LPG>
 __global__ __launch_bounds__(MT) void msd_ties_kernel(const uint8_t* __restrict__ table, uint32_t C, uint32_t n, uint32_t* __restrict__ perm,
                                                       uint8_t* __restrict__ heads, const uint32_t* __restrict__ tie_list,
                                                       const uint32_t* __restrict__ tie_count, uint32_t nchunks, uint32_t* __restrict__ leftover) {
-    const uint32_t lane = threadIdx.x & 63u, t = lane & 7u, sub = lane & 56u;
+    constexpr uint32_t LM = (1u << LPG) - 1u;                 // a sub-wave's lanes in a ballot, shifted down
+    constexpr uint32_t CB8 = 8;                               // chunks a workgroup takes at a time: their lists, one behind the other, keep every sub-wave busy
+    const uint32_t lane = threadIdx.x & 63u, t = lane & (LPG - 1), sub = lane & ~(uint32_t)(LPG - 1);
     constexpr int U = 2;
-    // a workgroup per chunk's list (finish left them per chunk: no counter that every workgroup of the device would queue on)
-    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
-    const uint32_t ngroups = tie_count[c];
-    const uint32_t* __restrict__ list = tie_list + (uint64_t)c * (MSD_CAP / 2);
-    for (uint32_t g0 = (threadIdx.x >> 3) * U; g0 < ngroups; g0 += (MT / 8) * U) {
+    // (finish left the lists per chunk: no counter that every workgroup of the device would queue on)
+    for (uint32_t c0 = blockIdx.x * CB8; c0 < nchunks; c0 += gridDim.x * CB8) {
+    uint32_t pre[CB8 + 1];
+    pre[0] = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < CB8; ++k) pre[k + 1] = pre[k] + (c0 + k < nchunks ? tie_count[c0 + k] : 0u);
+    const uint32_t ngroups = pre[CB8];
+    for (uint32_t g0 = (threadIdx.x / LPG) * U; g0 < ngroups; g0 += (MT / LPG) * U) {
         uint32_t jj[U], kk[U], xa[U], xb[U];
         uint64_t a0[U], a1[U], b0[U], b1[U];
         const uint32_t off = 16 * t;
@@ -435,16 +442,19 @@ __global__ __launch_bounds__(MT) void msd_ties_kernel(const uint8_t* __restrict_
             const uint32_t g = g0 + u;
             jj[u] = 0; kk[u] = 0; xa[u] = xb[u] = 0; a0[u] = a1[u] = b0[u] = b1[u] = 0;
             if (g < ngroups) {
-                const uint32_t j = list[g];
+                uint32_t kc = 0;
+#pragma unroll
+                for (uint32_t k = 1; k < CB8; ++k) kc += g >= pre[k] ? 1u : 0u;
+                const uint32_t j = tie_list[(uint64_t)(c0 + kc) * (MSD_CAP / 2) + (g - pre[kc])];
                 jj[u] = j;
                 // the group's length: lane t looks at position j + 1 + t; the first position that is not open ends the group
                 uint32_t len = 1;
-                for (uint32_t basep = j + 1; ; basep += 8) {
+                for (uint32_t basep = j + 1; ; basep += LPG) {
                     const uint32_t pos = basep + t;
                     const bool open = pos < n && heads[pos] == 0;
-                    const uint32_t closed = (uint32_t)(__ballot(!open) >> sub) & 0xFFu;
+                    const uint32_t closed = (uint32_t)(__ballot(!open) >> sub) & LM;
                     if (closed) { len += (uint32_t)__ffs((int)closed) - 1u; break; }
-                    len += 8;
+                    len += LPG;
                     if (len > MSD_SEG_MAX) break;
                 }
                 kk[u] = len;
@@ -466,37 +476,44 @@ __global__ __launch_bounds__(MT) void msd_ties_kernel(const uint8_t* __restrict_
             if (len > MSD_SEG_MAX) { if (t == 0) *leftover = 1u; continue; }
             if (len == 2) {                                   // nearly every group: one comparison settles the order and the flag
                 int cm;                                       // memcmp(row xb, row xa)
-                if (C >= 16 && C <= 128) {
+                if (C >= 16 && C <= 16 * LPG) {
                     int c = 0;
                     if (b0[u] != a0[u]) c = __builtin_bswap64(b0[u]) < __builtin_bswap64(a0[u]) ? -1 : 1;
                     else if (b1[u] != a1[u]) c = __builtin_bswap64(b1[u]) < __builtin_bswap64(a1[u]) ? -1 : 1;
-                    const uint32_t mine = (uint32_t)(__ballot(c != 0) >> sub) & 0xFFu;
+                    const uint32_t mine = (uint32_t)(__ballot(c != 0) >> sub) & LM;
                     cm = mine ? __shfl(c, (int)(sub + (uint32_t)__ffs((int)mine) - 1u), 64) : 0;
-                } else cm = msd_row_cmp8(table + (uint64_t)xb[u] * C, table + (uint64_t)xa[u] * C, C, t, sub);
+                } else cm = msd_row_cmp8<LPG>(table + (uint64_t)xb[u] * C, table + (uint64_t)xa[u] * C, C, t, sub);
                 if (t == 0) {
                     if (cm < 0) { perm[j] = xb[u]; perm[j + 1] = xa[u]; }
                     heads[j + 1] = cm == 0 ? (uint8_t)2 : (uint8_t)1;
                 }
                 continue;
             }
-            // a longer group: its row numbers in the sub-wave's registers (lane t holds entries t, t + 8, t + 16, t + 24)
-            uint32_t e[4];
+            // a longer group: its row numbers in the sub-wave's registers (lane t holds entries t, t + LPG, t + 2 LPG, ...)
+            constexpr int EW = (MSD_SEG_MAX + LPG - 1) / LPG;
+            uint32_t e[EW];
 #pragma unroll
-            for (int w = 0; w < 4; ++w) e[w] = (t + 8 * w) < len ? perm[j + t + 8 * w] : 0u;
-            auto entry = [&](uint32_t i) -> uint32_t {      // entry i of the group, the same value in all eight lanes
-                const uint32_t w = i >> 3;
-                const uint32_t v = w == 0 ? e[0] : w == 1 ? e[1] : w == 2 ? e[2] : e[3];
-                return __shfl(v, (int)(sub + (i & 7u)), 64);
+            for (int w = 0; w < EW; ++w) e[w] = (t + LPG * w) < len ? perm[j + t + LPG * w] : 0u;
+            auto entry = [&](uint32_t i) -> uint32_t {      // entry i of the group, the same value in all lanes of the sub-wave
+                const uint32_t w = i / LPG;
+                uint32_t v = 0;
+#pragma unroll
+                for (int q = 0; q < EW; ++q) v = w == (uint32_t)q ? e[q] : v;
+                return __shfl(v, (int)(sub + (i & (LPG - 1))), 64);
             };
             auto put = [&](uint32_t i, uint32_t x) {
-                if (t == (i & 7u)) { const uint32_t w = i >> 3; if (w == 0) e[0] = x; else if (w == 1) e[1] = x; else if (w == 2) e[2] = x; else e[3] = x; }
+                const uint32_t w = i / LPG;
+                if (t == (i & (LPG - 1))) {
+#pragma unroll
+                    for (int q = 0; q < EW; ++q) e[q] = w == (uint32_t)q ? x : e[q];
+                }
             };
             for (uint32_t i = 1; i < len; ++i) {
                 const uint32_t x = entry(i);
                 uint32_t tt = i;
                 while (tt > 0) {
                     const uint32_t y = entry(tt - 1);
-                    if (msd_row_cmp8(table + (uint64_t)x * C, table + (uint64_t)y * C, C, t, sub) >= 0) break;
+                    if (msd_row_cmp8<LPG>(table + (uint64_t)x * C, table + (uint64_t)y * C, C, t, sub) >= 0) break;
                     put(tt, y);
                     --tt;
                 }
@@ -506,12 +523,12 @@ __global__ __launch_bounds__(MT) void msd_ties_kernel(const uint8_t* __restrict_
             uint32_t dupmask = 0;                             // bit i: entry i equals entry i - 1
             for (uint32_t i = 1; i < len; ++i) {
                 const uint32_t x = entry(i);
-                if (msd_row_cmp8(table + (uint64_t)x * C, table + (uint64_t)prev * C, C, t, sub) == 0) dupmask |= 1u << i;
+                if (msd_row_cmp8<LPG>(table + (uint64_t)x * C, table + (uint64_t)prev * C, C, t, sub) == 0) dupmask |= 1u << i;
                 prev = x;
             }
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const uint32_t i = t + 8 * w;
+            for (int w = 0; w < EW; ++w) {
+                const uint32_t i = t + LPG * w;
                 if (i < len) { perm[j + i] = e[w]; if (i > 0) heads[j + i] = ((dupmask >> i) & 1u) ? (uint8_t)2 : (uint8_t)1; }
             }
         }
@@ -630,7 +647,9 @@ static int msd_round0_impl(uq_ctx* ctx, const uint8_t* table, uint32_t C, uint64
     if (rows) {
         msd_finish_kernel<K, true><<<fgrid, MT, 0, s>>>(kin, vin, bound, nchunks, perm, heads, misc + 1, tie_list, tie_cnt);
         UQ_LAUNCH_CHECK();
-        msd_ties_kernel<<<nchunks < UQ_NUM_CU * 8 ? nchunks : UQ_NUM_CU * 8, MT, 0, s>>>(table, C, (uint32_t)n, perm, heads, tie_list, tie_cnt, nchunks, misc + 2);
+        const uint32_t tgrid = (nchunks + 7) / 8 < UQ_NUM_CU * 8 ? (nchunks + 7) / 8 : UQ_NUM_CU * 8;
+        if (C <= 64) msd_ties_kernel<4><<<tgrid, MT, 0, s>>>(table, C, (uint32_t)n, perm, heads, tie_list, tie_cnt, nchunks, misc + 2);
+        else msd_ties_kernel<8><<<tgrid, MT, 0, s>>>(table, C, (uint32_t)n, perm, heads, tie_list, tie_cnt, nchunks, misc + 2);
     } else msd_finish_kernel<K, false><<<fgrid, MT, 0, s>>>(kin, vin, bound, nchunks, perm, heads, misc + 1, nullptr, nullptr);
     UQ_LAUNCH_CHECK();
     UQ_TRY(uq_read_back(ctx, ctx->h_pinned, misc, 16));
