@@ -35,6 +35,11 @@ struct uq_ctx {
     // threshold, < 0 = never); msd_levels > 0: the digits of its levels instead of the automatic plan; how many sorts went which way
     long long msd_min_rows; int msd_levels; int msd_bits[4];
     unsigned long long n_msd_rounds, n_lsd_rounds;
+    // per-context caches of what used to be function statics (a second context on another device, or on another thread, must not share them):
+    // register counts of the pack kernels by kernel pointer (the persistent grid is sized from them), and whether this context's device has had
+    // qf_wide_kernel's dynamic LDS limit raised
+    const void* kreg_key[8]; int kreg_val[8]; int kreg_n;
+    bool qf_attr_set;
 };
 
 void uq_set_error(const char* fmt, ...);

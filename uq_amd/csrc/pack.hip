@@ -906,11 +906,14 @@ static int pack_impl(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_s
     {
         // (computed from the kernel's register count: hipOccupancyMaxActiveBlocksPerMultiprocessor is one workgroup per CU high for
         // kernels with 97-112 SGPRs on this ROCm -- MI355X_MICROARCH.md, Correctness boundaries -- which these are)
-        static PackKernel cached_k = nullptr; static int cached_regs = 0;
-        if (cached_k != k) {
+        int cached_regs = 0;
+        for (int i = 0; i < ctx->kreg_n; ++i) if (ctx->kreg_key[i] == (const void*)k) cached_regs = ctx->kreg_val[i];
+        if (cached_regs == 0) {
             hipFuncAttributes fa;
             UQ_CHECK_HIP(hipFuncGetAttributes(&fa, (const void*)k));
-            cached_k = k; cached_regs = fa.numRegs;
+            cached_regs = fa.numRegs > 0 ? fa.numRegs : 128;
+            const int slot = ctx->kreg_n < 8 ? ctx->kreg_n++ : 7;                  // (a context alternates between two or three instances)
+            ctx->kreg_key[slot] = (const void*)k; ctx->kreg_val[slot] = cached_regs;
         }
         const uint32_t alloc = ((uint32_t)(cached_regs > 0 ? cached_regs : 128) + 7) & ~7u;          // VGPRs are handed out in eights
         uint32_t waves_per_simd = 512 / alloc; if (waves_per_simd > 8) waves_per_simd = 8; if (waves_per_simd < 1) waves_per_simd = 1;

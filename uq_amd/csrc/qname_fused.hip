@@ -461,8 +461,7 @@ extern "C" int uq_qname_fused_finish(uq_ctx* ctx, uq_qname_fused* d_q, const uin
     UQ_LAUNCH_CHECK();
     qf_count_kernel<<<dim3(4, UQ_QF_MAXC), QF_THREADS, 0, ctx->stream>>>(d_q, (const uint32_t*)scr);
     UQ_LAUNCH_CHECK();
-    static bool attr_set = false;
-    if (!attr_set) { UQ_CHECK_HIP(hipFuncSetAttribute((const void*)qf_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(QF_FT / 8))); attr_set = true; }
+    if (!ctx->qf_attr_set) { UQ_CHECK_HIP(hipFuncSetAttribute((const void*)qf_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(QF_FT / 8))); ctx->qf_attr_set = true; }
     qf_wide_kernel<<<UQ_QF_MAXC, QF_THREADS, QF_FT / 8, ctx->stream>>>(d_q, d_vals, vals_pitch);
     UQ_LAUNCH_CHECK();
     // the structure is sent on its way to the host right away (a region of the pinned staging that nothing else uses):
