@@ -203,6 +203,13 @@ def main():
                 census.chunk(0, fastq_bytes)
                 census.end_async()
                 g = ops.head_guess(side, d_buf, notricks=notricks, head_bytes=ops.HEAD_BYTES_SMALL, head_reads=ops.HEAD_READS_INDEXED)
+                if g is None and use_dist and qname_in_step:
+                    # N > 1: the broadcast of rank 0's layout guess is a collective -- a rank without a guess of its own takes part all the same
+                    # (its flag makes every rank stand down together in analyse_fused_sharded)
+                    from uq_amd import qname_device
+                    fq = ops.FusedQname(ctx, 16)
+                    if rank == 0: fq.q.zero_()                                  # ok = 0: no layout
+                    qname_device.broadcast_guess(ctx, fq, shard)
                 if g is not None:
                     guess, rpb = g
                     cap_reads = int(fastq_bytes * rpb * 1.02) + 1024
@@ -269,7 +276,10 @@ def main():
             qpath, qres = None, None
             if qname_in_step:
                 from uq_amd import qname_device
-                qres = qname_device.analyse_fused_sharded(ctx, fq, nreads, shard) if (fq is not None and spec is not None) else None
+                if use_dist:                    # collective: a rank whose own pass did not hold says so inside, and every rank stands down with it
+                    qres = qname_device.analyse_fused_sharded(ctx, fq, nreads, shard, usable=spec is not None and queued is not None)
+                else:
+                    qres = qname_device.analyse_fused(ctx, fq, nreads) if (fq is not None and spec is not None) else None
                 qpath = 'fused into the pack kernel' + (' (rank 0\'s layout guess broadcast, every rank verifies; flags / ranges / first occurrences combined over the ranks)' if use_dist else '')
                 if qres is None:
                     ls = index()

@@ -43,7 +43,7 @@ def main():
     packed = ops.pack_stats(ctx, buf, ls, 0, n, guess, fq=fq) if n and guess is not None else None
     if packed is not None: ops.qname_fused_finish(ctx, fq)
     # (a rank whose pack kernel did not run reports it through its flags: nreads != n)
-    res = qname_device.analyse_fused_sharded(ctx, fq, n if packed is not None or n == 0 else -1, shard)
+    res = qname_device.analyse_fused_sharded(ctx, fq, n, shard, usable=packed is not None or n == 0)
     out = None
     if res is not None:
         pre, suf, sep, cols, arrs = res

@@ -306,24 +306,29 @@ def broadcast_guess(ctx, fq, shard):
         dist.broadcast(fq.q, src=0, group=shard.group)
 
 
-def analyse_fused_sharded(ctx, fq, nreads, shard):
+def analyse_fused_sharded(ctx, fq, nreads, shard, usable=True):
     """analyse_fused for one rank of a sharded file (`nreads` = this rank's reads, shard = uq_amd.dist.Shard): the layout was rank 0's guess
     (broadcast_guess), every rank's pack kernel verified it on its own reads and ran its local qname_fused_finish.  Combined here:
       * ok / flags / read counts / vmin / vmax of all ranks, and rank 0's early-checkpoint counts of the wide-range columns (reads
         [0, 40 000] are rank 0's), in ONE all-gather of a few integers per rank;
       * the small-range columns' first-occurrence tables (file-wide read numbers) in ONE all-reduce (MIN): the distinct counts at every
         checkpoint of the FILE follow (uq.py:586-602, 634-638).
-    Every rank takes the same decisions from the same numbers.  None: some rank raised a flag, a column stays undecided (it would need
+    Every rank takes the same decisions from the same numbers, and every rank MUST call this (it is collective): a rank whose own pass is
+    not usable -- no speculative pack, a declined guess, tables beyond their capacity -- passes usable=False and says so in the all-gather.
+    None: some rank raised a flag, a column stays undecided (it would need
     the distributed sort of its values) or a mapping of strings -- the caller runs analyse_device(shard=...), the exact sharded kernels."""
     if shard is None or shard.world == 1:
         return analyse_fused(ctx, fq, nreads)
     t = ctx.torch
-    r = ops.qname_fused_fetch(ctx, fq)
     n = int(nreads)
     MAXC = 8
-    mine = [int(bool(r.ok)), int(r.flags != 0 or int(r.nreads) != n), n, int(r.nsep)]
-    mine += [int(r.vmin[c]) for c in range(MAXC)] + [int(r.vmax[c]) for c in range(MAXC)] + [int(r.undetermined[c]) for c in range(MAXC)]
-    mine += [int(r.counts[c][k]) for c in range(MAXC) for k in range(3)]
+    if usable and fq is not None:
+        r = ops.qname_fused_fetch(ctx, fq)
+        mine = [int(bool(r.ok)), int(r.flags != 0 or int(r.nreads) != n), n, int(r.nsep)]
+        mine += [int(r.vmin[c]) for c in range(MAXC)] + [int(r.vmax[c]) for c in range(MAXC)] + [int(r.undetermined[c]) for c in range(MAXC)]
+        mine += [int(r.counts[c][k]) for c in range(MAXC) for k in range(3)]
+    else:
+        mine = [0, 1, n, 0] + [0] * (3 * MAXC + 3 * MAXC)
     flat = [0] * (len(mine) * shard.world)
     flat[shard.rank * len(mine):(shard.rank + 1) * len(mine)] = mine
     allv = shard.reduce(flat, 'sum')
