@@ -371,6 +371,60 @@ def test_pack_stats_fused(ctx, name, n, length, kw, dk):
     assert ops.same_pack_params(p, p)
 
 
+DEFAULT_FORM_CASES = FUSED_CASES + [
+    ('var_long_tail', 6000, (36, 301), dict(n_rate=1), {}),                       # (several tiles per workgroup: the LDS image is cleared by the copy-out, tile after tile)
+    ('var_mostly_short', 4000, (1, 40), dict(n_rate=1), {}),
+    ('var_two_lengths', 3000, (149, 150), {}, {}),                                # rows with one empty slot at most
+    ('fixed_len8', 3000, 8, {}, {}), ('var_9_to_17', 3000, (9, 17), dict(n_rate=2), dict(notricks=True)),
+]
+
+
+@pytest.mark.parametrize('qn', [False, True], ids=['plain', 'qname-phase'])
+@pytest.mark.parametrize('name,n,length,kw,dk', DEFAULT_FORM_CASES, ids=[c[0] for c in DEFAULT_FORM_CASES])
+def test_default_encode_form_against_the_oracle(ctx, name, n, length, kw, dk, qn):
+    """The kernel the product runs by default -- census lists instead of a record index, pack + statistics (+ QNAME fields) in one launch,
+    the variable-length instances that skip a row's empty groups -- DIRECTLY against the C oracle (test_pack_stats_fused
+    compares HIP with HIP): packed rows == oracle_c.pack, counts and ranges == oracle_c.stats, QNAME columns == the oracle's."""
+    spec = synth.Spec(S + 61, length, **kw)
+    host = synth.fastq_array(spec, n)
+    hls = oracle_c.index_lines(host)
+    ref = oracle_c.stats(host, hls, 0, n)
+    d = _decide_from_stats(type('H', (), dict(counts=ref['counts'], len_min=ref['len_min'], len_max=ref['len_max'], nz_keys=None))(), **dk)
+    rd, rq, rbad = oracle_c.pack(host, hls, 0, n, d['bases'], d['qualities'], d['N_qual'], d['bits_per_base'], d['bits_per_quality'],
+                                 d['variable_read_lengths'], d['dna_bytes_per_row'], d['quality_bytes_per_row'])
+    assert rbad is None
+    p = ops.make_pack_params(d['bases'], d['qualities'], d['N_qual'], d['bits_per_base'], d['bits_per_quality'], d['variable_read_lengths'],
+                             d['dna_bytes_per_row'], d['quality_bytes_per_row'], d['dna_max'], ref['max_record_bytes'], avg_record_bytes=host.size // n)
+    for rep in range(2):                                                          # twice: the second launch starts from the first one's LDS
+        ops.scribble_lds(ctx, 0x5EED0000 + rep) if rep == 0 else None
+        d_buf = ctx.to_device(host)
+        cen = ops.ChunkedCensus(ctx, d_buf); cen.chunk(0, d_buf.numel()); cen.end_async()
+        fq = None
+        if qn:
+            fq = ops.FusedQname(ctx, n + 7)
+            ops.qname_guess_async(ctx, d_buf, None, fq)
+        q = ops.pack_stats_async(ctx, d_buf, None, n + 7, p, fq=fq)
+        assert q is not None
+        if qn: ops.qname_fused_finish(ctx, fq)
+        hs = ops.stats_fetch(ctx, q[3])
+        nl, ok = cen.wait()
+        if not ok: pytest.skip('more than 1024 newlines in a census tile: the queued form stands down (covered elsewhere)')
+        assert nl == 4 * n and not hs.incomplete
+        assert np.array_equal(hs.counts, ref['counts']) and (hs.len_min, hs.len_max, hs.max_record_bytes) == (ref['len_min'], ref['len_max'], ref['max_record_bytes'])
+        assert np.array_equal(ctx.to_numpy(q[0][:n * d['dna_bytes_per_row']]).reshape(n, -1), rd), 'DNA rows differ from the oracle'
+        assert np.array_equal(ctx.to_numpy(q[1][:n * d['quality_bytes_per_row']]).reshape(n, -1), rq), 'QUAL rows differ from the oracle'
+        assert ops.bad_index(q[2]) is None
+        if qn:
+            from uq_amd import qname_device
+            got = qname_device.analyse_fused(ctx, fq, n)
+            lines = O.read_lines(host.tobytes())
+            p1 = O.pass1(lines)
+            ocols = O.qname_columns(lines, p1['prefix'], p1['suffix'], p1['separators'])
+            oarr = O.qname_encode(lines, p1['prefix'], p1['suffix'], p1['separators'], ocols)
+            assert got is not None and list(got[:3]) == [p1['prefix'], p1['suffix'], p1['separators']] and got[3] == ocols
+            for a, b in zip(got[4], oarr): assert np.array_equal(ctx.to_numpy(a, b.dtype), b)
+
+
 def test_pack_stats_wrong_guesses(ctx):
     """A wrong guess never goes unnoticed: the statistics stay exact (or say they are incomplete) and differ from the guess."""
     n = 4000
