@@ -3,7 +3,7 @@
 //
 // A table of n rows needs about log2(n) bits of sorting, not 32 or 64.  The rows' heads (their first eight bytes behind the z leading
 // bits every row shares, as a big-endian number; the top 32 bits of that for tables that do not crowd on them) are partitioned
-// MSD-first on T = log2(n / 256) .. bits in two or three levels of at most eight bits, then every run of neighbouring buckets that fits
+// MSD-first on T = log2(n / 64) bits in two or three levels of at most eight bits, then every run of neighbouring buckets that fits
 // a workgroup's LDS is put in its final order there:
 //   extract   rows -> keys, the level-1 histogram, AND / OR over all heads (the check of z)                    reads the row heads once
 //   level l   per-parent histograms of the next digit (count: reads the keys), exclusive scan = the buckets' first slots, then the
@@ -15,6 +15,10 @@
 //             binned by the key's position in the chunk's key range, ranked inside the bin by counting.  Row number as the tie-break
 //             IS the stable order (uq.py's argsort under the Q17 rule), whatever the levels did.  The head flags (key differs from the
 //             key in front) fall out of the same counting loop.
+//   ties      rows wider than the key: the positions where a group of equal keys starts are listed per chunk by the finishing kernel;
+//             msd_ties_kernel sorts each group by whole rows, a sub-wave of four or eight lanes per pair of rows (every lane fetches
+//             sixteen bytes of each row), and sets the final flags (1 = a new row value, 2 = equal to the row in front).
+// (tools/variants.sh msd.hip <name> -DMSD_ABL=2 builds the finishing kernel without its rank loop: the ablation DESIGN.md section 11 quotes.)
 // Tables whose buckets come out heavier than a chunk (few distinct heads: QNAME columns, a read copied a million times) are
 // reported back (*status = 1) before the last scatter and take the LSD passes as before.
 #include "radix.h"
