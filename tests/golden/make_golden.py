@@ -195,6 +195,22 @@ def rename(fastq_bytes, name_of):
     return b'\n'.join(lines)
 
 
+def custom(n, length, bases, quals, seed, special=None):
+    """A FASTQ of n reads over the given alphabets (numpy's legacy RandomState: the same bytes on every numpy): names @c:<i % 7>:<1000 + i>; variable
+    lengths avoid multiples of four (Q7).  `special(i, seq, qual, rng)` may edit a read."""
+    import numpy as np
+    rng = np.random.RandomState(seed)
+    out = []
+    for i in range(n):
+        l = length if isinstance(length, int) else int(rng.randint(length[0], length[1] + 1))
+        if not isinstance(length, int) and l % 4 == 0: l += 1 if l < length[1] else -1
+        s = ''.join(bases[int(x)] for x in rng.randint(0, len(bases), size=l))
+        q = ''.join(quals[int(x)] for x in rng.randint(0, len(quals), size=l))
+        if special: s, q = special(i, s, q, rng)
+        out.append('@c:%d:%d\n%s\n+\n%s\n' % (i % 7, 1000 + i, s, q))
+    return ''.join(out).encode('latin-1')
+
+
 def case_refuses(name):
     """Cases named *_refused are inputs the reference gives up on (exit message or exception): the fixture is the refusal."""
     return name.endswith('_refused')
@@ -297,6 +313,29 @@ def cases():
     nt = synth.fastq(S + 28, 500, 45, n_rate=3, dup='dna', dup_templates=25)
     yield 'notricks_keyed', nt, ['--notricks', '--sort', 'None', '--pattern', '1.1', '2.2'], False
     yield 'notricks_sort_dna_keyed_stable', nt, ['--notricks', '--sort', 'DNA', '--pattern', '3.2', '2.1'], True
+
+    # ---- round 4: alphabets and widths (uq.py:448-457, 477-545).  The synthetic generator only makes ACGT(N) with 41 qualities: 2- / 3-bit bases, 6-bit
+    # qualities.  24. eleven IUPAC bases -> 4-bit DNA, 30 qualities -> 5 bits; the same sorted and keyed
+    iupac = custom(300, 33, 'ACGTNRYKMSW', [chr(33 + k) for k in range(30)], 1)
+    yield 'alpha_iupac_4bit', iupac, RAW, False
+    yield 'alpha_iupac_sort_dna_keyed_stable', custom(300, 33, 'ACGTNRYKMSW', [chr(33 + k) for k in range(30)], 8), ['--sort', 'DNA', '--pattern', '1.1', '0.2'], True
+    # 25. 70 qualities -> 7 bits; 133 qualities (bytes beyond 127 among them) -> 8 bits
+    yield 'qual_7bit', custom(300, 29, 'ACGT', [chr(33 + k) for k in range(70)], 2), RAW, False
+    yield 'qual_8bit', custom(300, 21, 'ACGT', [chr(33 + k) for k in range(93)] + [chr(161 + k) for k in range(40)], 3), RAW, False
+    # 26. TWO N-trick bases (uq.py:480-494): N always with '!' and nothing else has '!' (its code is that quality's index), X always with '#' which
+    #     other bases share (a NEW quality code, Q9); the order of the two is the order of first appearance (Q11)
+    def two_ntrick(i, s, q, rng):
+        s, q = list(s), list(q)
+        for k in range(len(s)):
+            if rng.rand() < 0.03: s[k] = 'N'; q[k] = '!'
+            elif rng.rand() < 0.03: s[k] = 'X'; q[k] = '#'
+            elif q[k] == '!': q[k] = '$'
+        return ''.join(s), ''.join(q)
+    yield 'two_ntrick_bases', custom(400, 41, 'ACGT', [chr(35 + k) for k in range(20)], 4, two_ntrick), RAW, False
+    # 27. one base and one quality (2 bits each, the ladder's floor); upper and lower case (eight bases -> 3 bits); three bases and three qualities, variable lengths
+    yield 'one_base_one_qual', custom(50, 10, 'A', 'I', 5), RAW, False
+    yield 'alpha_mixed_case', custom(300, 37, 'ACGTacgt', [chr(40 + k) for k in range(12)], 6), RAW, False
+    yield 'var_tiny_alphabets', custom(300, (5, 23), 'ACG', '#5I', 7), RAW, False
 
 
 if __name__ == '__main__':

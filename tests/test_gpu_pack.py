@@ -278,7 +278,8 @@ def test_pack_reports_uncoded_symbol(ctx):
     assert ops.bad_index(bad) == 1
 
 
-@pytest.mark.parametrize('name', ['cfg1_10k_100bp', 'fixed_n_newcode', 'variable_ntrick', 'variable_notricks', 'fixed_pad'])
+@pytest.mark.parametrize('name', ['cfg1_10k_100bp', 'fixed_n_newcode', 'variable_ntrick', 'variable_notricks', 'fixed_pad', 'alpha_iupac_4bit', 'qual_7bit', 'qual_8bit',
+                                  'two_ntrick_bases', 'one_base_one_qual', 'alpha_mixed_case', 'var_tiny_alphabets'])
 def test_pack_matches_reference_golden(ctx, name):
     """DNA.raw / QUAL.raw written by the reference itself (tests/golden/*.uQ) == the HIP packers' rows."""
     meta = json.load(open(os.path.join(GOLD, name + '.json')))

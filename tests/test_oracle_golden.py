@@ -15,6 +15,7 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 GOLDEN = sorted(os.path.basename(f)[:-5] for f in glob.glob(os.path.join(GOLD, '*.json')))
 REFUSED = [n for n in GOLDEN if n.endswith('_refused')]        # inputs the reference itself gives up on: the fixture is the refusal
 WRITTEN = [n for n in GOLDEN if n not in REFUSED]
+Q9 = ['fixed_n_newcode', 'two_ntrick_bases']                   # a NEW N quality code (uq.py:493-494): no decoder can read these files back, the reference's included
 
 
 def flags_to_kwargs(flags):
@@ -32,7 +33,7 @@ def flags_to_kwargs(flags):
 
 
 def test_golden_set_is_complete():
-    assert len(WRITTEN) >= 32 and len(REFUSED) >= 6
+    assert len(WRITTEN) >= 40 and len(REFUSED) >= 6
     for name in GOLDEN:
         for ext in ('.fastq', '.json') + (() if name in REFUSED else ('.uQ',)):
             assert os.path.exists(os.path.join(GOLD, name + ext))
@@ -52,6 +53,16 @@ def test_golden_set_covers_more_than_one_qname_grammar():
             fmts.add(c['format']); dtypes.add(c['dtype']); offsets.add(c.get('offset'))
     assert seps >= set(': _-=;') and fmts == {'integers', 'mapping'} and dtypes >= {'uint8', 'uint16', 'uint32', 'uint64'}
     assert len(suffixes) >= 3 and {True, False} <= offsets and len(ncols) >= 4
+
+
+def test_golden_set_covers_the_width_ladder():
+    """... and the alphabets: every DNA width from 2 to 4 bits and every QUAL width from 2 to 8 occurs in a reference-written container (uq.py:497-503,
+    534-540), with and without N-trick bases, two of them at once included (Q11: order of first appearance; Q9: a new quality code)."""
+    bd, bq, ntrick = set(), set(), set()
+    for name in WRITTEN:
+        cfg, _ = O.read_tar(os.path.join(GOLD, name + '.uQ'))
+        bd.add(cfg['bits_per_base']); bq.add(cfg['bits_per_quality']); ntrick.add(len(cfg['N_qual']))
+    assert bd >= {2, 3, 4} and bq >= {2, 4, 5, 6, 7, 8} and ntrick >= {0, 1, 2}, (bd, bq, ntrick)
 
 
 @pytest.mark.parametrize('name', REFUSED)
@@ -188,7 +199,7 @@ def test_fixtures_regenerate_from_the_reference(tmp_path):
     assert sorted(names) == GOLDEN or os.environ.get('UQ_SKIP_SLOW_GOLDEN')
 
 
-@pytest.mark.parametrize('name', [n for n in WRITTEN if n != 'fixed_n_newcode'])
+@pytest.mark.parametrize('name', [n for n in WRITTEN if n not in Q9])
 def test_oracle_decode_roundtrip(name):
     fq = open(os.path.join(GOLD, name + '.fastq'), 'rb').read()
     ref_cfg, ref_members = O.read_tar(os.path.join(GOLD, name + '.uQ'))
