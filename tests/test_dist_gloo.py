@@ -352,7 +352,7 @@ def _load_job(rank, world, path, slack):
     import fake_decode_ops as F
     from uq_amd import dist_encode, uq
     dist_encode.SLACK = slack
-    args = uq.validate_args(uq.build_parser().parse_args(['-i', path, '--quiet']))
+    args = uq.validate_args(uq.build_parser().parse_args(['-i', path, '--quiet', '--multi-pass']))      # (the numpy stand-ins cover the separate passes; the queued fused step is the GPU suite's)
     s = dist_encode.ShardedSession(args, ctx=F.FakeCtx())
     s.io, s.ops = F.FakeIO(), F.FakeLoadOps()
     try:

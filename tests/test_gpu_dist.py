@@ -23,12 +23,12 @@ def _free_port():
     s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _run_sharded(world, inp, out, flags, backend='gloo'):
+def _run_sharded(world, inp, out, flags, backend='gloo', extra_env=None):
     port = _free_port()
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1',
-                   MASTER_PORT=str(port), UQ_DIST_BACKEND=backend, PYTHONPATH=REPO)
+                   MASTER_PORT=str(port), UQ_DIST_BACKEND=backend, PYTHONPATH=REPO, **(extra_env or {}))
         procs.append(subprocess.Popen([sys.executable, '-m', 'uq_amd.dist_encode', '-i', str(inp), '-o', str(out), '--quiet'] + flags,
                                       env=env, cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = []
@@ -40,6 +40,7 @@ def _run_sharded(world, inp, out, flags, backend='gloo'):
             raise
         logs.append(o.decode(errors='replace'))
     assert all(p.returncode == 0 for p in procs), '\n'.join(logs)
+    return logs
 
 
 CASES = [
@@ -55,6 +56,19 @@ CASES = [
 def test_sharded_encoder_on_rccl_single_rank(tmp_path):
     """The same program over the nccl (= RCCL) backend; one rank is all a one-GPU box can host."""
     _check(tmp_path, 1, ['--sort', 'QUAL', '--raw', 'DNA'], backend='nccl')
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_encoder_runs_the_benched_step(tmp_path, world):
+    """Each rank runs the single-GPU step on its shard -- census, rank 0's QNAME guess (broadcast), ONE pack + statistics + QNAME
+    field pass without a record index -- and the column analysis comes out of the fused pass's all-gathered facts; the exact
+    sharded kernels are the fallback, not the default.  The container is the oracle's."""
+    fq = synth.fastq(20261005, 45000 * world, 36, n_rate=2)                          # rank 0 holds the checkpoints at 10 000 .. 40 000 reads
+    logs = _check(tmp_path, world, ['--sort', 'QUAL'], fq=fq, extra_env={'UQ_TIMING': '1'})
+    line = [l for l in '\n'.join(logs).splitlines() if '"uq_timing": "dist_encode"' in l]
+    assert len(line) == 1, logs
+    rec = json.loads(line[0])
+    assert rec['qname'] == 'fused' and 'no record index' in rec['load'], rec
 
 
 @pytest.mark.parametrize('world,flags', CASES, ids=lambda v: str(v).replace(' ', ''))
@@ -117,11 +131,11 @@ def test_sharded_encode_fuzz(tmp_path, seed):
     _check(tmp_path, 2 + seed % (2 if seed < 5000 else 3), flags, fq=fq)
 
 
-def _check(tmp_path, world, flags, backend='gloo', fq=None):
+def _check(tmp_path, world, flags, backend='gloo', fq=None, extra_env=None):
     if fq is None: fq = synth.fastq(20261003 + 40, 3000, (30, 61), n_rate=2, dup='both', dup_templates=40)
     inp = tmp_path / 'in.fastq'; inp.write_bytes(fq)
     out = tmp_path / 'out.uQ'
-    _run_sharded(world, inp, out, flags, backend)
+    logs = _run_sharded(world, inp, out, flags, backend, extra_env)
     cfg, members = O.read_tar(str(out))
 
     from test_gpu_e2e import _oracle_flags
@@ -135,6 +149,7 @@ def _check(tmp_path, world, flags, backend='gloo', fq=None):
         assert json.loads(json.dumps(cfg[k])) == json.loads(json.dumps(ocfg[k])), k
     new_n_code = ocfg['N_qual'] and max(ocfg['N_qual'].values()) >= len(ocfg['qualities'])      # Q9: not decodable by the reference either
     assert of['sort'] is not None or new_n_code or O.decode(cfg, members) == fq.decode('latin-1')
+    return logs
 
 
 DECODE_CASES = [

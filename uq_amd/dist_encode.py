@@ -118,16 +118,38 @@ class ShardedSession(Session):
         if n:
             ends = ctx.to_numpy(ls[k0:k0 + 4 * n + 1:4 * n], np.uint64)
             start, end = int(ends[0]), int(ends[1])
-            self.d_buf = chunk[start:end]
-            self.d_ls = ls[k0:k0 + 4 * n + 1] - start              # index arithmetic only
+            del ls
+            # the shard's own records through the single-GPU step (Session.load_device: census -> [rank 0: QNAME layout guess] -> ONE broadcast of the guess
+            # -> pack + statistics + QNAME fields in one kernel, no record index; `d_ls` is expanded when a fallback asks for it)
+            self.load_device(chunk[start:end])
+            if self.total != n: error('ERROR: rank %d counted %d reads in a shard of %d' % (self.rank, self.total, n))
         else:
             self.d_buf, self.d_ls = chunk[:0], t.zeros(1, dtype=t.int64, device=ctx.device)
-        self.d_stats = ops.stats_new(ctx)
-        if n: ops.stats_accumulate(ctx, self.d_stats, self.d_buf, self.d_ls, 0, n)
+            self._spec, self._fq, self._guess_shared = None, None, False
+            self.d_stats = ops.stats_new(ctx)
+        if self.fused_qname_enabled() and not self._guess_shared:
+            # a rank without reads, or whose head gave no guess of its own, still takes part in the broadcast (its analyse_qname says "not usable")
+            self.share_qname_guess(ops.FusedQname(ctx, 16), dummy=True)
+
+    # the fused QNAME pass over shards: rank 0's guess is every rank's (qname_device.broadcast_guess), exactly once per load
+    def owns_qname_guess(self):
+        return self.rank == 0
+
+    def share_qname_guess(self, fq, dummy=False):
+        from . import qname_device
+        if dummy and self.rank == 0: fq.q.zero_()                 # rank 0 itself has no guess: ok = 0, every rank stands down
+        qname_device.broadcast_guess(self.ctx, fq, self.shard)
+        self._guess_shared = True
 
     # ------------------------------------------------------------------ analysis seams
     def fetch_stats(self):
-        return uqdist.allreduce_stats(self.ctx, self.d_stats, self.read_offset)
+        hs = uqdist.allreduce_stats(self.ctx, self.d_stats, self.read_offset)
+        if hs.incomplete:                        # the speculative pass of SOME rank could not count everything (the flag is summed): all redo the plain pass
+            self._spec = None
+            self.d_stats = self.ops.stats_new(self.ctx)
+            if self.total: self.ops.stats_accumulate(self.ctx, self.d_stats, self.d_buf, self.d_ls, 0, self.total)
+            hs = uqdist.allreduce_stats(self.ctx, self.d_stats, self.read_offset)
+        return hs
 
     def starts_with_at(self):
         flag = 1 if (self.rank != 0 or (self.total and int(self.d_buf[0]) == ord('@'))) else 0
@@ -145,8 +167,14 @@ class ShardedSession(Session):
 
     def analyse_qname(self):
         from . import qname, qname_device
-        self.qname_path = 'device'
-        res = qname_device.analyse_device(self.ctx, self.d_buf, self.d_ls, self.total, self.shard)
+        res = None
+        if self.fused_qname_enabled():           # collective: every rank enters, a rank whose own pass did not hold says so inside
+            self.qname_path = 'fused'
+            fq, self._fq = getattr(self, '_fq', None), None
+            res = qname_device.analyse_fused_sharded(self.ctx, fq, self.total, self.shard, usable=fq is not None or self.total == 0)
+        if res is None:
+            self.qname_path = 'device'
+            res = qname_device.analyse_device(self.ctx, self.d_buf, self.d_ls, self.total, self.shard)
         if res is None:
             raise qname.QnameError('ERROR: these QNAMEs need the sequential host passes (see DESIGN.md 2), which the sharded '
                                    'encoder does not run; encode this file on one GPU')
@@ -420,22 +448,25 @@ def main(argv=None):
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', device))
     else:
         dist.init_process_group(backend, rank=rank, world_size=world)
-    code = 0
+    code, session = 0, None
     t_ready = time.perf_counter()                                  # interpreter, torch and the process group are up
     try:
         args.device = device
         validate_args(args)
+        session = ShardedSession(args)
         if args.decode:
             if not args.output: error('ERROR: the sharded decoder writes a file: give it -o reads.fastq')
-            ShardedSession(args).decode_sharded(args.output)
+            session.decode_sharded(args.output)
         else:
-            ShardedSession(args).encode()
+            session.encode()
     except UqError as e:
         if rank == 0: print(e)
         code = 1
     finally:
         if os.environ.get('UQ_TIMING') and rank == 0:
-            print(json.dumps({'uq_timing': 'dist_encode', 'world': world, 'work_s': round(time.perf_counter() - t_ready, 3)}), file=sys.stderr, flush=True)
+            print(json.dumps({'uq_timing': 'dist_encode', 'world': world, 'work_s': round(time.perf_counter() - t_ready, 3),
+                              'load': getattr(session, 'load_path', None), 'qname': getattr(session, 'qname_path', None)}),
+                  file=sys.stderr, flush=True)
         dist.destroy_process_group()
     return code
 

@@ -318,7 +318,7 @@ def analyse_fused_sharded(ctx, fq, nreads, shard, usable=True):
     None: some rank raised a flag, a column stays undecided (it would need
     the distributed sort of its values) or a mapping of strings -- the caller runs analyse_device(shard=...), the exact sharded kernels."""
     if shard is None or shard.world == 1:
-        return analyse_fused(ctx, fq, nreads)
+        return analyse_fused(ctx, fq, nreads) if (usable and fq is not None) else None
     t = ctx.torch
     n = int(nreads)
     MAXC = 8

@@ -160,6 +160,7 @@ class Session:
         self.d_buf = d_buf
         if not hasattr(self, '_host'): self.path, self._host = None, None
         self._spec, self._fq, self._d_ls, self.load_path = None, None, None, 'multi-pass'
+        self._guess_shared = False
         nbytes = int(d_buf.numel())
         nlines, queued, guess, cap = None, None, None, 0
         if not getattr(args, 'multi_pass', False) and nbytes:
@@ -177,9 +178,10 @@ class Session:
                 cap = int(nbytes * rpb * 1.02) + 1024
                 guess.avg_record_bytes = int(1.0 / rpb)
                 fq = None
-                if not getattr(args, 'host_qname', False) and not getattr(args, 'exact_qname', False):
+                if self.fused_qname_enabled():
                     fq = ops.FusedQname(ctx, cap)
-                    ops.qname_guess_async(ctx, d_buf, None, fq)
+                    if self.owns_qname_guess(): ops.qname_guess_async(ctx, d_buf, None, fq)
+                    self.share_qname_guess(fq)
                 queued = ops.pack_stats_async(ctx, d_buf, None, cap, guess, fq=fq)
                 if queued is not None and fq is not None: ops.qname_fused_finish(ctx, fq)
             nlines, ok = census.wait()
@@ -205,9 +207,10 @@ class Session:
             del queued
             guess = ops.head_guess_indexed(ctx, self.d_buf, self.d_ls, self.total, args.notricks, args.pad)
             fq = None
-            if guess is not None and not getattr(args, 'host_qname', False) and not getattr(args, 'exact_qname', False):
+            if guess is not None and self.fused_qname_enabled() and not self._guess_shared:
                 fq = ops.FusedQname(ctx, self.total)
-                ops.qname_guess(ctx, self.d_buf, self.d_ls, self.total, fq)
+                if self.owns_qname_guess(): ops.qname_guess(ctx, self.d_buf, self.d_ls, self.total, fq)
+                self.share_qname_guess(fq)
             res = ops.pack_stats(ctx, self.d_buf, self.d_ls, 0, self.total, guess, fq=fq) if guess is not None else None
             if res is not None:
                 self._spec = (guess,) + res[:3]
@@ -219,6 +222,17 @@ class Session:
         if self._spec is None:
             self.d_stats = ops.stats_new(ctx)
             ops.stats_accumulate(ctx, self.d_stats, self.d_buf, self.d_ls, 0, self.total)
+
+    # the fused QNAME pass's seams (the sharded session overrides the last two: rank 0's guess is every rank's)
+    def fused_qname_enabled(self):
+        return not getattr(self.args, 'multi_pass', False) and not getattr(self.args, 'host_qname', False) and not getattr(self.args, 'exact_qname', False)
+
+    def owns_qname_guess(self):
+        return True
+
+    def share_qname_guess(self, fq):
+        """One GPU: nothing to share (and a fallback may guess again).  The sharded session broadcasts rank 0's structure here -- once per load,
+        which is what `_guess_shared` records."""
 
     @property
     def d_ls(self):
