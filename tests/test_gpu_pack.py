@@ -820,4 +820,6 @@ def test_side_context_allocations_follow_the_discipline(ctx):
         assert ok and nl2 == nl
         assert t.equal(got[0][:n * g.dna_bytes_per_row], ref[0]) and t.equal(got[1][:n * g.quality_bytes_per_row], ref[1])
         assert np.array_equal(ops.stats_fetch(ctx, got[3]).counts, ops.stats_fetch(ctx, ref[3]).counts)
-    assert side.stream.cuda_stream != ctx.stream.cuda_stream
+    # (no claim that the two streams differ: torch hands streams out of a pool of 32 per device, which wraps around in a long test session --
+    # on one stream the two contexts merely serialise)
+    assert side.stream.device == ctx.stream.device

@@ -821,7 +821,11 @@ __global__ __launch_bounds__(EM_THREADS, 4) void decode_stream_kernel(EmitGeom g
         nr = fetch_rows(t + gridDim.x);
         const bool staged = qst[Rt] <= tg.qcap;           // else (QNAME lines far beyond what the staging was sized for): a wave per line, straight out
         // ---- QNAME lines -> staging: render the fields, the separators and (lane of the last field) the suffix + '\n'
+#ifdef DS_ABL_NOQNAME
+        if (false) {
+#else
         if (staged) {
+#endif
             for (uint32_t idx = tid; idx < Rt * ncols; idx += EM_THREADS) {
                 const uint32_t i = idx / ncols, c = idx - i * ncols;
                 uint32_t pos = g.prefix_len;
@@ -902,6 +906,12 @@ __global__ __launch_bounds__(EM_THREADS, 4) void decode_stream_kernel(EmitGeom g
                         for (int c = 0; c < K; ++c) { qlo[c] += fa.qmin4; qhi[c] += fa.qmin4; }
                     }
                     uint8_t* ts = out + s_off[r + 1] - (L + 8 * K * (wg + 1) + 4);      // chunk c of the piece: SEQ at ts + 8 c, QUAL at ts + L + 3 + 8 c
+#ifdef DS_ABL_NOFULL
+                    if (nv == (uint32_t)K) { if ((blo[0] ^ qlo[0]) == 0x12345678u && bhi[K - 1] == qhi[K - 1]) ts[0] = 1; } else
+#endif
+#ifdef DS_ABL_NOPART
+                    if (nv != (uint32_t)K) { if ((blo[1] ^ qlo[1]) == 0x12345678u && bhi[K - 1] == qhi[K - 1]) ts[0] = 1; } else
+#endif
                     if (nv == (uint32_t)K) {
                         uint32_t vb[2 * K], vq[2 * K];
 #pragma unroll
@@ -941,6 +951,9 @@ __global__ __launch_bounds__(EM_THREADS, 4) void decode_stream_kernel(EmitGeom g
         }
         // ---- a lane per read: the L % 8 characters at the front of the two lines (their row bytes are read like a group's: what
         // lies before them decodes to characters that are not stored), and the separators
+#ifdef DS_ABL_NOFRONT
+        if (false)
+#endif
         for (uint32_t i = tid; i < Rt; i += EM_THREADS) {
             const uint32_t L = s_len[i], nsym = L & 7u;
             uint8_t* ts = out + s_off[i + 1] - (2 * L + 4);
@@ -958,7 +971,11 @@ __global__ __launch_bounds__(EM_THREADS, 4) void decode_stream_kernel(EmitGeom g
         }
         __syncthreads();
         // ---- QNAME lines: staging -> HBM, eight lanes per line, eight bytes a lane (aligned in LDS, wherever they fall in HBM)
+#ifdef DS_ABL_NOQNAME
+        if (false) {
+#else
         if (staged) {
+#endif
             for (uint32_t idx = tid; idx < Rt * 8u; idx += EM_THREADS) {
                 const uint32_t i = idx >> 3, L = s_len[i];
                 const uint64_t o = s_off[i];

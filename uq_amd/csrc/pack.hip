@@ -61,12 +61,32 @@ __device__ __forceinline__ uint32_t acgt_codes(uint32_t w) { return ((w ^ (w >> 
 // the characters those codes stand for (v_perm_b32 picks bytes of "ACGT")
 __device__ __forceinline__ uint32_t acgt_chars(uint32_t codes) { return __builtin_amdgcn_perm(0u, 0x54474341u, codes); }
 // four B-bit codes (one per byte, first character in byte 0) -> 4*B bits, first character most significant
+// (the bytes hold codes below 2^B.  v_dot4_u32_u8 weighs the four bytes in one full-rate instruction: a 32-bit multiply is quarter rate, and the
+// shift-and-mask form is eight instructions per four 6-bit codes)
 template <int B>
 __device__ __forceinline__ uint32_t pack4(uint32_t x) {
     if (B == 8) return __builtin_amdgcn_perm(0u, x, 0x00010203u);
+#ifndef PK_OLD_PACK4
+    if (B <= 2) return __builtin_amdgcn_udot4(x, (1u << (3 * B)) | (1u << (2 * B + 8)) | (1u << (B + 16)) | (1u << 24), 0u, false);
+    {
+        const uint32_t hi = __builtin_amdgcn_udot4(x, (1u << B) | (1u << 8), 0u, false);
+        return __builtin_amdgcn_udot4(x, (1u << (B + 16)) | (1u << 24), hi << (2 * B), false);        // (the low pair added onto the shifted high pair)
+    }
+#endif
     if (B == 2) return (x * 0x40100401u) >> 24;
     const uint32_t c0 = x & ((1u << B) - 1), c1 = (x >> 8) & ((1u << B) - 1), c2 = (x >> 16) & ((1u << B) - 1), c3 = x >> 24;
     return (((((c0 << B) | c1) << B) | c2) << B) | c3;
+}
+
+// byte i (from the least significant) of a group's B bytes = a0 << 4 B | a1, the two halves of four codes each: with an even B the bytes never
+// straddle the halves -- no 64-bit shifts, and the byte stores take bits 0-7 or (d16_hi) 16-23 of a register as they are
+template <int B>
+__device__ __forceinline__ uint32_t group_byte(uint32_t a0, uint32_t a1, int i) {
+#ifndef PK_OLD_STORE
+    if constexpr ((4 * B) % 8 == 0) return i < B / 2 ? a1 >> (8 * i) : a0 >> (8 * (i - B / 2));
+    else
+#endif
+    return (uint32_t)((((uint64_t)a0 << (4 * B)) | a1) >> (8 * i));
 }
 
 // LDS tile (16-byte aligned) -> global span, with the widest stores the destination alignment allows.
@@ -234,13 +254,20 @@ __device__ __forceinline__ void qname_tile(const uint8_t* stage, const uint32_t*
 constexpr int PK_NV = 5;   // 16-byte loads per lane per tile: a tile spans at most PK_NV * 256 * 16 = 20 KiB
 constexpr int PK_NV_STATS = 4;   // the fused pack + statistics kernel keeps a few KiB of LDS for its count table: 16 KiB tiles, same occupancy
 // Its counts are taken on the CODES the lookup-free conversion has just produced (bin = base code << 6 | quality code: two
-// instructions per four pairs instead of re-deriving bins from the characters), into a PKS_COPIES-fold replicated LDS table;
+// instructions per four pairs instead of re-deriving bins from the characters), into an LDS table (3-bit bases: four copies);
 // code 0 fill pairs of a read's partial top group and the N-trick positions (counted as their substitute there) are taken off
 // again at the flush, the N-trick base's own pairs go to a 128-entry table by quality character.  A symbol outside the guessed
 // alphabets is not counted at all: the statistics are flagged incomplete (the guess is wrong then anyway).
-constexpr int PKS_COPIES = 4;
+// The table is a STATIC LDS array (address 0 of the workgroup's LDS, known to the compiler), four copies chosen by the lane.  (Tried, round 4: ONE
+// copy for the 2-bit bases -- a counter's address is then `byte of the bin word << 2` plus an immediate, one SDWA shift per atomic, 10 VALU
+// instructions per group of eight pairs instead of 20; the lanes that meet in a counter cost more than that saves, 1.66 -> 1.71 ms: PK_ONE_COPY.)
+#ifdef PK_ONE_COPY
+constexpr int pks_copies(int bd) { return bd == 3 ? 4 : 1; }
+#else
+constexpr int pks_copies(int bd) { return 4; }
+#endif
 constexpr uint32_t pks_bins(int bd) { return bd == 3 ? 512u : 256u; }     // bin = base code << 6 | quality code (3-bit bases: nine bits)
-constexpr uint32_t pks_words(int bd) { return pks_bins(bd) * PKS_COPIES + 128; }
+constexpr uint32_t pks_words(int bd) { return pks_bins(bd) * pks_copies(bd) + 128; }
 
 // The queued forms take their line starts from the census's lists instead of an expanded index (lines.h): a record per pack tile (TileRec): the start of
 // the tile's first record (entry `ntiles`: the end of the last record), where the newline in front of it sits (census tile,
@@ -322,12 +349,13 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && (NTRICK || QN)) ? 4 : 5) void
     if (NTRICK) l_nq[tid] = lut.n_qual[tid];
     RecordAcc acc;
     bool incomplete = false;
-    uint32_t* cnt_tab = (uint32_t*)(l_nq + 256);                 // [256 bins][PKS_COPIES], then [128] N-trick base by quality character
+    constexpr int PKS_COPIES = pks_copies(BD);
+    __shared__ uint32_t cnt_tab[STATS ? pks_words(BD) : 1];      // [bins][PKS_COPIES], then [128] N-trick base by quality character
     uint32_t fill_pairs = 0, n_pairs = 0;                        // pairs counted in bin 0 / bin n_code that were fills / N-trick positions
     constexpr uint32_t PKS_BINS = pks_bins(BD), PKS_WORDS = pks_words(BD);
     if (STATS) for (uint32_t i = tid; i < PKS_WORDS; i += PK_THREADS) cnt_tab[i] = 0;       // the first tile's barrier orders it
     if (VAR) for (uint32_t i = tid; i < (g.out_bytes >> 4); i += PK_THREADS) ((uint4*)out_d)[i] = make_uint4(0, 0, 0, 0);       // (likewise; every copy-out clears what it reads)
-    QnLds* qn = (QnLds*)(cnt_tab + pks_words(BD));                   // the QNAME phase's state (uq_pack_stats_qname only)
+    QnLds* qn = (QnLds*)(l_nq + 256);                            // the QNAME phase's state (uq_pack_stats_qname only)
     bool qn_on = false;
     if (STATS && QN) qn_on = qf->ok != 0;                        // the guess kernels in front may have declined: the lines are left alone
     if (STATS && QN) {
@@ -436,29 +464,33 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && (NTRICK || QN)) ? 4 : 5) void
         const bool ok = cur.ok;
         between();
         // the QNAME lines of the tile: the last wave, a lane per read (its lanes have no part in phase B: P is sized for three waves)
+#ifndef PK_ABL_NOQN
         if (STATS && QN && qn_on && ok && tid >= PK_THREADS - 64 && tid - (PK_THREADS - 64) < Rt)
             qname_tile(stage, meta, tid - (PK_THREADS - 64), qn, qvals, qpitch, r0 + (tid - (PK_THREADS - 64)));
+#endif
         if (ok) {
             // ---- B: P lanes per read; a lane owns groups of 8 consecutive symbols, both streams:
             //         characters -> codes -> bits (8 symbols of b bits = b whole bytes)
             // one group of eight symbols of read r (length L, SEQ / QUAL lines at so / qo of the stage, the rows' last bytes at orow_d / orow_q):
             // characters -> codes -> bits, counted (STATS), stored into the LDS image of the two tables
-            auto pack_group = [&](const uint32_t r, const uint32_t L, const uint32_t so, const uint32_t qo, uint8_t* orow_d, uint8_t* orow_q, const uint32_t gg) {
+            // (wd / wq: the dword-aligned LDS offsets of the group's two windows, shd / shq: the windows' byte phases -- the same for every group of a
+            // read, since the windows move by eight bytes: one subtraction per window and group instead of add, two ANDs, add)
+            auto pack_group = [&](const uint32_t r, const uint32_t L, const int32_t wd, const uint32_t shd, const int32_t wq, const uint32_t shq, uint8_t* orow_d,
+                                  uint8_t* orow_q, const uint32_t gg) {
                 // symbols t = 8gg .. 8gg+7 (t counts from the END of the read) = characters j = L-1-t, i.e. the
                 // 8 bytes ending at position L - 8gg; byte k of the window is character j = j0 + k
                 const int32_t j0 = (int32_t)L - 8 * (int32_t)gg - 8;
-                uint64_t vd = 0, vq = 0;
+                uint32_t ad0 = 0, ad1 = 0, aq0 = 0, aq1 = 0;      // 4 symbols each; *0 = the more significant half
                 if (j0 > -8) {      // else: the whole group lies above the read (rows are sized for the longest one): zeros
                 uint32_t b_lo, b_hi, q_lo, q_hi;
-                lds_window8(stage, (int32_t)so + j0, b_lo, b_hi);
-                lds_window8(stage, (int32_t)qo + j0, q_lo, q_hi);
+                lds_window8_at(stage, wd, shd, b_lo, b_hi);
+                lds_window8_at(stage, wq, shq, q_lo, q_hi);
                 if (j0 < 0) {   // window reaches above the first base: those symbols are zero (fill with code-0 characters)
                     uint32_t mlo, mhi;
                     window_masks((uint32_t)(-j0), mlo, mhi);
                     b_lo = bfi(mlo, b_lo, g.fill_d); b_hi = bfi(mhi, b_hi, g.fill_d);
                     q_lo = bfi(mlo, q_lo, g.fill_q); q_hi = bfi(mhi, q_hi, g.fill_q);
                 }
-                uint32_t ad0, ad1, aq0, aq1;      // 4 symbols each; *0 = the more significant half
                 bool generic = !FAST;
                 if (FAST) {
                     uint32_t c0, c1, e0, e1;                     // codes, and (non-zero byte) = not a base of the alphabet
@@ -488,14 +520,23 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && (NTRICK || QN)) ? 4 : 5) void
                     aq0 = pack4<BQ>(x0); aq1 = pack4<BQ>(x1);
                     if (STATS) {
                         if (generic) incomplete = true;          // a symbol outside the guess: not counted here
+#ifdef PK_ABL_NOCOUNT
+                        else if (false) {
+#else
                         else {
+#endif
                             uint8_t* hb = (uint8_t*)cnt_tab + ((lane_id() & (PKS_COPIES - 1)) << 2);
                             if constexpr (BD == 2) {
                                 const uint32_t bin0 = (c0 << 6) | x0, bin1 = (c1 << 6) | x1;    // BQ <= 6 and two bits of base: a bin per byte
 #pragma unroll
                                 for (int k = 0; k < 4; ++k) {
-                                    atomicAdd((uint32_t*)(hb + (((bin0 >> (8 * k)) & 0xFFu) * (4 * PKS_COPIES))), 1u);
-                                    atomicAdd((uint32_t*)(hb + (((bin1 >> (8 * k)) & 0xFFu) * (4 * PKS_COPIES))), 1u);
+                                    if constexpr (PKS_COPIES == 1) {
+                                        atomicAdd(&cnt_tab[(bin0 >> (8 * k)) & 0xFFu], 1u);
+                                        atomicAdd(&cnt_tab[(bin1 >> (8 * k)) & 0xFFu], 1u);
+                                    } else {
+                                        atomicAdd((uint32_t*)(hb + (((bin0 >> (8 * k)) & 0xFFu) * (4 * PKS_COPIES))), 1u);
+                                        atomicAdd((uint32_t*)(hb + (((bin1 >> (8 * k)) & 0xFFu) * (4 * PKS_COPIES))), 1u);
+                                    }
                                 }
                             } else {                                                            // three bits of base: nine bits of bin, pair by pair
 #pragma unroll
@@ -542,30 +583,33 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && (NTRICK || QN)) ? 4 : 5) void
                     }
                     ad0 = ad[0]; ad1 = ad[1]; aq0 = aq[0]; aq1 = aq[1];
                 }
-                vd = ((uint64_t)ad0 << (4 * BD)) | ad1;
-                vq = ((uint64_t)aq0 << (4 * BQ)) | aq1;
                 }
                 if (g.variable) {                                  // sentinel = code 1 at symbol index t = L
                     const int32_t i = (int32_t)L - 8 * (int32_t)gg;
-                    if (i >= 0 && i < 8) { vd |= 1ull << (BD * i); vq |= 1ull << (BQ * i); }
+                    if (i >= 0 && i < 4) { ad1 |= 1u << (BD * i); aq1 |= 1u << (BQ * i); }
+                    else if (i >= 4 && i < 8) { ad0 |= 1u << (BD * (i - 4)); aq0 |= 1u << (BQ * (i - 4)); }
                 }
                 // byte index counts from the row's LAST byte; only the top group can stick out of the row
                 uint8_t* od = orow_d - BD * gg;
                 uint8_t* oq = orow_q - BQ * gg;
+#ifdef PK_ABL_NOSTORE
+                if ((ad0 ^ aq0) == 0x12345678u && (ad1 ^ aq1) == 0x9ABCDEF0u) od[0] = 1;      // (keeps the values alive)
+                else if (false)
+#endif
                 if (gg + 1 < g.G) {
                     // byte stores: unaligned ds_write_b32 / b16 pieces are accepted by gfx950 but slower (1.11 -> 1.27 ms)
 #pragma unroll
-                    for (int i = 0; i < BD; ++i) od[-i] = (uint8_t)(vd >> (8 * i));
+                    for (int i = 0; i < BD; ++i) od[-i] = (uint8_t)group_byte<BD>(ad0, ad1, i);
 #pragma unroll
-                    for (int i = 0; i < BQ; ++i) oq[-i] = (uint8_t)(vq >> (8 * i));
+                    for (int i = 0; i < BQ; ++i) oq[-i] = (uint8_t)group_byte<BQ>(aq0, aq1, i);
                 } else {
                     const uint32_t nd = g.Cd - BD * gg, nq = g.Cq - BQ * gg;     // bytes left in the row from here up
 #pragma unroll
                     for (int i = 0; i < BD; ++i)
-                        if ((uint32_t)i < nd) od[-i] = (uint8_t)(vd >> (8 * i));
+                        if ((uint32_t)i < nd) od[-i] = (uint8_t)group_byte<BD>(ad0, ad1, i);
 #pragma unroll
                     for (int i = 0; i < BQ; ++i)
-                        if ((uint32_t)i < nq) oq[-i] = (uint8_t)(vq >> (8 * i));
+                        if ((uint32_t)i < nq) oq[-i] = (uint8_t)group_byte<BQ>(aq0, aq1, i);
                 }
             };
             if (rr < Rt) {
@@ -575,7 +619,9 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && (NTRICK || QN)) ? 4 : 5) void
                 const uint32_t qo = meta[4 * r + 3];
                 if (STATS) {
                     const uint32_t Lq = meta[4 * r + 4] - qo - 1;
+#ifndef PK_ABL_NOREC
                     if (pp == 0) acc.record(r0 + r, stage[meta[4 * r + 2]] == '+', L, Lq, meta[4 * r + 4] - meta[4 * r]);
+#endif
                     if (L > g.dna_max || Lq != L) incomplete = true;        // symbols this kernel does not visit
                 }
                 if (L > g.dna_max || meta[4 * r + 4] - qo - 1 != L) { badr = badr < (uint32_t)(r0 + r) ? badr : (uint32_t)(r0 + r); L = 0; }
@@ -584,7 +630,13 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && (NTRICK || QN)) ? 4 : 5) void
                 // VAR: only the groups that hold a symbol or the sentinel -- the rows' empty upper parts are zero already: every copy-out clears what
                 // it reads (rows are sized for the LONGEST read: 38 group slots for 21.5 groups on average at 36 - 301 bp)
                 const uint32_t gend = VAR ? (((L + 8) >> 3) < g.G ? ((L + 8) >> 3) : g.G) : g.G;
-                for (uint32_t gg = pp; gg < gend; gg += g.P) pack_group(r, L, so, qo, orow_d, orow_q, gg);
+#ifndef PK_ABL_NOGROUP
+                int32_t wd = (int32_t)(so + L) - 8 * (int32_t)pp - 8, wq = (int32_t)(qo + L) - 8 * (int32_t)pp - 8;      // so + j0, qo + j0 of group pp
+                const uint32_t shd = (uint32_t)wd & 3u, shq = (uint32_t)wq & 3u;
+                wd &= ~3; wq &= ~3;
+                const int32_t wstep = 8 * (int32_t)g.P;
+                for (uint32_t gg = pp; gg < gend; gg += g.P, wd -= wstep, wq -= wstep) pack_group(r, L, wd, shd, wq, shq, orow_d, orow_q, gg);
+#endif
             }
         }
         __syncthreads();
@@ -895,14 +947,15 @@ static int pack_impl(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_s
     if (d_stats && ntrick_bases == 1 && hp->n_qual[nchar] >= nq) return 0;    // the N-trick code is no quality of the alphabet (Q9): exact kernels only
     if (d_stats && (!fast || (bd != 2 && bd != 3) || bq > 6)) return 0;  // the fused kernels exist for the lookup-free paths (2- / 3-bit bases, <= 64 contiguous qualities) only
     const bool var_deal = d_stats && use_lists && hp->variable;
-    const size_t lds = 16 + (size_t)g.stage_bytes + g.out_bytes + (4 * R + 4) * 4 + 3 * 512 + (d_stats ? pks_words((int)bd) * 4 + sizeof(QnLds) : 0);
-    UQ_REQUIRE(lds <= 160 * 1024, "uq_pack: tile needs %zu bytes of LDS", lds);
+    const size_t lds_static = d_stats ? pks_words((int)bd) * 4 : 4;        // the kernels' count table
+    const size_t lds = 16 + (size_t)g.stage_bytes + g.out_bytes + (4 * R + 4) * 4 + 3 * 512 + (d_stats ? sizeof(QnLds) : 0);
+    UQ_REQUIRE(lds + lds_static <= 160 * 1024, "uq_pack: tile needs %zu bytes of LDS", lds + lds_static);
     const uint64_t tiles = (nreads + R - 1) / R;
     PackKernel k = d_stats ? pick_stats_kernel((int)bd, (int)bq, ntrick, d_q != nullptr, use_lists, var_deal) : pick_kernel((int)bd, (int)bq, ntrick, fast);
     if (lds > 48 * 1024) UQ_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // persistent workgroups: exactly as many as are resident at once (LDS and registers both limit that: a grid sized from the LDS
     // alone would leave the kernels built for four waves per SIMD with a second, quarter-full round of workgroups)
-    uint32_t per_cu = (uint32_t)((160 * 1024) / lds);
+    uint32_t per_cu = (uint32_t)((160 * 1024) / (lds + lds_static));
     {
         // (computed from the kernel's register count: hipOccupancyMaxActiveBlocksPerMultiprocessor is one workgroup per CU high for
         // kernels with 97-112 SGPRs on this ROCm -- MI355X_MICROARCH.md, Correctness boundaries -- which these are)

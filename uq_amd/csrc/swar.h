@@ -35,6 +35,13 @@ __device__ __forceinline__ void lds_window8(const uint8_t* base, int32_t o, uint
     lo = __builtin_amdgcn_alignbyte(b, a, sh);
     hi = __builtin_amdgcn_alignbyte(c, b, sh);
 }
+// the same with the offset already split into its dword-aligned part and its byte phase (loops whose windows move by multiples of four bytes)
+__device__ __forceinline__ void lds_window8_at(const uint8_t* base, int32_t aligned, uint32_t sh, uint32_t& lo, uint32_t& hi) {
+    const uint32_t* p = (const uint32_t*)(base + aligned);
+    const uint32_t a = p[0], b = p[1], c = p[2];
+    lo = __builtin_amdgcn_alignbyte(b, a, sh);
+    hi = __builtin_amdgcn_alignbyte(c, b, sh);
+}
 // bytes k < nbad of the 8-byte window are above the first base: byte masks of the bytes to KEEP
 __device__ __forceinline__ void window_masks(uint32_t nbad, uint32_t& mlo, uint32_t& mhi) {
     mlo = nbad >= 4 ? 0u : (0xFFFFFFFFu << (8 * nbad));
