@@ -133,7 +133,13 @@ __device__ void emit_record_direct(const EmitGeom& g, const uint8_t* __restrict_
 constexpr int EM_THREADS = 256;
 constexpr uint32_t EM_RMAX = 64;
 constexpr int DE_K = 5;                  // chunks per lane of the fixed-length instances
-constexpr int DS_K = 4;                  // groups per lane of decode_stream_kernel's instances
+#ifndef DS_K_
+#define DS_K_ 4
+#endif
+#ifndef DS_OCC
+#define DS_OCC 4
+#endif
+constexpr int DS_K = DS_K_;              // groups per lane of decode_stream_kernel's instances
 constexpr int DE_NVD = 2, DE_NVQ = 3;    // 16-byte vectors per lane of packed rows in flight: DNA rows <= 8 KiB, QUAL rows <= 12 KiB per tile
 constexpr uint32_t EM_BUDGET_TEXT = 19 * 1024, EM_BUDGET_PACKED = 36 * 1024;   // dynamic LDS per workgroup (the registers allow four workgroups per CU)
 
@@ -345,8 +351,8 @@ __global__ __launch_bounds__(EM_THREADS, 4) void emit_tile_kernel(EmitGeom g, Ti
         const uint64_t ad = (uint64_t)(uintptr_t)(seq + tt * R * tg.Cd), aq = (uint64_t)(uintptr_t)(qual + tt * R * tg.Cq);
         x.skd = (uint32_t)(ad & 15); x.skq = (uint32_t)(aq & 15);
         x.nvd = (x.skd + Rt * tg.Cd + 15) >> 4; x.nvq = (x.skq + Rt * tg.Cq + 15) >> 4;
-        const uint4* sd = (const uint4*)(uintptr_t)(ad & ~uint64_t(15));
-        const uint4* sq = (const uint4*)(uintptr_t)(aq & ~uint64_t(15));
+        const uint4* sd = (const uint4*)(seq + ((int64_t)(tt * R * tg.Cd) - (int64_t)x.skd));         // (global_load, not flat_load: see pack.hip)
+        const uint4* sq = (const uint4*)(qual + ((int64_t)(tt * R * tg.Cq) - (int64_t)x.skq));
 #pragma unroll
         for (int u = 0; u < DE_NVD; ++u) { const uint32_t i = u * EM_THREADS + tid; if (i < x.nvd) x.d[u] = sd[i]; }
 #pragma unroll
@@ -723,7 +729,7 @@ __device__ __forceinline__ void store_low_bytes(uint8_t* p, uint64_t v, uint32_t
 }
 
 template <int BQ = 0, bool HASN = false, int K = 1>
-__global__ __launch_bounds__(EM_THREADS, 4) void decode_stream_kernel(EmitGeom g, StreamGeom tg, const uint8_t* __restrict__ dna, const uint8_t* __restrict__ qual,
+__global__ __launch_bounds__(EM_THREADS, DS_OCC) void decode_stream_kernel(EmitGeom g, StreamGeom tg, const uint8_t* __restrict__ dna, const uint8_t* __restrict__ qual,
                                                                    const uint32_t* __restrict__ len, uint64_t n, const uint64_t* __restrict__ offsets,
                                                                    uint8_t* __restrict__ out) {
     extern __shared__ __align__(16) uint8_t tile[];                                  // [qcap] QNAME staging, the two sets of per-tile arrays, the rows
@@ -758,8 +764,8 @@ __global__ __launch_bounds__(EM_THREADS, 4) void decode_stream_kernel(EmitGeom g
         const uint64_t ad = (uint64_t)(uintptr_t)(dna + tt * R * tg.Cd), aq = (uint64_t)(uintptr_t)(qual + tt * R * tg.Cq);
         x.skd = (uint32_t)(ad & 15); x.skq = (uint32_t)(aq & 15);
         x.nvd = (x.skd + Rt * tg.Cd + 15) >> 4; x.nvq = (x.skq + Rt * tg.Cq + 15) >> 4;
-        const uint4* sd = (const uint4*)(uintptr_t)(ad & ~uint64_t(15));
-        const uint4* sq = (const uint4*)(uintptr_t)(aq & ~uint64_t(15));
+        const uint4* sd = (const uint4*)(dna + ((int64_t)(tt * R * tg.Cd) - (int64_t)x.skd));         // (global_load, not flat_load: see pack.hip)
+        const uint4* sq = (const uint4*)(qual + ((int64_t)(tt * R * tg.Cq) - (int64_t)x.skq));
 #pragma unroll
         for (int u = 0; u < DE_NVD; ++u) { const uint32_t i = u * EM_THREADS + tid; if (i < x.nvd) x.d[u] = sd[i]; }
 #pragma unroll
@@ -869,7 +875,11 @@ __global__ __launch_bounds__(EM_THREADS, 4) void decode_stream_kernel(EmitGeom g
         const uint32_t od = tg.o_ind + skd + tg.Cd - 1, oq = tg.o_inq + skq + tg.Cq - 1;      // last byte of row 0
         if (tg.variable || tg.RS == 0) {                  // (RS = 0: fixed-length reads of more groups than the workgroup has lanes)
             // flat over the tile: item = (read, group) in the order of cum[]
+#ifdef DS_ABL_NOGROUPS
+            const uint32_t total = 0;
+#else
             const uint32_t total = cum[Rt];
+#endif
             for (uint32_t item = tid; item < total; item += EM_THREADS) {
                 uint32_t r = 0, hi = Rt;                                 // largest r with cum[r] <= item
 #pragma unroll
@@ -988,7 +998,9 @@ __global__ __launch_bounds__(EM_THREADS, 4) void decode_stream_kernel(EmitGeom g
                 }
             }
         } else {
+#ifndef DS_ABL_NOQNAME
             for (uint32_t i = tid >> 6; i < Rt; i += EM_THREADS / 64) emit_qname_direct(g, out + s_off[i], r0 + i, lane);
+#endif
         }
     }
 }
@@ -1127,7 +1139,7 @@ size_t plan_stream(StreamGeom& sg, const EmitGeom& g, const uq_unpack_params* up
     const uint32_t ncols = g.ncols ? g.ncols : 1;
     auto a16 = [](uint32_t b) { return (b + 15) & ~15u; };
     const uint64_t per = qp + 2ull * (8 + 4 + 4 + 4 + 2 * ncols) + sg.Cd + sg.Cq;
-    uint64_t R = (EM_BUDGET_PACKED - 1024) / per;
+    uint64_t R = ((DS_OCC == 4 ? EM_BUDGET_PACKED : 160u * 1024u / DS_OCC - 4096u) - 1024) / per;
     if (R > 63) R = 63;                                      // wave 0 scans the tile's offsets and lengths, one more offset than reads
     while (R > 0 && (R * sg.Cd + 48 > DE_NVD * EM_THREADS * 16u || R * sg.Cq + 48 > DE_NVQ * EM_THREADS * 16u)) --R;
     if (sg.RS && R > sg.RS) R -= R % sg.RS;                  // whole steps of the fixed-length group loop
@@ -1231,7 +1243,7 @@ extern "C" int uq_decode_fastq(uq_ctx* ctx, const uq_emit_params* hp, const uq_u
         const size_t lds = plan_stream(sg, g, up, tg.fa);
         if (lds) {
             const uint64_t tiles = (nreads + sg.R - 1) / sg.R;
-            const uint32_t tb = tile_blocks(tiles, lds, 4);
+            const uint32_t tb = tile_blocks(tiles, lds, DS_OCC);
 #define UQ_STREAM_CASE(Q) \
             case Q: if (sg.fa.has_n) decode_stream_kernel<Q, true, DS_K><<<tb, EM_THREADS, lds, ctx->stream>>>(g, sg, d_dna, d_qual, lens, nreads, d_offsets, d_out); \
                     else decode_stream_kernel<Q, false, DS_K><<<tb, EM_THREADS, lds, ctx->stream>>>(g, sg, d_dna, d_qual, lens, nreads, d_offsets, d_out); \

@@ -424,7 +424,7 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && (NTRICK || QN)) ? 4 : 5) void
             if (kk + 4 * cnt > avail) x.ok = false;         // (lines of many KiB: the tile goes piece by piece, each with its own search)
         }
         if (!x.ok) return x;                          // tiles are sized from the AVERAGE record: a long-winded one is split below
-        const uint4* src = (const uint4*)(uintptr_t)a0;
+        const uint4* src = (const uint4*)(buf + ((int64_t)b.g0 - (int64_t)x.skew));      // (pointer arithmetic on the kernel's own argument, not an integer cast back to a pointer: the loads are global_load, not flat_load -- a flat access counts in lgkmcnt as well and returns out of order, so every wait for LDS data also waited for the tile in flight)
 #pragma unroll
         for (int u = 0; u < NV; ++u) { const uint32_t i = u * PK_THREADS + tid; if (i < x.nvec) x.v[u] = src[i]; }
         if (tid <= 4 * x.Rt) {
@@ -640,6 +640,12 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && (NTRICK || QN)) ? 4 : 5) void
             }
         }
         __syncthreads();
+#ifndef PK_NO_EARLY_WAIT
+        // The next tile's bytes were requested a whole phase B ago: wait for them HERE, before this tile's stores are issued.  vmcnt counts loads and
+        // stores together, in issue order: the wait the compiler would put in front of the next tile's phase A also waits for the stores below to be
+        // acknowledged (1 - 1.5 us under load, every tile); behind this one it has nothing left to wait for.
+        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), expcnt / lgkmcnt left alone
+#endif
         if (ok) {
             // ---- C: coalesced stores of the two packed tiles (widest vector the tile's byte offset allows)
             if constexpr (STATS && (NTRICK || QN)) {            // (the forms built for four workgroups per CU have the registers for the inline loop)
@@ -655,6 +661,9 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && (NTRICK || QN)) ? 4 : 5) void
     uint64_t t = blockIdx.x;
     Bounds b_next = load_bounds(t + S);
     Regs cur = issue(t * R, tile_reads(t), load_bounds(t));
+#ifndef PK_NO_EARLY_WAIT
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // (every path into a tile's phase A has waited for the tile's bytes: see phase C)
+#endif
     for (; t < ntiles; t += S) {
         const Bounds b_nn = load_bounds(t + 2 * S);
         if (cur.ok) {
@@ -686,6 +695,9 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && (NTRICK || QN)) ? 4 : 5) void
                 __syncthreads();                      // the next piece overwrites the stage and the out tile
             }
             cur = issue((t + S) * R, tile_reads(t + S), b_next); b_next = b_nn;
+#ifndef PK_NO_EARLY_WAIT
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+#endif
         }
     }
     if (badr != 0xFFFFFFFFu) atomicMin(bad, (unsigned long long)badr);

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(ST_THREADS) void stats_kernel(const uint8_t* __rest
         x.staged = span + 16 <= ST_CAP;
         if (!x.staged) return x;
         x.nvec = (uint32_t)((span + 15) >> 4);
-        const uint4* src = (const uint4*)(uintptr_t)a0;
+        const uint4* src = (const uint4*)(buf + ((int64_t)b.g0 - (int64_t)x.skew));      // (global_load, not flat_load: see pack.hip)
 #pragma unroll
         for (int u = 0; u < ST_NV; ++u) { const uint32_t i = u * ST_THREADS + tid; if (i < x.nvec) x.v[u] = src[i]; }
         const uint64_t* lsp = ls + 4 * (first + tt * R);

@@ -11,7 +11,7 @@ __device__ __forceinline__ uint32_t stage_span(const uint8_t* src, uint32_t len,
     const uint64_t a0 = (uint64_t)(uintptr_t)src & ~uint64_t(15);
     const uint32_t skew = (uint32_t)((uint64_t)(uintptr_t)src - a0);
     const uint32_t nvec = (skew + len + 15) >> 4;
-    const uint4* s4 = (const uint4*)(uintptr_t)a0;
+    const uint4* s4 = (const uint4*)(src - skew);         // (keeps the pointer's address space: global_load, not flat_load)
     uint4* d4 = (uint4*)lds;
     for (uint32_t i = threadIdx.x; i < nvec; i += PT_THREADS) d4[i] = s4[i];
     return skew;
@@ -28,7 +28,7 @@ __device__ __forceinline__ void emit_span(uint8_t* dst, uint32_t len, F f) {
         if (k0 >= 0 && (uint32_t)k0 + 16 <= len) {
             uint32_t w[4];
             f((uint32_t)k0, w);
-            *(uint4*)(uintptr_t)(a0 + (uint64_t)q * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+            *(uint4*)(dst + k0) = make_uint4(w[0], w[1], w[2], w[3]);
         } else {
             for (int b = 0; b < 16; ++b) {
                 int32_t k = k0 + b;

@@ -133,8 +133,8 @@ __global__ __launch_bounds__(UT) void unpack_pipe_kernel(const uint8_t* __restri
         const uint64_t ad = (uint64_t)(uintptr_t)(dna + tt * R * g.Cd), aq = (uint64_t)(uintptr_t)(qual + tt * R * g.Cq);
         x.skd = (uint32_t)(ad & 15); x.skq = (uint32_t)(aq & 15);
         x.nvd = (x.skd + x.Rt * g.Cd + 15) >> 4; x.nvq = (x.skq + x.Rt * g.Cq + 15) >> 4;
-        const uint4* sd = (const uint4*)(uintptr_t)(ad & ~uint64_t(15));
-        const uint4* sq = (const uint4*)(uintptr_t)(aq & ~uint64_t(15));
+        const uint4* sd = (const uint4*)(dna + ((int64_t)(tt * R * g.Cd) - (int64_t)x.skd));          // (global_load, not flat_load: see pack.hip)
+        const uint4* sq = (const uint4*)(qual + ((int64_t)(tt * R * g.Cq) - (int64_t)x.skq));
 #pragma unroll
         for (int u = 0; u < UP_NVD; ++u) { const uint32_t i = u * UT + tid; if (i < x.nvd) x.d[u] = sd[i]; }
 #pragma unroll
