@@ -134,7 +134,7 @@ constexpr int EM_THREADS = 256;
 constexpr uint32_t EM_RMAX = 64;
 constexpr int DE_K = 5;                  // chunks per lane of the fixed-length instances
 #ifndef DS_K_
-#define DS_K_ 4
+#define DS_K_ 2
 #endif
 #ifndef DS_OCC
 #define DS_OCC 4
@@ -915,7 +915,11 @@ __global__ __launch_bounds__(EM_THREADS, DS_OCC) void decode_stream_kernel(EmitG
 #pragma unroll
                         for (int c = 0; c < K; ++c) { qlo[c] += fa.qmin4; qhi[c] += fa.qmin4; }
                     }
+#ifdef DS_ABL_SMALLOUT
+                    uint8_t* ts = out + 4096u + (blockIdx.x & 255u) * 65536u + tid * 128u - L;      // (ablation: every store lands in a few MiB that stay in the L2s)
+#else
                     uint8_t* ts = out + s_off[r + 1] - (L + 8 * K * (wg + 1) + 4);      // chunk c of the piece: SEQ at ts + 8 c, QUAL at ts + L + 3 + 8 c
+#endif
 #ifdef DS_ABL_NOFULL
                     if (nv == (uint32_t)K) { if ((blo[0] ^ qlo[0]) == 0x12345678u && bhi[K - 1] == qhi[K - 1]) ts[0] = 1; } else
 #endif
