@@ -61,7 +61,16 @@ struct GatherFn {
     }
 };
 
-__global__ __launch_bounds__(GT) void gather_rows_kernel(const uint8_t* __restrict__ table, const void* __restrict__ idx, int itemsize,
+// IS = the index's itemsize (an instance each: with the width chosen per load, every index load sat in a branch of its own, followed by its own wait)
+template <int IS>
+__device__ __forceinline__ uint64_t load_index_t(const void* idx, uint64_t j) {
+    if (IS == 1) return ((const uint8_t*)idx)[j];
+    if (IS == 2) return ((const uint16_t*)idx)[j];
+    if (IS == 4) return ((const uint32_t*)idx)[j];
+    return ((const uint64_t*)idx)[j];
+}
+template <int IS>
+__global__ __launch_bounds__(GT) void gather_rows_kernel(const uint8_t* __restrict__ table, const void* __restrict__ idx,
                                                          GatherGeom g, uint8_t* __restrict__ out) {
     extern __shared__ __align__(16) uint8_t smem[];   // [TR][P dwords] + skew[TR]
     uint8_t* skew = smem + (size_t)g.TR * g.P * 4;
@@ -79,7 +88,7 @@ __global__ __launch_bounds__(GT) void gather_rows_kernel(const uint8_t* __restri
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const uint32_t i = i0 + u * groups;
-                r[u] = i < n ? load_index(idx, itemsize, j0 + i) : 0;
+                r[u] = load_index_t<IS>(idx, j0 + (i < n ? i : n - 1));       // (unconditional: a load behind `i < n` is followed by its own wait -- the four would go one by one)
                 if (r[u] >= g.table_rows) r[u] = 0;
             }
             uint32_t v[U], sk[U];
@@ -88,7 +97,7 @@ __global__ __launch_bounds__(GT) void gather_rows_kernel(const uint8_t* __restri
                 const uint8_t* s = table + r[u] * g.C;
                 sk[u] = (uint32_t)((uintptr_t)s & 3);
                 const uint32_t nd = (sk[u] + g.C + 3) >> 2;
-                v[u] = (i0 + u * groups < n && gl < nd) ? ((const uint32_t*)(s - sk[u]))[gl] : 0u;
+                v[u] = ((const uint32_t*)(s - sk[u]))[gl < nd ? gl : 0u];           // (likewise; lanes beyond the row read its first dword and store nothing)
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -101,7 +110,7 @@ __global__ __launch_bounds__(GT) void gather_rows_kernel(const uint8_t* __restri
         }
     } else {
         for (uint32_t i = threadIdx.x / g.G; i < n; i += groups) {
-            uint64_t r = load_index(idx, itemsize, j0 + i);
+            uint64_t r = load_index_t<IS>(idx, j0 + i);
             if (r >= g.table_rows) r = 0;
             const uint8_t* s = table + r * g.C;
             const uint32_t sk = (uint32_t)((uintptr_t)s & 3);
@@ -153,8 +162,9 @@ int uq_gather_rows_internal(uq_ctx* ctx, const uint8_t* d_table, uint64_t table_
     const size_t lds = (size_t)TR * g.P * 4 + TR + 16;
     const uint64_t tiles = (n_out + TR - 1) / TR;
     UQ_REQUIRE(tiles <= 0x7fffffffu, "uq_gather_rows: too many tiles");
-    if (lds > 48 * 1024) UQ_CHECK_HIP(hipFuncSetAttribute((const void*)gather_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    gather_rows_kernel<<<(uint32_t)tiles, GT, lds, ctx->stream>>>(d_table, d_index, index_itemsize, g, d_out);
+    auto k = index_itemsize == 1 ? gather_rows_kernel<1> : index_itemsize == 2 ? gather_rows_kernel<2> : index_itemsize == 4 ? gather_rows_kernel<4> : gather_rows_kernel<8>;
+    if (lds > 48 * 1024) UQ_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    k<<<(uint32_t)tiles, GT, lds, ctx->stream>>>(d_table, d_index, g, d_out);
     UQ_LAUNCH_CHECK();
     return 0;
 }

@@ -66,15 +66,16 @@ __global__ __launch_bounds__(IDX_THREADS) void census_list_kernel(const uint4* _
     const uint64_t tile = tile0 + blockIdx.x;                 // tile0: the chunked census (uq_count_lines_chunk) walks the buffer in pieces
     const uint64_t v0 = (tile * IDX_TILE + (uint64_t)w * IDX_WAVE_BYTES) / 16 + lane;
     uint32_t m[IDX_LOADS];
+    // all of the lane's vectors are requested before the first is looked at (a load inside the `vi < nvec` branch was followed by its own wait: one
+    // vector in flight per lane); beyond the stream the last vector is read again and masked out
+    uint4 q[IDX_LOADS];
+#pragma unroll
+    for (int it = 0; it < IDX_LOADS; ++it) { const uint64_t vi = v0 + (uint64_t)it * 64; q[it] = abuf[vi < nvec ? vi : nvec - 1]; }
 #pragma unroll
     for (int it = 0; it < IDX_LOADS; ++it) {
         const uint64_t vi = v0 + (uint64_t)it * 64;
-        m[it] = 0;
-        if (vi < nvec) {
-            const uint4 q = abuf[vi];
-            const int64_t p = (int64_t)(vi * 16) - (int64_t)mis;
-            m[it] = nl_mask16(q) & valid_mask16(p, nbytes);
-        }
+        const int64_t p = (int64_t)(vi * 16) - (int64_t)mis;
+        m[it] = vi < nvec ? nl_mask16(q[it]) & valid_mask16(p, nbytes) : 0u;
     }
     const uint32_t c0 = __popc(m[0]), c1 = __popc(m[1]), c2 = __popc(m[2]), c3 = __popc(m[3]);
     const uint32_t i01 = wave_inclusive_sum(c0 | (c1 << 16)), i23 = wave_inclusive_sum(c2 | (c3 << 16));

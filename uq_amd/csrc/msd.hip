@@ -64,7 +64,7 @@ __global__ __launch_bounds__(MT) void msd_extract_kernel(const uint8_t* __restri
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
             const uint64_t idx = base + (uint64_t)i * MT + tid;
-            c64[i] = idx < n ? msd_chunk0(table + idx * C, C) : 0;
+            c64[i] = msd_chunk0(table + (idx < n ? idx : n - 1) * C, C);       // (unconditional: a load behind `idx < n` is followed by its own wait -- one row head in flight per lane)
         }
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
@@ -136,10 +136,13 @@ __global__ __launch_bounds__(MT) void msd_count_kernel(const K* __restrict__ key
         const uint32_t pend = parent_end[p];
         const uint32_t lo = (p ? parent_end[p - 1] : 0u) + (t - tile_prefix[p]) * TILE;
         const uint32_t m = pend - lo < (uint32_t)TILE ? pend - lo : (uint32_t)TILE;
+        K kv[ITEMS];
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) { const uint32_t q = i * MT + tid; kv[i] = keys[lo + (q < m ? q : 0u)]; }      // all of the lane's keys requested before the first is counted
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
             const uint32_t q = i * MT + tid;
-            if (q < m) atomicAdd(&h[(uint32_t)(keys[lo + q] >> shift) & mask], 1u);
+            if (q < m) atomicAdd(&h[(uint32_t)(kv[i] >> shift) & mask], 1u);
         }
     }
     __syncthreads();
@@ -191,8 +194,9 @@ __global__ __launch_bounds__(MT) void msd_scatter_kernel(const K* __restrict__ k
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
             const uint32_t q = i * MT + tid;
-            key[i] = q < m ? keys_in[lo + q] : (K)0;
-            val[i] = FIRST ? lo + q : (q < m ? idx_in[lo + q] : 0u);
+            const uint32_t qc = q < m ? q : 0u;                     // (unconditional loads: all in flight at once)
+            key[i] = keys_in[lo + qc];
+            val[i] = FIRST ? lo + q : idx_in[lo + qc];
         }
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {

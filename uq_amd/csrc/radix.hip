@@ -96,8 +96,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_rows_prefix_census_kernel(const
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {                  // (rows of at least eight bytes: the caller's 32-bit round 0 is for wider tables)
             const uint64_t idx = base + (uint64_t)i * RS_THREADS + tid;
-            c64[i] = 0;
-            if (idx < n) { uint64_t v; __builtin_memcpy(&v, table + idx * C, 8); c64[i] = __builtin_bswap64(v); }
+            { uint64_t v; __builtin_memcpy(&v, table + (idx < n ? idx : n - 1) * C, 8); c64[i] = __builtin_bswap64(v); }      // (unconditional: see rs_count_kernel)
         }
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
@@ -135,10 +134,13 @@ __global__ __launch_bounds__(RS_THREADS) void rs_count_kernel(const K* __restric
     h[threadIdx.x] = 0;
     __syncthreads();
     const uint64_t base = (uint64_t)blockIdx.x * RS_TILE;
+    K kv[RS_ITEMS];           // all of the lane's keys are requested before the first is counted (a load behind `idx < n` is followed by its own wait)
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; ++i) { const uint64_t idx = base + (uint64_t)i * RS_THREADS + threadIdx.x; kv[i] = keys[idx < n ? idx : n - 1]; }
 #pragma unroll
     for (int i = 0; i < RS_ITEMS; ++i) {
         uint64_t idx = base + (uint64_t)i * RS_THREADS + threadIdx.x;
-        if (idx < n) atomicAdd(&h[digit_of(keys[idx], shift)], 1u);
+        if (idx < n) atomicAdd(&h[digit_of(kv[i], shift)], 1u);
     }
     __syncthreads();
     block_hist[(uint64_t)threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
@@ -169,11 +171,15 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const K* __restr
     uint32_t rank[RS_ITEMS];
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
+    for (int i = 0; i < RS_ITEMS; ++i) {                   // (unconditional loads, all in flight at once; slots beyond the tile read its first pair and are never used)
+        const uint32_t loc = w * RS_WAVE_KEYS + i * 64 + lane, lc = loc < ntile ? loc : 0u;
+        key[i] = keys_in[tile0 + lc];
+        val[i] = vals_in[tile0 + lc];
+    }
+#pragma unroll
     for (int i = 0; i < RS_ITEMS; ++i) {
         const uint32_t loc = w * RS_WAVE_KEYS + i * 64 + lane;
         const bool valid = loc < ntile;
-        key[i] = valid ? keys_in[tile0 + loc] : 0;
-        val[i] = valid ? vals_in[tile0 + loc] : 0;
         const uint32_t d = digit_of(key[i], shift);
         uint64_t peers = __ballot(valid);
 #pragma unroll

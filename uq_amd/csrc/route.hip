@@ -120,10 +120,13 @@ __global__ __launch_bounds__(RT) void partition_count_kernel(const uint8_t* __re
     if (threadIdx.x < PMAXD) h[threadIdx.x] = 0;
     __syncthreads();
     const uint64_t base = (uint64_t)blockIdx.x * PT;
+    uint32_t dv[PI];          // (unconditional loads, all in flight at once: a load behind `p < n` is followed by its own wait)
+#pragma unroll
+    for (int i = 0; i < PI; ++i) { const uint64_t p = base + (uint64_t)i * RT + threadIdx.x; dv[i] = dest[p < n ? p : n - 1]; }
 #pragma unroll
     for (int i = 0; i < PI; ++i) {
         const uint64_t p = base + (uint64_t)i * RT + threadIdx.x;
-        if (p < n) { const uint32_t d = dest[p]; if (d < ndest) atomicAdd(&h[d], 1u); else atomicMin(bad, (unsigned long long)p); }
+        if (p < n) { const uint32_t d = dv[i]; if (d < ndest) atomicAdd(&h[d], 1u); else atomicMin(bad, (unsigned long long)p); }
     }
     __syncthreads();
     if (threadIdx.x < ndest) tile_counts[(uint64_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
@@ -136,9 +139,11 @@ __global__ __launch_bounds__(RT) void partition_rank_kernel(const uint8_t* __res
     const uint64_t lt = lane ? (~0ull >> (64 - lane)) : 0ull;
     uint32_t d[PI], below[PI];
 #pragma unroll
+    for (int i = 0; i < PI; ++i) { const uint64_t p = base + (uint64_t)i * RT + tid; d[i] = dest[p < n ? p : n - 1]; }
+#pragma unroll
     for (int i = 0; i < PI; ++i) {
         const uint64_t p = base + (uint64_t)i * RT + tid;
-        d[i] = p < n ? dest[p] : 0xFFFFFFFFu;
+        if (p >= n) d[i] = 0xFFFFFFFFu;
         below[i] = 0;
         for (uint32_t k = 0; k < ndest; ++k) {
             const uint64_t b = __ballot(d[i] == k);

@@ -506,8 +506,13 @@ __global__ __launch_bounds__(ST) void heads_count_kernel(const uint8_t* __restri
     __shared__ uint32_t sc[ST / 64];
     const uint64_t j0 = (uint64_t)blockIdx.x * CB + (uint64_t)threadIdx.x * 4;
     uint32_t c = 0;
+    if (j0 + 4 <= n) {            // the lane's four flags in one aligned load (j0 is a multiple of four)
+        const uint32_t w = *(const uint32_t*)(heads + j0) ^ 0x01010101u;             // a zero byte = a flag that is 1
+        c = (uint32_t)__popc(~(((w & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | w) & 0x80808080u);
+    } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) c += (j0 + i < n && heads[j0 + i] == 1) ? 1u : 0u;
+        for (int i = 0; i < 4; ++i) c += (j0 + i < n && heads[j0 + i] == 1) ? 1u : 0u;
+    }
     c = wave_sum(c);
     if (lane_id() == 0) sc[threadIdx.x >> 6] = c;
     __syncthreads();
@@ -520,8 +525,16 @@ __global__ __launch_bounds__(ST) void keys_from_groups2_kernel(const uint8_t* __
     const uint64_t j0 = (uint64_t)blockIdx.x * CB + (uint64_t)threadIdx.x * 4;
     bool hd[4];
     uint32_t c = 0;
+    uint32_t pv[4] = {0, 0, 0, 0};
+    if (j0 + 4 <= n) {            // the four flags in one aligned load, the four permutation entries in one (unconditional: all in flight before the scan's barrier)
+        const uint32_t w = *(const uint32_t*)(heads + j0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { hd[i] = j0 + i < n && heads[j0 + i] == 1; c += hd[i]; }
+        for (int i = 0; i < 4; ++i) { hd[i] = ((w >> (8 * i)) & 0xFFu) == 1u; c += hd[i]; }
+        if (perm) { const uint4 q = *(const uint4*)(perm + j0); pv[0] = q.x; pv[1] = q.y; pv[2] = q.z; pv[3] = q.w; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { hd[i] = j0 + i < n && heads[j0 + i] == 1; c += hd[i]; if (perm && j0 + i < n) pv[i] = perm[j0 + i]; }
+    }
     uint32_t total;
     uint32_t g = block_exclusive_sum<uint32_t, ST / 64>(c, lds, total) + boffs[blockIdx.x];       // heads in front of position j0
 #pragma unroll
@@ -529,7 +542,7 @@ __global__ __launch_bounds__(ST) void keys_from_groups2_kernel(const uint8_t* __
         const uint64_t j = j0 + i;
         if (j >= n) break;
         g += hd[i];                              // inclusive count of heads
-        const uint32_t row = perm ? perm[j] : (uint32_t)j;          // (no perm: the table itself is in sorted order)
+        const uint32_t row = perm ? pv[i] : (uint32_t)j;            // (no perm: the table itself is in sorted order)
         if (key) key[row] = g - 1;
         if (sorted_key) sorted_key[j] = g - 1;
         if (uidx && hd[i]) uidx[g - 1] = row;
