@@ -36,15 +36,14 @@ __global__ __launch_bounds__(IDX_THREADS) void count_newlines_kernel(const uint4
     const uint32_t lane = lane_id(), w = threadIdx.x >> 6;
     const uint64_t v0 = ((uint64_t)blockIdx.x * IDX_TILE + (uint64_t)w * IDX_WAVE_BYTES) / 16 + lane;
     uint32_t c = 0;
+    uint4 q[IDX_LOADS];           // (all requested before the first is looked at: see census_list_kernel)
+#pragma unroll
+    for (int it = 0; it < IDX_LOADS; ++it) { const uint64_t vi = v0 + (uint64_t)it * 64; q[it] = abuf[vi < nvec ? vi : nvec - 1]; }
 #pragma unroll
     for (int it = 0; it < IDX_LOADS; ++it) {
         uint64_t vi = v0 + (uint64_t)it * 64;
-        uint32_t m = 0;
-        if (vi < nvec) {
-            uint4 q = abuf[vi];
-            int64_t p = (int64_t)(vi * 16) - (int64_t)mis;
-            m = nl_mask16(q) & valid_mask16(p, nbytes);
-        }
+        int64_t p = (int64_t)(vi * 16) - (int64_t)mis;
+        const uint32_t m = vi < nvec ? nl_mask16(q[it]) & valid_mask16(p, nbytes) : 0u;
         bitmap[vi] = (uint16_t)m;
         c += __popc(m);
     }

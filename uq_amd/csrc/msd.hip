@@ -61,10 +61,21 @@ __global__ __launch_bounds__(MT) void msd_extract_kernel(const uint8_t* __restri
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint64_t base = tile * TILE;
         uint64_t c64[ITEMS];
+        // (unconditional loads, and the row width tested once for all of them: a load behind `idx < n` or behind msd_chunk0's `C >= 8` is followed by
+        // its own wait -- one row head in flight per lane)
+        if (C >= 8) {
 #pragma unroll
-        for (int i = 0; i < ITEMS; ++i) {
-            const uint64_t idx = base + (uint64_t)i * MT + tid;
-            c64[i] = msd_chunk0(table + (idx < n ? idx : n - 1) * C, C);       // (unconditional: a load behind `idx < n` is followed by its own wait -- one row head in flight per lane)
+            for (int i = 0; i < ITEMS; ++i) {
+                const uint64_t idx = base + (uint64_t)i * MT + tid;
+                uint64_t v; __builtin_memcpy(&v, table + (idx < n ? idx : n - 1) * C, 8);
+                c64[i] = __builtin_bswap64(v);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) {
+                const uint64_t idx = base + (uint64_t)i * MT + tid;
+                c64[i] = msd_chunk0(table + (idx < n ? idx : n - 1) * C, C);
+            }
         }
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
