@@ -19,7 +19,8 @@ One step = one pass of the hot path over the shard, everything from the raw byte
     -> the QNAME passes (uq.py:394-444 layout, 555-678 column typing, 717-736 column encoding) INSIDE that
        second read: the pack kernel holds the QNAME lines in its LDS tiles anyway; a layout guessed on the device from a sample of
        the reads is verified on every read while the fields are parsed; distinct-value counts and the column encoders are queued
-       behind it.  (N > 1: the shards are timed without the QNAME passes -- the layout belongs to the whole file.)
+       behind it.  (N > 1: rank 0's layout guess is broadcast, every rank verifies it on its shard inside its pack kernel, flags / ranges / first
+       occurrences are combined over the ranks in one all-gather and one all-reduce: qname.in_step is true at every N.)
 `value` = FASTQ bytes of all ranks / time, MAX over ranks.
 Besides the contract fields the JSON line carries `roofline` (pack kernel, HIP-event timed inside the
 timed region on the launch stream) and `cpu_baseline` (the faithful per-base Python loops of the
@@ -446,15 +447,6 @@ def main():
         del big
         torch.cuda.empty_cache()
 
-    # ---- end to end (SURVEY.md 8d: "given twice -- kernel and end to end"): the drop-in CLI on a FILE of the same workload, both ways.  File system,
-    # PCIe and tar writing are all inside; this is never `value` (which has its input resident in HBM).
-    if world == 1 and not use_dist and args.workload == 'cfg2' and not args.no_e2e:
-        try:
-            result['end_to_end'] = end_to_end(ctx, args)
-        except OSError as e:                                   # (no room on the tmpfs of this box: say so instead of failing the line)
-            result['end_to_end'] = {'skipped': '%s: %s' % (type(e).__name__, e)}
-        torch.cuda.empty_cache()
-
     # ---- the global --sort legs (the north_star's scaling claim: ">= 6x further at 8 GPUs for --sort DNA"; BASELINE configs[3] is
     # `--sort QUAL --raw DNA QUAL QNAME` over 8 GPUs).  STRONG scaling: args.sort_reads reads over all N GPUs (200 M / N each), so
     # that the N = 1 and N = 8 lines divide directly.  Table movements of the two mixes, through uq_amd.dist (N = 1: the same calls
@@ -464,6 +456,17 @@ def main():
     #                   order and fetched in the DNA order                                                (uq.py:784-798 twice)
     if args.sort_reads > 0 and args.workload == 'cfg2':
         result['sort_leg'] = sort_legs(ctx, args, rank, world, use_dist, fence, fetch, red_dev)
+    # (after the sort legs: the CLI's 8 GB of tmpfs files and pinned staging buffers leave the host busy for a while -- the legs' host round trips
+    # read 60 ms before it and 78 ms behind it)
+    # ---- end to end (SURVEY.md 8d: "given twice -- kernel and end to end"): the drop-in CLI on a FILE of the same workload, both ways.  File system,
+    # PCIe and tar writing are all inside; this is never `value` (which has its input resident in HBM).
+    if world == 1 and not use_dist and args.workload == 'cfg2' and not args.no_e2e:
+        try:
+            result['end_to_end'] = end_to_end(ctx, args)
+        except OSError as e:                                   # (no room on the tmpfs of this box: say so instead of failing the line)
+            result['end_to_end'] = {'skipped': '%s: %s' % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
+
     if rank == 0:
         print(json.dumps(result), file=json_out, flush=True)
     if use_dist:
