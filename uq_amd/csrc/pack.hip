@@ -393,6 +393,40 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && (NTRICK || QN)) ? 4 : 5) void
     const uint64_t S = gridDim.x;
     struct Bounds { uint64_t g0, g1; uint32_t pT, pA, pB; };       // pT, pA, pB: PackLists::place
     struct Regs { uint4 v[NV]; uint64_t m0; uint64_t g0; uint32_t skew, nvec, Rt, mrel, mraw; bool ok; };      // (lists: line start - g0 + skew = mrel + mraw)
+    // The bounds of a tile two steps ahead are requested by VECTOR loads, a dword (or an index entry) a lane, and put together with v_readlane when the tile's
+    // bytes are requested a step later.  (As scalar loads -- which the compiler makes of a uniform address -- they were followed by `s_waitcnt lgkmcnt(0)` on the
+    // spot: the kernel is short of SGPRs, the loaded values went straight to VGPR lanes, and every tile began with a round trip to the L2.  A vector load waits
+    // behind phase C's `vmcnt(0)`, a whole tile later.)
+    struct RawBounds { uint32_t lo, hi; };
+    auto load_raw = [&](uint64_t tt) {
+        RawBounds x{0u, 0u};
+        if (tt < ntiles) {
+            const uint32_t ln = lane_id();
+            if constexpr (lists) {                // lanes 0 .. 7: the six dwords of the tile's record and the two of the next record's start
+                x.lo = ((const uint32_t*)(trec + tt))[ln < 8u ? ln : 0u];
+            } else {
+                const uint32_t Rn = (uint32_t)((n - tt * R) < R ? (n - tt * R) : R);
+                const uint64_t v = ls[4 * (first + tt * R) + (ln == 1u ? 4 * Rn : 0u)];           // lane 0: the tile's start, lane 1: its end
+                x.lo = (uint32_t)v; x.hi = (uint32_t)(v >> 32);
+            }
+        }
+        return x;
+    };
+    auto bounds_of = [&](uint64_t tt, const RawBounds& x) {
+        auto lane = [](uint32_t v, int k) { return (uint32_t)__builtin_amdgcn_readlane((int)v, k); };       // (the builtin returns int: without the cast a set bit 31 -- an offset beyond 2 GiB -- would be sign-extended into the upper half)
+        Bounds b{0, 0, 0, 0, 0};
+        if (tt < ntiles) {
+            if constexpr (lists) {
+                b.g0 = (uint64_t)lane(x.lo, 0) | ((uint64_t)lane(x.lo, 1) << 32);
+                b.pT = lane(x.lo, 2); b.pA = lane(x.lo, 3); b.pB = lane(x.lo, 4);
+                b.g1 = (uint64_t)lane(x.lo, 6) | ((uint64_t)lane(x.lo, 7) << 32);
+            } else {
+                b.g0 = (uint64_t)lane(x.lo, 0) | ((uint64_t)lane(x.hi, 0) << 32);
+                b.g1 = (uint64_t)lane(x.lo, 1) | ((uint64_t)lane(x.hi, 1) << 32);
+            }
+        }
+        return b;
+    };
     auto load_bounds = [&](uint64_t tt) {
         Bounds b{0, 0, 0, 0, 0};
         if (tt < ntiles) {
@@ -659,16 +693,15 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && (NTRICK || QN)) ? 4 : 5) void
     };
 
     uint64_t t = blockIdx.x;
-    Bounds b_next = load_bounds(t + S);
+    RawBounds b_next = load_raw(t + S);
     Regs cur = issue(t * R, tile_reads(t), load_bounds(t));
 #ifndef PK_NO_EARLY_WAIT
     __builtin_amdgcn_s_waitcnt(0x0F70);          // (every path into a tile's phase A has waited for the tile's bytes: see phase C)
 #endif
     for (; t < ntiles; t += S) {
-        const Bounds b_nn = load_bounds(t + 2 * S);
         if (cur.ok) {
             const Regs now = cur;
-            do_tile(t * R, now, [&] { cur = issue((t + S) * R, tile_reads(t + S), b_next); b_next = b_nn; });
+            do_tile(t * R, now, [&] { cur = issue((t + S) * R, tile_reads(t + S), bounds_of(t + S, b_next)); b_next = load_raw(t + 2 * S); });
         } else {
             // the tile's records add up to more than the stage holds (R comes from the average record length): pack it in
             // pieces of g.Rs reads, which always fit, one after the other; then pick the pipeline up again
@@ -694,7 +727,7 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && (NTRICK || QN)) ? 4 : 5) void
                 do_tile(rf, piece, [] {});
                 __syncthreads();                      // the next piece overwrites the stage and the out tile
             }
-            cur = issue((t + S) * R, tile_reads(t + S), b_next); b_next = b_nn;
+            cur = issue((t + S) * R, tile_reads(t + S), bounds_of(t + S, b_next)); b_next = load_raw(t + 2 * S);
 #ifndef PK_NO_EARLY_WAIT
             __builtin_amdgcn_s_waitcnt(0x0F70);
 #endif
