@@ -871,6 +871,12 @@ __global__ __launch_bounds__(EM_THREADS, DS_OCC) void decode_stream_kernel(EmitG
                 }
             }
         }
+        // The next tile's rows and metadata were requested before the QNAME lines were rendered: wait for them HERE, before the tile's first store.  With a load
+        // pending, the compiler puts a `s_waitcnt vmcnt(0)` in front of every loop that stores (its preheader rule for targets whose stores share the loads'
+        // counter): in front of the group loop it waited for the rows just requested, in front of the front pieces for all of the groups' stores to be
+        // acknowledged, in front of the QNAME copy for the front pieces', in front of the next tile's phase A for the copy's -- four round trips a tile, which
+        // is what the ablations saw (the kernel's time did not depend on where its stores went).  Behind this wait nothing is pending and no store waits.
+        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0); expcnt / lgkmcnt left alone
         // ---- whole groups -> HBM
         const uint32_t od = tg.o_ind + skd + tg.Cd - 1, oq = tg.o_inq + skq + tg.Cq - 1;      // last byte of row 0
         if (tg.variable || tg.RS == 0) {                  // (RS = 0: fixed-length reads of more groups than the workgroup has lanes)
