@@ -239,10 +239,6 @@ __global__ __launch_bounds__(MT) void msd_scatter_kernel(const K* __restrict__ k
             }
         }
         __syncthreads();
-        // Every load of the tile has long been used; saying so HERE keeps the stores below from waiting for one another.  (The last key load's wait is a
-        // counted one; along the paths that skip an item's `if (q < m)` block the compiler still sees that load pending when it reuses the register, and
-        // puts a vmcnt(0) into every block -- which at run time waits for the previous block's two stores to be acknowledged: sixteen round trips a tile.)
-        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
             const uint32_t q = i * MT + tid;

@@ -222,7 +222,6 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const K* __restr
         }
     }
     __syncthreads();
-    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): no load is pending any more -- the stores below must not wait for one another (msd_scatter_kernel has the story)
 #pragma unroll
     for (int i = 0; i < RS_ITEMS; ++i) {
         const uint32_t p = i * RS_THREADS + tid;
