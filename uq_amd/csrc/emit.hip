@@ -29,12 +29,16 @@ struct EmitGeom {
     const uint32_t* map_offs[EM_MAXCOLS]; // and their offsets [nmap + 1]
 };
 
+// The column / string-table pointers reach the kernels inside a struct (kept in LDS): generic pointers, whose loads would be FLAT -- counted in lgkmcnt as
+// well, returning out of order, so that the next wait of any kind becomes `vmcnt(0) lgkmcnt(0)`.  They point to device memory: said so, the loads are global.
+template <typename T> using gptr = const __attribute__((address_space(1))) T*;
+template <typename T> __device__ __forceinline__ gptr<T> as_global(const void* p) { return (gptr<T>)(uintptr_t)p; }
 __device__ __forceinline__ uint64_t load_col(const void* p, uint32_t itemsize, uint64_t r) {
     switch (itemsize) {
-        case 1: return ((const uint8_t*)p)[r];
-        case 2: return ((const uint16_t*)p)[r];
-        case 4: return ((const uint32_t*)p)[r];
-        default: return ((const uint64_t*)p)[r];
+        case 1: return as_global<uint8_t>(p)[r];
+        case 2: return as_global<uint16_t>(p)[r];
+        case 4: return as_global<uint32_t>(p)[r];
+        default: return as_global<uint64_t>(p)[r];
     }
 }
 __device__ __forceinline__ uint32_t ndigits_u64(uint64_t v) {
@@ -54,9 +58,10 @@ __device__ __forceinline__ uint32_t field_from_raw(const EmitGeom& g, uint32_t c
         // string instead of whatever lies behind the offsets (callers that want the error ask uq_check_index_range first)
         const uint64_t nmap = (uint64_t)g.add[c];
         if (nmap && raw >= nmap) raw = nmap - 1;
-        moff = g.map_offs[c][raw];
+        const gptr<uint32_t> mo = as_global<uint32_t>(g.map_offs[c]);
+        moff = mo[raw];
         mag = 0; neg = false;
-        return g.map_offs[c][raw + 1] - moff;
+        return mo[raw + 1] - moff;
     }
     const int64_t v = (int64_t)raw + g.add[c];      // str(row[i] + min): columns narrower than 64 bit never wrap here
     neg = v < 0 && g.itemsize[c] < 8;               // a uint64 column without offset prints as unsigned
@@ -67,6 +72,21 @@ __device__ __forceinline__ uint32_t field_from_raw(const EmitGeom& g, uint32_t c
 }
 __device__ __forceinline__ uint32_t field_len(const EmitGeom& g, uint32_t c, uint64_t r, uint64_t& mag, bool& neg, uint32_t& moff) {
     return field_from_raw(g, c, load_col(g.col[c], g.itemsize[c], r), mag, neg, moff);
+}
+// The tile kernels request the next tile's rows right behind their first barrier and want them in flight through the whole of phase B.  vmcnt counts every
+// vector-memory operation in issue order, and the compiler merges "a load is pending" over all paths: a load in a COLD branch of phase B (a column value that
+// was not prefetched, a mapping column's characters) left every later reuse of its registers behind an unconditional `s_waitcnt vmcnt(0)` -- which, at run
+// time, waited for the rows just requested.  The cold loads therefore live in functions of their own: a call waits for everything on both sides, but only
+// where it is executed.
+struct FieldCold { uint64_t mag; uint32_t fl, moff, neg; };          // (returned in registers: out-parameters by address would put the hot path's copies on the stack)
+__device__ __noinline__ FieldCold field_len_cold(const EmitGeom* g, uint32_t c, uint64_t r) {
+    FieldCold f; bool neg;
+    f.fl = field_len(*g, c, r, f.mag, neg, f.moff); f.neg = neg ? 1u : 0u;
+    return f;
+}
+__device__ __noinline__ void copy_chars_cold(uint8_t* o, const uint8_t* src, uint32_t n) {      // (o: an LDS address, passed as a generic pointer)
+    const gptr<uint8_t> gs = as_global<uint8_t>(src);
+    for (uint32_t k = 0; k < n; ++k) o[k] = gs[k];
 }
 
 __global__ void emit_sizes_kernel(EmitGeom g, const uint32_t* __restrict__ len, uint64_t n, uint64_t* __restrict__ sizes) {
@@ -334,7 +354,7 @@ __global__ __launch_bounds__(EM_THREADS, 4) void emit_tile_kernel(EmitGeom g, Ti
         const uint64_t r0 = tt * R;
         const uint32_t Rt = (uint32_t)((n - r0) < R ? (n - r0) : R);
         if (tid <= Rt) x.off = offsets[r0 + tid];
-        if (tid < Rt) x.L = len ? len[r0 + tid] : g.dna_max;
+        if (tid < Rt) { x.L = g.dna_max; if (len) x.L = len[r0 + tid]; }      // (not `len ? len[i] : g.dna_max`: the compiler selects between the two ADDRESSES -- kernel argument or table -- and the load becomes flat)
         if (one_item && tid < Rt * ncols) { const uint32_t i = tid / ncols, c = tid - i * ncols; x.raw = load_col(sg.col[c], sg.itemsize[c], r0 + i); }
         return x;
     };
@@ -427,10 +447,10 @@ __global__ __launch_bounds__(EM_THREADS, 4) void emit_tile_kernel(EmitGeom g, Ti
             for (uint32_t k = 0; k < c; ++k) pos += flen[i * ncols + k] + 1u;
             uint8_t* o = tile + ro(i) + pos;
             uint64_t mag = my_mag; bool neg = my_neg; uint32_t moff = my_moff;
-            const uint32_t fl = one_item ? my_fl : field_len(sg, c, r0 + i, mag, neg, moff);
+            uint32_t fl = my_fl;
+            if (!one_item) { const FieldCold f = field_len_cold(&sg, c, r0 + i); fl = f.fl; mag = f.mag; neg = f.neg != 0; moff = f.moff; }
             if (sg.map_chars[c]) {
-                const uint8_t* mc = sg.map_chars[c];
-                for (uint32_t k = 0; k < fl; ++k) o[k] = mc[moff + k];
+                copy_chars_cold(o, sg.map_chars[c] + moff, fl);
             } else {
                 uint32_t k = fl;
                 if (mag >> 32) { do { o[--k] = (uint8_t)('0' + mag % 10); mag /= 10; } while (mag); }
@@ -667,6 +687,7 @@ __global__ __launch_bounds__(EM_THREADS, 4) void emit_tile_kernel(EmitGeom g, Ti
             }
         }
         __syncthreads();
+        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the next tile's rows, requested a whole phase ago -- with nothing pending, none of the store loops below is entered behind a wait (decode_stream_kernel tells the story)
         // ---- 3: LDS image -> HBM (tile[skew ...] is out[o0 ...]; interior vectors are 16-byte aligned on both sides)
         {
             uint8_t* dst = out + o0 - skew;                            // 16-byte aligned
@@ -838,9 +859,11 @@ __global__ __launch_bounds__(EM_THREADS, DS_OCC) void decode_stream_kernel(EmitG
                 for (uint32_t k = 0; k < c; ++k) pos += flen[i * ncols + k] + 1u;
                 uint8_t* o = tile + qst[i] + pos;
                 uint64_t mag = my_mag; bool neg = my_neg; uint32_t moff = my_moff;
+                // (inline here, unlike emit_tile_kernel: this kernel sits at its 128 registers, and calls -- their live registers saved around them -- made it spill;
+                // its one explicit wait below covers what these loads leave pending)
                 const uint32_t fl = one_item ? my_fl : field_len(sg, c, r0 + i, mag, neg, moff);
                 if (sg.map_chars[c]) {
-                    const uint8_t* mc = sg.map_chars[c];
+                    const gptr<uint8_t> mc = as_global<uint8_t>(sg.map_chars[c]);
                     for (uint32_t k = 0; k < fl; ++k) o[k] = mc[moff + k];
                 } else {
                     uint32_t k = fl;
