@@ -60,32 +60,28 @@ __global__ __launch_bounds__(MT) void msd_extract_kernel(const uint8_t* __restri
     const uint64_t ntiles = (n + TILE - 1) / TILE;
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint64_t base = tile * TILE;
-        uint64_t c64[ITEMS];
-        // (unconditional loads, and the row width tested once for all of them: a load behind `idx < n` or behind msd_chunk0's `C >= 8` is followed by
-        // its own wait -- one row head in flight per lane)
+        auto take = [&](uint64_t idx, uint64_t c) {
+            a &= c; o |= c;
+            const K k = (K)((c << z) >> (64 - 8 * sizeof(K)));
+            keys[idx] = k;
+            atomicAdd(&h[(uint32_t)(k >> shift)], 1u);
+        };
         if (C >= 8) {
+            // all of the lane's row heads are requested before the first is used (unconditional loads with a clamped row number: a load behind `idx < n` is
+            // followed by its own wait -- one head in flight per lane), and the row width is tested once for all of them
+            uint64_t c64[ITEMS];
 #pragma unroll
             for (int i = 0; i < ITEMS; ++i) {
                 const uint64_t idx = base + (uint64_t)i * MT + tid;
                 uint64_t v; __builtin_memcpy(&v, table + (idx < n ? idx : n - 1) * C, 8);
                 c64[i] = __builtin_bswap64(v);
             }
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) { const uint64_t idx = base + (uint64_t)i * MT + tid; if (idx < n) take(idx, c64[i]); }
         } else {
-#pragma unroll
-            for (int i = 0; i < ITEMS; ++i) {
-                const uint64_t idx = base + (uint64_t)i * MT + tid;
-                c64[i] = msd_chunk0(table + (idx < n ? idx : n - 1) * C, C);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < ITEMS; ++i) {
-            const uint64_t idx = base + (uint64_t)i * MT + tid;
-            if (idx < n) {
-                a &= c64[i]; o |= c64[i];
-                const K k = (K)((c64[i] << z) >> (64 - 8 * sizeof(K)));
-                keys[idx] = k;
-                atomicAdd(&h[(uint32_t)(k >> shift)], 1u);
-            }
+            // rows of fewer than eight bytes (up to eight byte loads a row): one row at a time -- sixteen rows' byte loads at once cost the kernel 252 VGPRs
+#pragma unroll 1
+            for (int i = 0; i < ITEMS; ++i) { const uint64_t idx = base + (uint64_t)i * MT + tid; if (idx < n) take(idx, msd_chunk0(table + idx * C, C)); }
         }
     }
 #pragma unroll
