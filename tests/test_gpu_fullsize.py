@@ -91,3 +91,35 @@ def test_table_build_properties_full_size(ctx, packed):
     assert t.equal(pay.view(C, N)[:, r].T.contiguous(), dna.view(N, C)[r])
     pay = ops.pattern(ctx, dna, N, C, '3.2')
     assert t.equal(pay.view(N, C)[N - 1 - r], dna.view(N, C)[r])
+
+
+@pytest.mark.parametrize('with_qname', [True, False], ids=['qname', 'plain'])
+def test_default_encode_form_beyond_2_gib(ctx, packed, with_qname):
+    """The product's default step -- queued census, no record index, pack + statistics (+ QNAME fields) in one kernel -- over the 3.4 GB buffer: offsets
+    beyond 2^31 reach the kernel through its tile records (round 4: a sign-extended `v_readlane` of such an offset faulted here and on nothing smaller).
+    Tables and statistics must be those of the indexed plain kernels."""
+    from uq_amd.device import SideContext
+    t = ctx.torch
+    d_buf, hs = packed['buf'], packed['hs']
+    side = SideContext(ctx)
+    st = ops.stats_new(ctx)
+    census = ops.ChunkedCensus(ctx, d_buf); census.chunk(0, d_buf.numel()); census.end_async()
+    guess, rpb = ops.head_guess(side, d_buf, head_bytes=ops.HEAD_BYTES_SMALL, head_reads=ops.HEAD_READS_INDEXED)
+    cap = int(d_buf.numel() * rpb * 1.02) + 1024
+    guess.avg_record_bytes = int(1.0 / rpb)
+    fq = None
+    if with_qname:
+        fq = ops.FusedQname(ctx, cap); ops.qname_guess_async(ctx, d_buf, None, fq)
+    sp = ops.pack_stats_async(ctx, d_buf, None, cap, guess, st=st, fq=fq)
+    nlines, ok = census.wait()
+    assert ok and nlines == 4 * N and sp is not None
+    assert t.equal(sp[0][:N * guess.dna_bytes_per_row], packed['dna']) and t.equal(sp[1][:N * guess.quality_bytes_per_row], packed['qual'])
+    h2 = ops.stats_fetch(ctx, sp[3])
+    assert not h2.incomplete and np.array_equal(h2.counts, hs.counts) and (h2.len_min, h2.len_max, h2.max_record_bytes) == (hs.len_min, hs.len_max, hs.max_record_bytes)
+    if with_qname:
+        from uq_amd import qname_device
+        ops.qname_fused_finish(ctx, fq)
+        got = qname_device.analyse_fused(ctx, fq, N)
+        want = qname_device.analyse_device(ctx, d_buf, packed['ls'], N)
+        assert got is not None and want is not None and got[:4] == want[:4]
+        for a, b in zip(got[4], want[4]): assert t.equal(a, b)
