@@ -95,7 +95,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--reads', type=int, default=10_000_000, help='reads per GPU (default: BASELINE configs[1])')
     ap.add_argument('--length', type=int, default=150)
-    ap.add_argument('--cpu-sample', type=int, default=100_000, help='reads timed on the host for cpu_baseline (0 = skip)')
+    ap.add_argument('--cpu-sample', type=int, default=250_000, help='reads timed on the host for cpu_baseline (0 = skip; the default is ~12 s of the Python port on one core)')
     ap.add_argument('--north-star-reads', type=int, default=200_000_000,
                     help='N = 1: the same step timed once more at the north_star\'s single-GPU size (200 M x 150 bp), reported as '
                          'north_star_200M; 0 = skip')
