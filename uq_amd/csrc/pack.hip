@@ -693,15 +693,26 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && (NTRICK || QN)) ? 4 : 5) void
     };
 
     uint64_t t = blockIdx.x;
-    RawBounds b_next = load_raw(t + S);
+    // (only the forms built for four workgroups per CU take the vector loads: at the 96 registers of the others they spill -- 27 dwords in the indexed
+    // pack + statistics kernel, 1.40 -> 1.50 ms -- and those keep the scalar loads, requested at the top of the tile before)
+    constexpr bool VBOUNDS = STATS && (NTRICK || QN);
+    using NextBounds = std::conditional_t<VBOUNDS, RawBounds, Bounds>;
+    auto fetch_next = [&](uint64_t tt) -> NextBounds { if constexpr (VBOUNDS) return load_raw(tt); else return load_bounds(tt); };
+    auto next_bounds = [&](uint64_t tt, const NextBounds& x) -> Bounds { if constexpr (VBOUNDS) return bounds_of(tt, x); else return x; };
+    NextBounds b_next = fetch_next(t + S);
     Regs cur = issue(t * R, tile_reads(t), load_bounds(t));
 #ifndef PK_NO_EARLY_WAIT
     __builtin_amdgcn_s_waitcnt(0x0F70);          // (every path into a tile's phase A has waited for the tile's bytes: see phase C)
 #endif
     for (; t < ntiles; t += S) {
+        NextBounds b_nn{};
+        if constexpr (!VBOUNDS) b_nn = fetch_next(t + 2 * S);
         if (cur.ok) {
             const Regs now = cur;
-            do_tile(t * R, now, [&] { cur = issue((t + S) * R, tile_reads(t + S), bounds_of(t + S, b_next)); b_next = load_raw(t + 2 * S); });
+            do_tile(t * R, now, [&] {
+                cur = issue((t + S) * R, tile_reads(t + S), next_bounds(t + S, b_next));
+                if constexpr (VBOUNDS) b_next = fetch_next(t + 2 * S); else b_next = b_nn;
+            });
         } else {
             // the tile's records add up to more than the stage holds (R comes from the average record length): pack it in
             // pieces of g.Rs reads, which always fit, one after the other; then pick the pipeline up again
@@ -727,7 +738,8 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && (NTRICK || QN)) ? 4 : 5) void
                 do_tile(rf, piece, [] {});
                 __syncthreads();                      // the next piece overwrites the stage and the out tile
             }
-            cur = issue((t + S) * R, tile_reads(t + S), bounds_of(t + S, b_next)); b_next = load_raw(t + 2 * S);
+            cur = issue((t + S) * R, tile_reads(t + S), next_bounds(t + S, b_next));
+            if constexpr (VBOUNDS) b_next = fetch_next(t + 2 * S); else b_next = b_nn;
 #ifndef PK_NO_EARLY_WAIT
             __builtin_amdgcn_s_waitcnt(0x0F70);
 #endif
