@@ -240,3 +240,12 @@ def test_decisions_from_the_nonzero_counters_equal_the_dense_ones():
         if n == len(keys):
             assert np.array_equal(hs.counts.astype(np.int64), c)
             assert analysis.decide_from_stats(hs, first_seen=fs) == analysis.decide_from_counts(c, 10, 11, first_seen=fs)
+
+
+def test_isa_scan_reads_a_kernel_file():
+    """tools/isa_scan.py (no GPU: hipcc cross-compiles): the per-kernel report of loads / stores / waits / spills comes out for a small source file."""
+    import subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(repo, 'tools', 'isa_scan.py'), 'scan.hip', '--all'], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert 'scan_tile_kernel' in r.stdout and 'vgpr' in r.stdout and 'lwl' in r.stdout
