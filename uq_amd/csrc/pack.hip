@@ -262,12 +262,14 @@ constexpr int PK_NV_STATS = 4;   // the fused pack + statistics kernel keeps a f
 // copy for the 2-bit bases -- a counter's address is then `byte of the bin word << 2` plus an immediate, one SDWA shift per atomic, 10 VALU
 // instructions per group of eight pairs instead of 20; the lanes that meet in a counter cost more than that saves, 1.66 -> 1.71 ms: PK_ONE_COPY.)
 #ifdef PK_ONE_COPY
-constexpr int pks_copies(int bd) { return bd == 3 ? 4 : 1; }
+constexpr int pks_copies(int bd, bool four_wg) { return bd == 3 ? 4 : 1; }
 #else
-constexpr int pks_copies(int bd) { return 4; }
+// (the forms built for four workgroups per CU -- QNAME phase or N-trick -- have the LDS for eight copies of the 256 bins: 1.56 -> 1.54 ms, two copies 1.60;
+// the others would drop from four workgroups per CU to three)
+constexpr int pks_copies(int bd, bool four_wg) { return bd == 2 && four_wg ? 8 : 4; }
 #endif
 constexpr uint32_t pks_bins(int bd) { return bd == 3 ? 512u : 256u; }     // bin = base code << 6 | quality code (3-bit bases: nine bits)
-constexpr uint32_t pks_words(int bd) { return pks_bins(bd) * pks_copies(bd) + 128; }
+constexpr uint32_t pks_words(int bd, bool four_wg) { return pks_bins(bd) * pks_copies(bd, four_wg) + 128; }
 
 // The queued forms take their line starts from the census's lists instead of an expanded index (lines.h): a record per pack tile (TileRec): the start of
 // the tile's first record (entry `ntiles`: the end of the last record), where the newline in front of it sits (census tile,
@@ -349,10 +351,11 @@ __global__ __launch_bounds__(PK_THREADS, (STATS && (NTRICK || QN)) ? 4 : 5) void
     if (NTRICK) l_nq[tid] = lut.n_qual[tid];
     RecordAcc acc;
     bool incomplete = false;
-    constexpr int PKS_COPIES = pks_copies(BD);
-    __shared__ uint32_t cnt_tab[STATS ? pks_words(BD) : 1];      // [bins][PKS_COPIES], then [128] N-trick base by quality character
+    constexpr bool FOUR_WG = STATS && (NTRICK || QN);
+    constexpr int PKS_COPIES = pks_copies(BD, FOUR_WG);
+    __shared__ uint32_t cnt_tab[STATS ? pks_words(BD, FOUR_WG) : 1];      // [bins][PKS_COPIES], then [128] N-trick base by quality character
     uint32_t fill_pairs = 0, n_pairs = 0;                        // pairs counted in bin 0 / bin n_code that were fills / N-trick positions
-    constexpr uint32_t PKS_BINS = pks_bins(BD), PKS_WORDS = pks_words(BD);
+    constexpr uint32_t PKS_BINS = pks_bins(BD), PKS_WORDS = pks_words(BD, FOUR_WG);
     if (STATS) for (uint32_t i = tid; i < PKS_WORDS; i += PK_THREADS) cnt_tab[i] = 0;       // the first tile's barrier orders it
     if (VAR) for (uint32_t i = tid; i < (g.out_bytes >> 4); i += PK_THREADS) ((uint4*)out_d)[i] = make_uint4(0, 0, 0, 0);       // (likewise; every copy-out clears what it reads)
     QnLds* qn = (QnLds*)(l_nq + 256);                            // the QNAME phase's state (uq_pack_stats_qname only)
@@ -1004,7 +1007,7 @@ static int pack_impl(uq_ctx* ctx, const uint8_t* d_buf, const uint64_t* d_line_s
     if (d_stats && ntrick_bases == 1 && hp->n_qual[nchar] >= nq) return 0;    // the N-trick code is no quality of the alphabet (Q9): exact kernels only
     if (d_stats && (!fast || (bd != 2 && bd != 3) || bq > 6)) return 0;  // the fused kernels exist for the lookup-free paths (2- / 3-bit bases, <= 64 contiguous qualities) only
     const bool var_deal = d_stats && use_lists && hp->variable;
-    const size_t lds_static = d_stats ? pks_words((int)bd) * 4 : 4;        // the kernels' count table
+    const size_t lds_static = d_stats ? pks_words((int)bd, ntrick || d_q != nullptr) * 4 : 4;        // the kernels' count table
     const size_t lds = 16 + (size_t)g.stage_bytes + g.out_bytes + (4 * R + 4) * 4 + 3 * 512 + (d_stats ? sizeof(QnLds) : 0);
     UQ_REQUIRE(lds + lds_static <= 160 * 1024, "uq_pack: tile needs %zu bytes of LDS", lds + lds_static);
     const uint64_t tiles = (nreads + R - 1) / R;
