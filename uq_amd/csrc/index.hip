@@ -55,50 +55,68 @@ __global__ __launch_bounds__(IDX_THREADS) void count_newlines_kernel(const uint4
 
 // The list form.  Stream order inside a tile = (wave, load, lane, bit); the counts of a lane's four vectors are scanned two
 // to a word (16-bit fields: a wave's sum stays below 2^16).
+#ifndef CENSUS_TPW
+#define CENSUS_TPW 2        // (same box: one tile a workgroup 2.46 ms per bench step, two 2.42, four 2.47)
+#endif
+// TPW tiles per workgroup, one behind the other: the next tile's vectors are requested before the current one's are looked at.
+template <int TPW>
 __global__ __launch_bounds__(IDX_THREADS) void census_list_kernel(const uint4* __restrict__ abuf, uint32_t mis, uint64_t nbytes, uint64_t nvec,
                                                                    uint32_t* __restrict__ partials, uint16_t* __restrict__ list,
-                                                                   uint32_t* __restrict__ overflow, uint64_t tile0) {
-    // one tile per workgroup, like the bitmap form: a persistent, register-prefetching variant (the shape that pays in the
-    // pack / statistics kernels) was slower here (0.81 vs 0.65 ms) -- eight small workgroups per CU already keep HBM busy
-    __shared__ uint32_t lds[IDX_THREADS / 64];
+                                                                   uint32_t* __restrict__ overflow, uint64_t tile0, uint64_t tile_end) {
+    __shared__ uint32_t lds[2][IDX_THREADS / 64];               // (by the parity of the tile's turn: one barrier a tile)
     const uint32_t lane = lane_id(), w = threadIdx.x >> 6;
-    const uint64_t tile = tile0 + blockIdx.x;                 // tile0: the chunked census (uq_count_lines_chunk) walks the buffer in pieces
-    const uint64_t v0 = (tile * IDX_TILE + (uint64_t)w * IDX_WAVE_BYTES) / 16 + lane;
-    uint32_t m[IDX_LOADS];
+    uint64_t tile = tile0 + (uint64_t)blockIdx.x * TPW;         // tile0: the chunked census (uq_count_lines_chunk) walks the buffer in pieces
     // all of the lane's vectors are requested before the first is looked at (a load inside the `vi < nvec` branch was followed by its own wait: one
     // vector in flight per lane); beyond the stream the last vector is read again and masked out
+    auto request = [&](uint64_t tl, uint4 (&q)[IDX_LOADS]) {
+        const uint64_t v0 = (tl * IDX_TILE + (uint64_t)w * IDX_WAVE_BYTES) / 16 + lane;
+#pragma unroll
+        for (int it = 0; it < IDX_LOADS; ++it) { const uint64_t vi = v0 + (uint64_t)it * 64; q[it] = abuf[vi < nvec ? vi : nvec - 1]; }
+    };
     uint4 q[IDX_LOADS];
-#pragma unroll
-    for (int it = 0; it < IDX_LOADS; ++it) { const uint64_t vi = v0 + (uint64_t)it * 64; q[it] = abuf[vi < nvec ? vi : nvec - 1]; }
-#pragma unroll
-    for (int it = 0; it < IDX_LOADS; ++it) {
-        const uint64_t vi = v0 + (uint64_t)it * 64;
-        const int64_t p = (int64_t)(vi * 16) - (int64_t)mis;
-        m[it] = vi < nvec ? nl_mask16(q[it]) & valid_mask16(p, nbytes) : 0u;
-    }
-    const uint32_t c0 = __popc(m[0]), c1 = __popc(m[1]), c2 = __popc(m[2]), c3 = __popc(m[3]);
-    const uint32_t i01 = wave_inclusive_sum(c0 | (c1 << 16)), i23 = wave_inclusive_sum(c2 | (c3 << 16));
-    const uint32_t t01 = __shfl(i01, 63, 64), t23 = __shfl(i23, 63, 64);
-    const uint32_t T0 = t01 & 0xFFFFu, T1 = t01 >> 16, T2 = t23 & 0xFFFFu, T3 = t23 >> 16;
-    if (lane == 0) lds[w] = T0 + T1 + T2 + T3;
-    __syncthreads();
-    uint32_t base = 0, total = 0;
-#pragma unroll
-    for (uint32_t i = 0; i < IDX_THREADS / 64; ++i) { const uint32_t x = lds[i]; if (i < w) base += x; total += x; }
-    if (threadIdx.x == 0) partials[tile] = total;
-    const uint32_t ex[IDX_LOADS] = {base + (i01 & 0xFFFFu) - c0, base + T0 + (i01 >> 16) - c1, base + T0 + T1 + (i23 & 0xFFFFu) - c2,
-                                    base + T0 + T1 + T2 + (i23 >> 16) - c3};
-    uint16_t* slot = list + tile * IDX_LIST_CAP;
+    request(tile, q);
     bool over = false;
 #pragma unroll
-    for (int it = 0; it < IDX_LOADS; ++it) {
-        uint32_t mm = m[it], k = ex[it];
-        const uint32_t pos0 = ((w * IDX_LOADS + it) * 64 + lane) * 16;
-        while (mm) {
-            const uint32_t b = (uint32_t)__ffs((int)mm) - 1u;
-            mm &= mm - 1;
-            if (k < IDX_LIST_CAP) slot[k] = (uint16_t)(pos0 + b); else over = true;
-            ++k;
+    for (int turn = 0; turn < TPW; ++turn, ++tile) {
+        if (tile >= tile_end) break;
+        uint4 qn[IDX_LOADS];
+        if (turn + 1 < TPW && tile + 1 < tile_end) request(tile + 1, qn);
+        const uint64_t v0 = (tile * IDX_TILE + (uint64_t)w * IDX_WAVE_BYTES) / 16 + lane;
+        uint32_t m[IDX_LOADS];
+#pragma unroll
+        for (int it = 0; it < IDX_LOADS; ++it) {
+            const uint64_t vi = v0 + (uint64_t)it * 64;
+            const int64_t p = (int64_t)(vi * 16) - (int64_t)mis;
+            m[it] = vi < nvec ? nl_mask16(q[it]) & valid_mask16(p, nbytes) : 0u;
+        }
+        const uint32_t c0 = __popc(m[0]), c1 = __popc(m[1]), c2 = __popc(m[2]), c3 = __popc(m[3]);
+        const uint32_t i01 = wave_inclusive_sum(c0 | (c1 << 16)), i23 = wave_inclusive_sum(c2 | (c3 << 16));
+        const uint32_t t01 = __shfl(i01, 63, 64), t23 = __shfl(i23, 63, 64);
+        const uint32_t T0 = t01 & 0xFFFFu, T1 = t01 >> 16, T2 = t23 & 0xFFFFu, T3 = t23 >> 16;
+        uint32_t* l = lds[turn & 1];
+        if (lane == 0) l[w] = T0 + T1 + T2 + T3;
+        __syncthreads();
+        uint32_t base = 0, total = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < IDX_THREADS / 64; ++i) { const uint32_t x = l[i]; if (i < w) base += x; total += x; }
+        if (threadIdx.x == 0) partials[tile] = total;
+        const uint32_t ex[IDX_LOADS] = {base + (i01 & 0xFFFFu) - c0, base + T0 + (i01 >> 16) - c1, base + T0 + T1 + (i23 & 0xFFFFu) - c2,
+                                        base + T0 + T1 + T2 + (i23 >> 16) - c3};
+        uint16_t* slot = list + tile * IDX_LIST_CAP;
+#pragma unroll
+        for (int it = 0; it < IDX_LOADS; ++it) {
+            uint32_t mm = m[it], k = ex[it];
+            const uint32_t pos0 = ((w * IDX_LOADS + it) * 64 + lane) * 16;
+            while (mm) {
+                const uint32_t b = (uint32_t)__ffs((int)mm) - 1u;
+                mm &= mm - 1;
+                if (k < IDX_LIST_CAP) slot[k] = (uint16_t)(pos0 + b); else over = true;
+                ++k;
+            }
+        }
+        if (turn + 1 < TPW) {
+#pragma unroll
+            for (int it = 0; it < IDX_LOADS; ++it) q[it] = qn[it];
         }
     }
     if (over) atomicOr(overflow, 1u);
@@ -188,8 +206,8 @@ int run_count(uq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint64_t* nblo
     if (list_form) {
         uint32_t* d_over = (uint32_t*)(ctx->idx_bitmap + nb * IDX_TILE_VECS);          // the 16 spare bytes behind the slots
         UQ_CHECK_HIP(hipMemsetAsync(d_over, 0, 4, ctx->stream));
-        census_list_kernel<<<(uint32_t)nb, IDX_THREADS, 0, ctx->stream>>>((const uint4*)(d_buf - mis), mis, nbytes, nvec, ctx->idx_partials,
-                                                                         ctx->idx_bitmap, d_over, 0);
+        census_list_kernel<CENSUS_TPW><<<(uint32_t)((nb + CENSUS_TPW - 1) / CENSUS_TPW), IDX_THREADS, 0, ctx->stream>>>((const uint4*)(d_buf - mis), mis, nbytes, nvec, ctx->idx_partials,
+                                                                         ctx->idx_bitmap, d_over, 0, nb);
     } else {
         count_newlines_kernel<<<(uint32_t)nb, IDX_THREADS, 0, ctx->stream>>>((const uint4*)(d_buf - mis), mis, nbytes, nvec, ctx->idx_partials,
                                                                             ctx->idx_bitmap);
@@ -255,8 +273,8 @@ extern "C" int uq_count_lines_chunk(uq_ctx* ctx, const uint8_t* d_buf, uint64_t 
                "uq_count_lines_chunk: a chunk must end on a 16 KiB tile boundary or with the buffer");
     const uint64_t t0 = (first_byte + mis) / IDX_TILE, t1 = first_byte + chunk_bytes == nbytes ? nb : (first_byte + chunk_bytes + mis) / IDX_TILE;
     if (t1 <= t0) return 0;
-    census_list_kernel<<<(uint32_t)(t1 - t0), IDX_THREADS, 0, ctx->stream>>>((const uint4*)(d_buf - mis), mis, nbytes, nvec, ctx->idx_partials,
-                                                                            ctx->idx_bitmap, (uint32_t*)(ctx->idx_bitmap + nb * IDX_TILE_VECS), t0);
+    census_list_kernel<CENSUS_TPW><<<(uint32_t)((t1 - t0 + CENSUS_TPW - 1) / CENSUS_TPW), IDX_THREADS, 0, ctx->stream>>>((const uint4*)(d_buf - mis), mis, nbytes, nvec, ctx->idx_partials,
+                                                                            ctx->idx_bitmap, (uint32_t*)(ctx->idx_bitmap + nb * IDX_TILE_VECS), t0, t1);
     UQ_LAUNCH_CHECK();
     return 0;
 }
