@@ -278,7 +278,7 @@ def _fuzz_case(rng):
     return b''.join(recs), flags
 
 
-@pytest.mark.parametrize('seed', range(int(os.environ.get('UQ_FUZZ_N', '48'))))      # UQ_FUZZ_N=2000 for a longer hunt
+@pytest.mark.parametrize('seed', range(int(os.environ.get('UQ_FUZZ_FROM', '0')), int(os.environ.get('UQ_FUZZ_FROM', '0')) + int(os.environ.get('UQ_FUZZ_N', '48'))))      # UQ_FUZZ_N=2000 for a longer hunt, UQ_FUZZ_FROM=25000 for seeds not hunted before
 def test_cli_fuzz_against_oracle(ctx, tmp_path, seed):
     """Differential fuzz of the whole CLI: random alphabets / bit widths / lengths / QNAME families / flag mixes."""
     fq, flags = _fuzz_case(np.random.default_rng(1000 + seed))
